@@ -1,0 +1,195 @@
+"""Context / operator / device-matrix handles over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Context:
+    """One MI355X: wraps `gsi_ctx`.  `Context(device)`; multi-GPU: one per process, then
+    `comm_init(nranks, rank, unique_id)`."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or L.load()
+        h = C.c_void_p()
+        L.check(self.lib.gsi_ctx_create(C.byref(h), int(device)), self.lib)
+        self.h = h
+        self.device = int(device)
+        self._children = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            for ch in list(self._children):
+                ch.close()
+            self.lib.gsi_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        L.check(self.lib.gsi_ctx_sync(self.h), self.lib)
+
+    # ---- multi-GPU ----
+    def unique_id(self):
+        buf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+        L.check(self.lib.gsi_comm_unique_id(buf), self.lib)
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), L.UNIQUE_ID_BYTES)
+        L.check(self.lib.gsi_ctx_comm_init(self.h, int(nranks), int(rank), buf), self.lib)
+
+    def rank(self):
+        r, n = C.c_int(), C.c_int()
+        L.check(self.lib.gsi_ctx_rank(self.h, C.byref(r), C.byref(n)), self.lib)
+        return r.value, n.value
+
+    def shard(self, m):
+        """Block-row layout the library expects: pad = ceil(m/nranks), row0 = rank*pad."""
+        r, n = self.rank()
+        pad = -(-m // n)
+        row0 = min(r * pad, m)
+        return row0, min(pad, m - row0)
+
+    # ---- measurement ----
+    def profile(self, on=True):
+        L.check(self.lib.gsi_ctx_profile(self.h, int(bool(on))), self.lib)
+
+    def phase_reset(self):
+        L.check(self.lib.gsi_ctx_phase_reset(self.h), self.lib)
+
+    def phase_times(self):
+        ms = (C.c_double * len(L.PHASES))()
+        cnt = (C.c_int64 * len(L.PHASES))()
+        L.check(self.lib.gsi_ctx_phase_times(self.h, ms, cnt), self.lib)
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(L.PHASES)}
+
+    def device_bytes(self):
+        b = C.c_int64()
+        L.check(self.lib.gsi_ctx_device_bytes(self.h, C.byref(b)), self.lib)
+        return b.value
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+        ctx._children.append(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            getattr(self.ctx.lib, self._destroy)(self.h)
+            self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Operator(_Handle):
+    """Device-resident linear operator (`gsi_op`): the duck type RandMatFact needs
+    (size, A*X, A'*X -- RandMatFact.jl:52-55,67,70,85)."""
+    _destroy = "gsi_op_destroy"
+
+    @property
+    def shape(self):
+        m, n = C.c_int64(), C.c_int64()
+        L.check(self.ctx.lib.gsi_op_size(self.h, C.byref(m), C.byref(n), None, None), self.ctx.lib)
+        return (m.value, n.value)
+
+    def size(self, i):
+        if i in (1, 2):
+            return self.shape[i - 1]
+        raise IndexError(f"there is no {i}-th dimension in a {type(self).__name__}")   # lowrank.jl:58
+
+    def _mul(self, X, trans):
+        Xf = L.fmat(X, "X")
+        m, n = self.shape
+        rows_in, rows_out = (m, n) if trans else (n, m)
+        if Xf.shape[0] != rows_in:
+            raise ValueError(f"dimension mismatch: operator is {m}x{n}, X has {Xf.shape[0]} rows")
+        Y = np.empty((rows_out, Xf.shape[1]), order="F")
+        L.check(self.ctx.lib.gsi_op_mul(self.ctx.h, self.h, int(trans), L.dptr(Xf), Xf.shape[0], Xf.shape[1],
+                                        L.dptr(Y), rows_out), self.ctx.lib)
+        return Y[:, 0].copy() if np.ndim(X) == 1 else Y
+
+    def matmul(self, X):
+        """`A * X`"""
+        return self._mul(X, 0)
+
+    def rmatmul_t(self, X):
+        """`A' * X`"""
+        return self._mul(X, 1)
+
+    __matmul__ = matmul
+
+
+def dense_operator(ctx, A):
+    """`Matrix{Float64}` operator.  With a communicator, `A` is the full matrix and only this rank's
+    block of rows is uploaded."""
+    Af = L.fmat(A, "A")
+    m, n = Af.shape
+    row0, mloc = ctx.shard(m)
+    h = C.c_void_p()
+    base = Af[row0:, :] if mloc > 0 else Af
+    L.check(ctx.lib.gsi_op_dense(ctx.h, C.byref(h), base.ctypes.data_as(L.c_dp), m, n, Af.shape[0], row0, mloc),
+            ctx.lib)
+    return Operator(ctx, h)
+
+
+def gridcov_operator(ctx, nx, ny, ell, kind=0):
+    """Synthetic covariance of an nx x ny unit grid generated in HBM.
+    kind 0: exp(-d^2/(2 ell^2)); kind 1: exp(-d/ell)."""
+    row0, mloc = ctx.shard(nx * ny)
+    h = C.c_void_p()
+    L.check(ctx.lib.gsi_op_dense_gridcov(ctx.h, C.byref(h), nx, ny, float(ell), int(kind), row0, mloc), ctx.lib)
+    return Operator(ctx, h)
+
+
+class DeviceMatrix(_Handle):
+    """Column-major Float64 matrix resident in HBM (`gsi_mat`)."""
+    _destroy = "gsi_mat_destroy"
+
+    def __init__(self, ctx, rows, cols):
+        h = C.c_void_p()
+        L.check(ctx.lib.gsi_mat_create(ctx.h, C.byref(h), int(rows), int(cols)), ctx.lib)
+        super().__init__(ctx, h)
+        self.shape = (int(rows), int(cols))
+
+    @classmethod
+    def from_host(cls, ctx, a):
+        af = L.fmat(a)
+        m = cls(ctx, *af.shape)
+        L.check(ctx.lib.gsi_mat_upload(ctx.h, m.h, L.dptr(af), af.shape[0]), ctx.lib)
+        return m
+
+    def randn(self, seed):
+        L.check(self.ctx.lib.gsi_mat_randn(self.ctx.h, self.h, int(seed)), self.ctx.lib)
+        return self
+
+    def to_host(self):
+        out = np.empty(self.shape, order="F")
+        L.check(self.ctx.lib.gsi_mat_download(self.ctx.h, self.h, L.dptr(out), self.shape[0]), self.ctx.lib)
+        return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on device 0 (LOCAL_RANK if set), created on first use."""
+    global _default_ctx
+    if _default_ctx is None or _default_ctx.h is None:
+        import os
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

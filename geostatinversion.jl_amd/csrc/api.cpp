@@ -1,0 +1,485 @@
+// api.cpp -- the C ABI of include/gsi_hip.h: argument checking, host<->device staging and
+// error translation around pipeline.cpp.  No C++ exception crosses the boundary.
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+#include "../../include/gsi_hip.h"
+#include "pipeline.hpp"
+
+using namespace gsi;
+
+struct gsi_ctx {
+  Context c;
+};
+struct gsi_op {
+  Operator op;
+};
+struct gsi_mat {
+  gsi_ctx* ctx;
+  Buf buf;
+  int64_t rows, cols;
+};
+
+namespace {
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return GSI_OK;
+  } catch (const Error& e) {
+    return fail(e.code, e.what());
+  } catch (const std::bad_alloc&) {
+    return fail(GSI_ERR_OOM, "host allocation failed");
+  } catch (const std::exception& e) {
+    return fail(GSI_ERR_INTERNAL, e.what());
+  } catch (...) {
+    return fail(GSI_ERR_INTERNAL, "unknown error");
+  }
+}
+
+#define REQUIRE(cond, msg) \
+  do { if (!(cond)) throw Error(GSI_ERR_ARG, msg); } while (0)
+
+void check_shard(Context& c, int64_t m, int64_t row0, int64_t mloc) {
+  REQUIRE(row0 >= 0 && mloc >= 0 && row0 + mloc <= m, "row shard out of range");
+  if (c.nranks() == 1) {
+    REQUIRE(row0 == 0 && mloc == m, "single-rank context: the operator must hold all rows");
+  } else {
+    int64_t r0, ml;
+    default_shard(m, c.nranks(), c.rank(), &r0, &ml);
+    REQUIRE(r0 == row0 && ml == mloc,
+            "multi-rank operators use the block-row layout: pad = ceil(m/nranks), row0 = rank*pad");
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int gsi_version(void) { return GSI_VERSION; }
+const char* gsi_last_error(void) { return g_last_error.c_str(); }
+const char* gsi_backend_name(void) { return backend_name(); }
+
+int gsi_ctx_create(gsi_ctx** ctx, int device_id) {
+  return guarded([&] {
+    REQUIRE(ctx != nullptr, "ctx is NULL");
+    *ctx = nullptr;
+    gsi_ctx* c = new gsi_ctx();
+    try {
+      c->c.be.reset(make_backend(device_id));
+    } catch (...) {
+      delete c;
+      throw;
+    }
+    *ctx = c;
+  });
+}
+
+int gsi_ctx_destroy(gsi_ctx* ctx) {
+  return guarded([&] {
+    if (!ctx) return;
+    ctx->c.comm.reset();
+    ctx->c.be.reset();
+    delete ctx;
+  });
+}
+
+int gsi_ctx_sync(gsi_ctx* ctx) {
+  return guarded([&] {
+    REQUIRE(ctx, "ctx is NULL");
+    ctx->c.be->sync();
+  });
+}
+
+int gsi_comm_unique_id(void* id_out) {
+  return guarded([&] {
+    REQUIRE(id_out, "id_out is NULL");
+    comm_unique_id(id_out);
+  });
+}
+
+int gsi_ctx_comm_init(gsi_ctx* ctx, int nranks, int rank, const void* id) {
+  return guarded([&] {
+    REQUIRE(ctx && id, "NULL argument");
+    REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
+    REQUIRE(!ctx->c.comm, "communicator already initialised");
+    if (nranks == 1) return;
+    ctx->c.comm.reset(make_comm(ctx->c.be.get(), nranks, rank, id));
+  });
+}
+
+int gsi_ctx_rank(gsi_ctx* ctx, int* rank, int* nranks) {
+  return guarded([&] {
+    REQUIRE(ctx, "ctx is NULL");
+    if (rank) *rank = ctx->c.rank();
+    if (nranks) *nranks = ctx->c.nranks();
+  });
+}
+
+int gsi_op_dense(gsi_ctx* ctx, gsi_op** op, const double* A_rows, int64_t m, int64_t n, int64_t lda,
+                 int64_t row0, int64_t m_local) {
+  return guarded([&] {
+    REQUIRE(ctx && op && A_rows, "NULL argument");
+    *op = nullptr;
+    REQUIRE(m >= 1 && n >= 1 && lda >= m_local && lda >= 1, "bad matrix shape");
+    check_shard(ctx->c, m, row0, m_local);
+    std::unique_ptr<gsi_op> o(new gsi_op());
+    Operator& A = o->op;
+    A.ctx = &ctx->c; A.kind = OP_DENSE; A.m = m; A.n = n; A.row0 = row0; A.mloc = m_local;
+    A.ld = m_local > 0 ? m_local : 1;
+    A.data = Buf(ctx->c.be.get(), (size_t)A.ld * n);
+    ctx->c.be->upload2d(A.data.p, A.ld, A_rows, lda, m_local, n);
+    *op = o.release();
+  });
+}
+
+int gsi_op_lowrank(gsi_ctx* ctx, gsi_op** op, const double* samples, int64_t n, int64_t N, int64_t lds,
+                   int center, int64_t row0, int64_t n_local) {
+  return guarded([&] {
+    REQUIRE(ctx && op && samples, "NULL argument");
+    *op = nullptr;
+    REQUIRE(n >= 1 && N >= 2 && lds >= n_local && lds >= 1, "bad sample matrix shape (need N >= 2 samples)");
+    check_shard(ctx->c, n, row0, n_local);
+    std::unique_ptr<gsi_op> o(new gsi_op());
+    Operator& A = o->op;
+    A.ctx = &ctx->c; A.kind = OP_LOWRANK; A.m = n; A.n = n; A.row0 = row0; A.mloc = n_local; A.N = N;
+    A.ld = n_local > 0 ? n_local : 1;
+    A.data = Buf(ctx->c.be.get(), (size_t)A.ld * N);
+    ctx->c.be->upload2d(A.data.p, A.ld, samples, lds, n_local, N);
+    if (center) ctx->c.be->center_rows(A.data.p, n_local, N, A.ld);   // lowrank.jl:17-27
+    *op = o.release();
+  });
+}
+
+int gsi_op_dense_gridcov(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, double ell, int kind,
+                         int64_t row0, int64_t m_local) {
+  return guarded([&] {
+    REQUIRE(ctx && op, "NULL argument");
+    *op = nullptr;
+    REQUIRE(nx >= 1 && ny >= 1 && ell > 0 && (kind == 0 || kind == 1), "bad grid covariance parameters");
+    const int64_t n = nx * ny;
+    check_shard(ctx->c, n, row0, m_local);
+    std::unique_ptr<gsi_op> o(new gsi_op());
+    Operator& A = o->op;
+    A.ctx = &ctx->c; A.kind = OP_DENSE; A.m = n; A.n = n; A.row0 = row0; A.mloc = m_local;
+    A.ld = m_local > 0 ? m_local : 1;
+    A.data = Buf(ctx->c.be.get(), (size_t)A.ld * n);
+    ctx->c.be->fill_gridcov(A.data.p, A.ld, nx, ny, ell, kind, row0, m_local);
+    *op = o.release();
+  });
+}
+
+int gsi_op_destroy(gsi_op* op) {
+  return guarded([&] { delete op; });
+}
+
+int gsi_op_size(const gsi_op* op, int64_t* m, int64_t* n, int64_t* row0, int64_t* m_local) {
+  return guarded([&] {
+    REQUIRE(op, "op is NULL");
+    if (m) *m = op->op.m;
+    if (n) *n = op->op.n;
+    if (row0) *row0 = op->op.row0;
+    if (m_local) *m_local = op->op.mloc;
+  });
+}
+
+int gsi_op_mul(gsi_ctx* ctx, const gsi_op* op, int trans, const double* X, int64_t ldx, int64_t l, double* Y,
+               int64_t ldy) {
+  return guarded([&] {
+    REQUIRE(ctx && op && X && Y, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c, "operator belongs to another context");
+    const Operator& A = op->op;
+    Backend* be = ctx->c.be.get();
+    REQUIRE(l >= 1, "need at least one column");
+    const int64_t rows_in = trans ? A.m : A.n, rows_out = trans ? A.n : A.m;
+    REQUIRE(ldx >= rows_in && ldy >= rows_out, "leading dimension too small");
+    Buf Xd(be, (size_t)rows_in * l), Yd(be, (size_t)rows_out * l);
+    be->upload2d(Xd.p, rows_in, X, ldx, rows_in, l);
+    if (!trans) {
+      Buf Yloc(be, (size_t)(A.mloc > 0 ? A.mloc : 1) * l);
+      op_mul(A, Xd.p, A.n, l, Yloc.p, A.mloc);
+      gather_rows(ctx->c, A, Yloc.p, A.mloc, l, Yd.p);
+    } else {
+      op_mul_t(A, Xd.p + A.row0, A.m, l, Yd.p, A.n);
+    }
+    be->download2d(Y, ldy, Yd.p, rows_out, rows_out, l);
+    check_async_errors(ctx->c);
+  });
+}
+
+int gsi_rangefinder(gsi_ctx* ctx, const gsi_op* op, const double* Omega, int64_t l, int64_t numiterations,
+                    double* Q_out) {
+  return guarded([&] {
+    REQUIRE(ctx && op && Omega && Q_out, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c, "operator belongs to another context");
+    const Operator& A = op->op;
+    Backend* be = ctx->c.be.get();
+    REQUIRE(l >= 1, "l must be positive");
+    Buf Om(be, (size_t)A.n * l);
+    be->upload2d(Om.p, A.n, Omega, A.n, A.n, l);
+    Buf Qloc = rangefinder(A, Om.p, l, numiterations);
+    Buf Qfull(be, (size_t)A.m * l);
+    gather_rows(ctx->c, A, Qloc.p, A.mloc, l, Qfull.p);
+    be->download2d(Q_out, A.m, Qfull.p, A.m, A.m, l);
+    check_async_errors(ctx->c);
+  });
+}
+
+int gsi_randsvd(gsi_ctx* ctx, const gsi_op* op, const double* Omega, int64_t K, int64_t p, int64_t q,
+                double* Z_out, double* S_out) {
+  return guarded([&] {
+    REQUIRE(ctx && op && Omega && Z_out, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c, "operator belongs to another context");
+    REQUIRE(K >= 0 && p >= 0 && K + p >= 1, "need K >= 0, p >= 0, K + p >= 1");
+    const Operator& A = op->op;
+    Backend* be = ctx->c.be.get();
+    const int64_t l = K + p;
+    Buf Om(be, (size_t)A.n * l), Z(be, (size_t)A.n * l), S(be, (size_t)l);
+    be->upload2d(Om.p, A.n, Omega, A.n, A.n, l);
+    randsvd(A, Om.p, K, p, q, Z.p, S.p);
+    be->download2d(Z_out, A.n, Z.p, A.n, A.n, l);
+    if (S_out) be->download2d(S_out, l, S.p, l, l, 1);
+    check_async_errors(ctx->c);
+  });
+}
+
+int gsi_eig_nystrom(gsi_ctx* ctx, const gsi_op* op, const double* Q, int64_t j, double* U_out,
+                    double* Sigma_out) {
+  return guarded([&] {
+    REQUIRE(ctx && op && Q && U_out && Sigma_out, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c, "operator belongs to another context");
+    const Operator& A = op->op;
+    Backend* be = ctx->c.be.get();
+    REQUIRE(j >= 1 && j <= A.n, "bad number of columns in Q");
+    Buf Qd(be, (size_t)A.n * j), U(be, (size_t)A.m * j), S(be, (size_t)j);
+    be->upload2d(Qd.p, A.n, Q, A.n, A.n, j);
+    eig_nystrom(A, Qd.p, j, U.p, S.p);
+    be->download2d(U_out, A.m, U.p, A.m, A.m, j);
+    be->download2d(Sigma_out, j, S.p, j, j, 1);
+    check_async_errors(ctx->c);
+  });
+}
+
+int gsi_rangefinder_adaptive(gsi_ctx* ctx, const gsi_op* op, gsi_randn_fn randn, void* user, double epsilon,
+                             int64_t r, double* Q_out, int64_t* ncols_out) {
+  return guarded([&] {
+    REQUIRE(ctx && op && randn && Q_out && ncols_out, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c, "operator belongs to another context");
+    *ncols_out = rangefinder_adaptive(op->op, randn, user, epsilon, r, Q_out);
+    check_async_errors(ctx->c);
+  });
+}
+
+// ---- device-resident matrices ------------------------------------------------------
+int gsi_mat_create(gsi_ctx* ctx, gsi_mat** mat, int64_t rows, int64_t cols) {
+  return guarded([&] {
+    REQUIRE(ctx && mat, "NULL argument");
+    *mat = nullptr;
+    REQUIRE(rows >= 1 && cols >= 1, "bad shape");
+    std::unique_ptr<gsi_mat> m(new gsi_mat());
+    m->ctx = ctx; m->rows = rows; m->cols = cols;
+    m->buf = Buf(ctx->c.be.get(), (size_t)rows * cols);
+    *mat = m.release();
+  });
+}
+int gsi_mat_destroy(gsi_mat* mat) {
+  return guarded([&] { delete mat; });
+}
+int gsi_mat_upload(gsi_ctx* ctx, gsi_mat* mat, const double* host, int64_t ldh) {
+  return guarded([&] {
+    REQUIRE(ctx && mat && host && mat->ctx == ctx, "bad argument");
+    REQUIRE(ldh >= mat->rows, "leading dimension too small");
+    ctx->c.be->upload2d(mat->buf.p, mat->rows, host, ldh, mat->rows, mat->cols);
+  });
+}
+int gsi_mat_download(gsi_ctx* ctx, const gsi_mat* mat, double* host, int64_t ldh) {
+  return guarded([&] {
+    REQUIRE(ctx && mat && host && mat->ctx == ctx, "bad argument");
+    REQUIRE(ldh >= mat->rows, "leading dimension too small");
+    ctx->c.be->download2d(host, ldh, mat->buf.p, mat->rows, mat->rows, mat->cols);
+  });
+}
+int gsi_mat_randn(gsi_ctx* ctx, gsi_mat* mat, uint64_t seed) {
+  return guarded([&] {
+    REQUIRE(ctx && mat && mat->ctx == ctx, "bad argument");
+    ctx->c.be->randn(mat->buf.p, (size_t)mat->rows * mat->cols, seed);
+  });
+}
+
+int gsi_rangefinder_dev(gsi_ctx* ctx, const gsi_op* op, const gsi_mat* Omega, int64_t numiterations,
+                        gsi_mat* Q) {
+  return guarded([&] {
+    REQUIRE(ctx && op && Omega && Q, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c && Omega->ctx == ctx && Q->ctx == ctx, "objects belong to another context");
+    const Operator& A = op->op;
+    const int64_t l = Omega->cols;
+    REQUIRE(Omega->rows == A.n, "Omega must have size(A,2) rows");
+    REQUIRE(Q->rows == A.m && Q->cols == l, "Q must be size(A,1) x l");
+    Buf Qloc = rangefinder(A, Omega->buf.p, l, numiterations);
+    gather_rows(ctx->c, A, Qloc.p, A.mloc, l, Q->buf.p);
+    check_async_errors(ctx->c);
+  });
+}
+
+int gsi_randsvd_dev(gsi_ctx* ctx, const gsi_op* op, const gsi_mat* Omega, int64_t K, int64_t p, int64_t q,
+                    gsi_mat* Z, gsi_mat* S) {
+  return guarded([&] {
+    REQUIRE(ctx && op && Omega && Z, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c && Omega->ctx == ctx && Z->ctx == ctx, "objects belong to another context");
+    REQUIRE(K >= 0 && p >= 0 && K + p >= 1, "need K >= 0, p >= 0, K + p >= 1");
+    const Operator& A = op->op;
+    const int64_t l = K + p;
+    REQUIRE(Omega->rows == A.n && Omega->cols == l, "Omega must be size(A,2) x (K+p)");
+    REQUIRE(Z->rows == A.n && Z->cols == l, "Z must be size(A,2) x (K+p)");
+    Backend* be = ctx->c.be.get();
+    Buf Stmp;
+    double* Sp;
+    if (S) {
+      REQUIRE(S->ctx == ctx && S->rows * S->cols == l, "S must hold K+p values");
+      Sp = S->buf.p;
+    } else {
+      Stmp = Buf(be, (size_t)l);
+      Sp = Stmp.p;
+    }
+    randsvd(A, Omega->buf.p, K, p, q, Z->buf.p, Sp);
+    check_async_errors(ctx->c);
+  });
+}
+
+// ---- panel primitives ----------------------------------------------------------------
+int gsi_lu_L(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double* L_out, int32_t* ipiv_out) {
+  return guarded([&] {
+    REQUIRE(ctx && Y && L_out, "NULL argument");
+    REQUIRE(m >= 1 && l >= 1 && l <= m, "lu_L: need 1 <= l <= m (tall panel)");
+    Backend* be = ctx->c.be.get();
+    Buf P(be, (size_t)m * l);
+    be->upload2d(P.p, m, Y, m, m, l);
+    be->lu_L(P.p, m, l, m, ipiv_out);
+    be->download2d(L_out, m, P.p, m, m, l);
+    check_async_errors(ctx->c);
+  });
+}
+
+int gsi_qr_thinQ(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double* Q_out, double* R_out) {
+  return guarded([&] {
+    REQUIRE(ctx && Y && Q_out, "NULL argument");
+    REQUIRE(m >= 1 && l >= 1 && l <= m, "qr_thinQ: need 1 <= l <= m (tall panel)");
+    Backend* be = ctx->c.be.get();
+    Buf P(be, (size_t)m * l), R(be, (size_t)l * l);
+    be->upload2d(P.p, m, Y, m, m, l);
+    be->qr_thinQ(P.p, m, l, m, R.p);
+    be->download2d(Q_out, m, P.p, m, m, l);
+    if (R_out) be->download2d(R_out, l, R.p, l, l, l);
+    check_async_errors(ctx->c);
+  });
+}
+
+int gsi_svd_tall(gsi_ctx* ctx, const double* W, int64_t n, int64_t l, double* V_out, double* S_out) {
+  return guarded([&] {
+    REQUIRE(ctx && W && V_out && S_out, "NULL argument");
+    REQUIRE(n >= 1 && l >= 1 && l <= n, "svd_tall: need 1 <= l <= n");
+    Backend* be = ctx->c.be.get();
+    Buf Wd(be, (size_t)n * l), V(be, (size_t)n * l), S(be, (size_t)l);
+    be->upload2d(Wd.p, n, W, n, n, l);
+    svd_tall(ctx->c, Wd.p, n, l, -1, V.p, S.p);
+    be->download2d(V_out, n, V.p, n, n, l);
+    be->download2d(S_out, l, S.p, l, l, 1);
+    check_async_errors(ctx->c);
+  });
+}
+
+int gsi_gemm(gsi_ctx* ctx, int trans, int64_t m, int64_t l, int64_t k, double alpha, const double* A,
+             int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc) {
+  return guarded([&] {
+    REQUIRE(ctx && A && B && C, "NULL argument");
+    REQUIRE(m >= 1 && l >= 1 && k >= 1, "bad shape");
+    const int64_t ar = trans ? k : m, ac = trans ? m : k;
+    REQUIRE(lda >= ar && ldb >= k && ldc >= m, "leading dimension too small");
+    Backend* be = ctx->c.be.get();
+    Buf Ad(be, (size_t)ar * ac), Bd(be, (size_t)k * l), Cd(be, (size_t)m * l);
+    be->upload2d(Ad.p, ar, A, lda, ar, ac);
+    be->upload2d(Bd.p, k, B, ldb, k, l);
+    if (trans) be->gemm_tn(m, l, k, alpha, Ad.p, ar, Bd.p, k, 0.0, Cd.p, m);
+    else be->gemm_nn(m, l, k, alpha, Ad.p, ar, Bd.p, k, 0.0, Cd.p, m);
+    be->download2d(C, ldc, Cd.p, m, m, l);
+    check_async_errors(ctx->c);
+  });
+}
+
+// ---- consumers -----------------------------------------------------------------------
+int gsi_pcga_params(gsi_ctx* ctx, const double* Z, int64_t n, int64_t K, const double* s, const double* X,
+                    double delta, double* out) {
+  return guarded([&] {
+    REQUIRE(ctx && Z && s && X && out, "NULL argument");
+    REQUIRE(n >= 1 && K >= 1, "bad shape");
+    Backend* be = ctx->c.be.get();
+    // out[:, i] = s + delta * col_i,  cols = [Z, X, s, 0]   as one rank-1-plus-scale product:
+    // built from the gemm kernel: out = [Z X s 0] * delta + s * ones'
+    Buf M(be, (size_t)n * (K + 3)), O(be, (size_t)n * (K + 3)), sv(be, (size_t)n);
+    be->upload2d(M.p, n, Z, n, n, K);
+    be->upload2d(M.p + (size_t)n * K, n, X, n, n, 1);
+    be->upload2d(M.p + (size_t)n * (K + 1), n, s, n, n, 1);
+    be->fill_zero(M.p + (size_t)n * (K + 2), (size_t)n);
+    be->upload2d(sv.p, n, s, n, n, 1);
+    for (int64_t c = 0; c < K + 3; ++c) {
+      be->scal_copy(n, 1.0, sv.p, O.p + (size_t)n * c);
+      be->axpy(n, delta, M.p + (size_t)n * c, O.p + (size_t)n * c);
+    }
+    be->download2d(out, n, O.p, n, n, K + 3);
+  });
+}
+
+int gsi_pcga_update(gsi_ctx* ctx, const double* Z, int64_t n, int64_t K, const double* X, double beta_bar,
+                    const double* etas, int64_t nobs, const double* xi_bar, double* s_out) {
+  return guarded([&] {
+    REQUIRE(ctx && Z && X && etas && xi_bar && s_out, "NULL argument");
+    REQUIRE(n >= 1 && K >= 1 && nobs >= 1, "bad shape");
+    Backend* be = ctx->c.be.get();
+    Buf Zd(be, (size_t)n * K), E(be, (size_t)nobs * K), xb(be, (size_t)nobs), w(be, (size_t)K), sd(be, (size_t)n),
+        Xd(be, (size_t)n);
+    be->upload2d(Zd.p, n, Z, n, n, K);
+    be->upload2d(E.p, nobs, etas, nobs, nobs, K);
+    be->upload2d(xb.p, nobs, xi_bar, nobs, nobs, 1);
+    be->upload2d(Xd.p, n, X, n, n, 1);
+    be->gemm_tn(K, 1, nobs, 1.0, E.p, nobs, xb.p, nobs, 0.0, w.p, K);   // w_i = dot(eta_i, xi_bar)
+    be->scal_copy(n, beta_bar, Xd.p, sd.p);                             // s = X * beta_bar
+    be->gemm_nn(n, 1, K, 1.0, Zd.p, n, w.p, K, 1.0, sd.p, n);           // s += sum_i xis[i] * w_i
+    be->download2d(s_out, n, sd.p, n, n, 1);
+  });
+}
+
+// ---- measurement ---------------------------------------------------------------------
+int gsi_ctx_profile(gsi_ctx* ctx, int enable) {
+  return guarded([&] {
+    REQUIRE(ctx, "ctx is NULL");
+    ctx->c.be->profile(enable != 0);
+  });
+}
+int gsi_ctx_phase_reset(gsi_ctx* ctx) {
+  return guarded([&] {
+    REQUIRE(ctx, "ctx is NULL");
+    ctx->c.be->phase_reset();
+  });
+}
+int gsi_ctx_phase_times(gsi_ctx* ctx, double* ms_out, int64_t* count_out) {
+  return guarded([&] {
+    REQUIRE(ctx && ms_out && count_out, "NULL argument");
+    static_assert((int)PH_COUNT == GSI_NUM_PHASES, "phase tables out of sync");
+    ctx->c.be->phase_times(ms_out, count_out);
+  });
+}
+int gsi_ctx_device_bytes(gsi_ctx* ctx, int64_t* bytes) {
+  return guarded([&] {
+    REQUIRE(ctx && bytes, "NULL argument");
+    *bytes = ctx->c.be->bytes_in_use();
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// backend.hpp -- the seam between the host-side algorithm (pipeline.cpp: the order of
+// operations of RandMatFact.jl, row-sharded) and the code that executes each operation.
+// The product library links exactly one implementation, the HIP/gfx950 one
+// (hip_backend.hip).  A second implementation over the C oracle exists ONLY in the test
+// tree (oracle/cpu_backend.cpp -> oracle/_build/libgsi_cpuref.so) so that the sharded
+// pipeline and the C ABI can be exercised on machines without a GPU; the product loader
+// never opens it.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+namespace gsi {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& msg) : std::runtime_error(msg), code(c) {}
+};
+
+enum Phase : int {
+  PH_GEMM_N = 0, PH_GEMM_T = 1, PH_LU = 2, PH_QR = 3, PH_SVD = 4, PH_SMALL_GEMM = 5,
+  PH_COMM = 6, PH_OTHER = 7, PH_COUNT = 8
+};
+
+// All pointers below are "backend memory" (HBM for the HIP backend), column-major fp64.
+class Backend {
+ public:
+  virtual ~Backend() {}
+  virtual const char* name() const = 0;
+
+  // ---- memory ----
+  virtual double* alloc(size_t count) = 0;  // throws Error(GSI_ERR_OOM)
+  virtual void release(double* p) = 0;
+  virtual int64_t bytes_in_use() const = 0;
+  virtual void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) = 0;
+  virtual void download2d(double* host, int64_t ldh, const double* src, int64_t lds, int64_t rows, int64_t cols) = 0;
+  virtual void copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) = 0;
+  virtual void fill_zero(double* p, size_t count) = 0;
+  virtual void sync() = 0;
+
+  // ---- products ----
+  // C(m x l) = alpha * A(m x k) * B(k x l) + beta * C      beta in {0, 1}
+  virtual void gemm_nn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double beta, double* C, int64_t ldc) = 0;
+  // C(m x l) = alpha * A'(m x k) * B(k x l) + beta * C,  A stored k x m
+  virtual void gemm_tn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double beta, double* C, int64_t ldc) = 0;
+
+  // ---- panel factorizations, in place ----
+  // Y (m x l, ld) <- L of lu(Y) in pivoted row order; ipiv (device int32[l]) may be null.
+  // Sets *singular_flag (backend int, see flags()) to j+1 on an exactly zero pivot.
+  virtual void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv_host_or_null) = 0;
+  // Y (m x l) <- thin Q; R (l x l, ld l) <- upper triangular factor if R != null
+  virtual void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R) = 0;
+  // G (l x l, ld l), columns orthogonalised in place by one-sided Jacobi; on return
+  // U (l x l) = left singular vectors sorted by descending S, S (l) singular values.
+  virtual void svd_small(double* G, int64_t l, double* U, double* S) = 0;
+  // upper Cholesky factor of the symmetric j x j B (upper triangle read), in place
+  virtual void chol_upper(double* B, int64_t j) = 0;
+  // F (m x j) <- F * inv(C), C upper triangular j x j
+  virtual void trsm_right_upper(double* F, int64_t m, int64_t j, int64_t ldf, const double* C) = 0;
+
+  // ---- small fused helpers ----
+  // U (l x l) <- U * diag(sqrt(S_i) for i < K, 0 otherwise)
+  virtual void scale_cols_sqrt(double* U, int64_t l, const double* S, int64_t K) = 0;
+  // rows of S (n x N, ld): subtract the mean over the N columns (lowrank.jl:17-27)
+  virtual void center_rows(double* S, int64_t n, int64_t N, int64_t ld) = 0;
+  virtual void randn(double* p, size_t count, uint64_t seed) = 0;
+  // synthetic covariance rows [row0,row0+mloc) of an (nx*ny)^2 grid covariance
+  virtual void fill_gridcov(double* A, int64_t lda, int64_t nx, int64_t ny, double ell, int kind,
+                            int64_t row0, int64_t mloc) = 0;
+  // column norms of Y (m x c) -> host array
+  virtual void colnorms(const double* Y, int64_t m, int64_t c, int64_t ld, double* host_out) = 0;
+  // y <- y - Q (Q' y) for Q m x j (classical Gram-Schmidt step of Alg 4.2), y length m
+  // and out = y/||y|| if normalize_into != null
+  virtual void axpy(int64_t n, double a, const double* x, double* y) = 0;
+  virtual double dot(int64_t n, const double* x, const double* y) = 0;
+  virtual double nrm2(int64_t n, const double* x) = 0;
+  virtual void scal_copy(int64_t n, double a, const double* x, double* y) = 0;  // y = a*x
+
+  // error flags raised asynchronously by kernels (zero pivot, non-posdef); checked and
+  // cleared by the pipeline at the end of each entry point. Returns GSI_* code or 0.
+  virtual int take_error(std::string* msg) = 0;
+
+  // ---- profiling ----
+  virtual void profile(bool on) = 0;
+  virtual void phase_begin(Phase p) = 0;
+  virtual void phase_end(Phase p) = 0;
+  virtual void phase_reset() = 0;
+  virtual void phase_times(double* ms, int64_t* counts) = 0;
+};
+
+class Comm {
+ public:
+  int rank = 0, nranks = 1;
+  virtual ~Comm() {}
+  virtual void allreduce_sum(double* buf, size_t count) = 0;
+  // every rank contributes `count` doubles; recv holds nranks*count, rank-major
+  virtual void allgather(const double* send, double* recv, size_t count) = 0;
+};
+
+// Provided by whichever backend is linked into the library.
+Backend* make_backend(int device_id);
+Comm* make_comm(Backend* be, int nranks, int rank, const void* unique_id);
+void comm_unique_id(void* id_out);
+const char* backend_name();
+
+struct ScopedPhase {
+  Backend* be; Phase p;
+  ScopedPhase(Backend* b, Phase ph) : be(b), p(ph) { be->phase_begin(p); }
+  ~ScopedPhase() { be->phase_end(p); }
+};
+
+}  // namespace gsi

@@ -1,0 +1,443 @@
+// hip_backend.hip -- the gfx950 implementation of gsi::Backend / gsi::Comm: one HIP stream
+// per context, every operation enqueued on it (no host round trips except where the
+// algorithm needs a scalar), workspaces grown on demand, RCCL for the collectives.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/gsi_hip.h"
+#include "backend.hpp"
+#include "hip_common.hpp"
+
+namespace gsi {
+
+#define HIP_CHECK(expr)                                                                            \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      throw Error(_e == hipErrorOutOfMemory ? GSI_ERR_OOM : GSI_ERR_HIP,                            \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                               \
+  } while (0)
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+class HipBackend : public Backend {
+ public:
+  explicit HipBackend(int device) : device_(device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+      throw Error(GSI_ERR_HIP, "no HIP device visible (libgsi_hip needs an AMD GPU; there is no CPU fallback)");
+    if (device < 0 || device >= count) throw Error(GSI_ERR_ARG, "device id out of range");
+    HIP_CHECK(hipSetDevice(device_));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device_));
+    arch_ = prop.gcnArchName;
+    if (arch_.find("gfx950") == std::string::npos)
+      throw Error(GSI_ERR_HIP, "libgsi_hip is built for gfx950 (MI355X); device reports " + arch_);
+    HIP_CHECK(hipStreamCreate(&st_));
+    HIP_CHECK(hipMalloc(&flags_, 16 * sizeof(int32_t)));
+    HIP_CHECK(hipMemsetAsync(flags_, 0, 16 * sizeof(int32_t), st_));
+    HIP_CHECK(hipMalloc(&scal_, 64 * sizeof(double)));
+  }
+  ~HipBackend() override {
+    hipSetDevice(device_);
+    hipStreamSynchronize(st_);
+    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_}) if (b->p) hipFree(b->p);
+    for (auto& ev : ev_pool_) hipEventDestroy(ev);
+    for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    hipFree(flags_);
+    hipFree(scal_);
+    hipStreamDestroy(st_);
+  }
+  const char* name() const override { return "hip-gfx950"; }
+  hipStream_t stream() const { return st_; }
+  void bind() { hipSetDevice(device_); }
+
+  // ---- memory ----
+  double* alloc(size_t count) override {
+    bind();
+    void* p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&p, count * sizeof(double));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      throw Error(GSI_ERR_OOM, "hipMalloc of " + std::to_string(count * sizeof(double)) + " bytes failed: " +
+                                   hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> g(mu_);
+    sizes_.push_back({p, count * sizeof(double)});
+    in_use_ += (int64_t)(count * sizeof(double));
+    return (double*)p;
+  }
+  void release(double* p) override {
+    if (!p) return;
+    bind();
+    hipStreamSynchronize(st_);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (size_t i = 0; i < sizes_.size(); ++i)
+        if (sizes_[i].p == p) {
+          in_use_ -= (int64_t)sizes_[i].bytes;
+          sizes_[i] = sizes_.back();
+          sizes_.pop_back();
+          break;
+        }
+    }
+    hipFree(p);
+  }
+  int64_t bytes_in_use() const override {
+    return in_use_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes);
+  }
+  void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) override {
+    if (rows <= 0 || cols <= 0) return;
+    bind();
+    HIP_CHECK(hipMemcpy2DAsync(dst, ldd * sizeof(double), host, ldh * sizeof(double), rows * sizeof(double),
+                               cols, hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));  // the caller may reuse / free the host buffer on return
+  }
+  void download2d(double* host, int64_t ldh, const double* src, int64_t lds, int64_t rows, int64_t cols) override {
+    if (rows <= 0 || cols <= 0) return;
+    bind();
+    HIP_CHECK(hipMemcpy2DAsync(host, ldh * sizeof(double), src, lds * sizeof(double), rows * sizeof(double),
+                               cols, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+  }
+  void copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) override {
+    if (rows <= 0 || cols <= 0) return;
+    bind();
+    HIP_CHECK(hipMemcpy2DAsync(dst, ldd * sizeof(double), src, lds * sizeof(double), rows * sizeof(double),
+                               cols, hipMemcpyDeviceToDevice, st_));
+  }
+  void fill_zero(double* p, size_t count) override {
+    bind();
+    HIP_CHECK(hipMemsetAsync(p, 0, count * sizeof(double), st_));
+  }
+  void sync() override {
+    bind();
+    HIP_CHECK(hipStreamSynchronize(st_));
+  }
+
+  // ---- products ----
+  void gemm_nn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda, const double* B,
+               int64_t ldb, double beta, double* C, int64_t ldc) override {
+    bind();
+    double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, k));
+    hipk::gemm_f64(st_, false, m, l, k, alpha, A, lda, B, ldb, beta, C, ldc, ws);
+    check_launch("gemm_nn");
+  }
+  void gemm_tn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda, const double* B,
+               int64_t ldb, double beta, double* C, int64_t ldc) override {
+    bind();
+    double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, k));
+    hipk::gemm_f64(st_, true, m, l, k, alpha, A, lda, B, ldb, beta, C, ldc, ws);
+    check_launch("gemm_tn");
+  }
+
+  // ---- panels ----
+  void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv_host) override {
+    bind();
+    const int64_t nb = hipk::lu_max_blocks(m);
+    const size_t need = sizeof(double) * (hipk::LU_NB + nb) + sizeof(int64_t) * nb + sizeof(int32_t) * (l + 4) + 64;
+    grow(ws_lu_, need);
+    char* base = (char*)ws_lu_.p;
+    hipk::LuWork w;
+    w.urow = (double*)base; base += sizeof(double) * hipk::LU_NB;
+    w.pval = (double*)base; base += sizeof(double) * nb;
+    w.pidx = (int64_t*)base; base += sizeof(int64_t) * nb;
+    w.ipiv = (int32_t*)base;
+    w.info = flags_ + 0;
+    w.maxblocks = nb;
+    // trailing updates: M <= m, L <= l, K = LU_NB  (never split) -> no slab workspace needed
+    double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, hipk::LU_NB));
+    hipk::lu_L(st_, Y, m, l, ld, w, ws);
+    check_launch("lu_L");
+    if (ipiv_host) {
+      HIP_CHECK(hipMemcpyAsync(ipiv_host, w.ipiv, sizeof(int32_t) * l, hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+    }
+  }
+  void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R) override {
+    bind();
+    const int64_t nb = hipk::qr_max_blocks(m);
+    const int NB = hipk::QR_NB;
+    const int64_t npan = (l + NB - 1) / NB;
+    size_t cnt = 0;
+    auto take = [&](size_t c) { size_t o = cnt; cnt += (c + 7) & ~(size_t)7; return o; };
+    const size_t o_coef = take(2 + NB + 2), o_part = take((size_t)nb * NB), o_tau = take(l),
+                 o_T = take((size_t)npan * NB * NB), o_G = take(NB * NB), o_V = take((size_t)m * NB),
+                 o_Wt = take((size_t)l * NB), o_W2 = take((size_t)l * NB), o_Q = take((size_t)m * l);
+    grow(ws_qr_, cnt * sizeof(double));
+    double* base = (double*)ws_qr_.p;
+    hipk::QrWork w;
+    w.coef = base + o_coef; w.part = base + o_part; w.tau = base + o_tau; w.T = base + o_T; w.G = base + o_G;
+    w.Vbuf = base + o_V; w.Wt = base + o_Wt; w.W2 = base + o_W2; w.Qo = base + o_Q; w.maxblocks = nb;
+    // gemm shapes inside: (t x NB, K = m), (NB x NB, K = m), (m x t, K = NB)
+    size_t g1 = hipk::gemm_workspace_doubles(l, NB, m);
+    size_t g2 = hipk::gemm_workspace_doubles(NB, NB, m);
+    size_t g3 = 0;
+    for (int64_t t = NB; t <= l; t += NB) {
+      size_t g = hipk::gemm_workspace_doubles(t, NB, m);
+      if (g > g3) g3 = g;
+    }
+    size_t gmax = g1 > g2 ? g1 : g2;
+    if (g3 > gmax) gmax = g3;
+    double* ws = gemm_ws(gmax + 64);
+    hipk::qr_thinQ(st_, Y, m, l, ld, R, w, ws);
+    check_launch("qr_thinQ");
+  }
+  void svd_small(double* G, int64_t l, double* U, double* S) override {
+    bind();
+    if (l > 600) throw Error(GSI_ERR_ARG, "sketch width l = K+p > 600 is not supported by the LDS-resident block Jacobi SVD");
+    grow(ws_svd_, sizeof(double) * (l + 8) + 64);
+    hipk::SvdWork w;
+    w.norms = (double*)ws_svd_.p;
+    w.rotcount = flags_ + 8;
+    last_svd_sweeps_ = hipk::svd_small(st_, G, l, U, S, w);
+    check_launch("svd_small");
+  }
+  void chol_upper(double* B, int64_t j) override {
+    bind();
+    if (j > 2048) throw Error(GSI_ERR_ARG, "chol_upper: j too large");
+    hipk::chol_upper(st_, B, j, flags_ + 1);
+    check_launch("chol_upper");
+  }
+  void trsm_right_upper(double* F, int64_t m, int64_t j, int64_t ldf, const double* C) override {
+    bind();
+    hipk::trsm_right_upper(st_, F, m, j, ldf, C);
+    check_launch("trsm_right_upper");
+  }
+  void scale_cols_sqrt(double* U, int64_t l, const double* S, int64_t K) override {
+    bind();
+    hipk::scale_cols_sqrt(st_, U, l, S, K);
+  }
+  void center_rows(double* S, int64_t n, int64_t N, int64_t ld) override {
+    bind();
+    hipk::center_rows(st_, S, n, N, ld);
+  }
+  void randn(double* p, size_t count, uint64_t seed) override {
+    bind();
+    hipk::randn_fill(st_, p, count, seed);
+  }
+  void fill_gridcov(double* A, int64_t lda, int64_t nx, int64_t ny, double ell, int kind, int64_t row0,
+                    int64_t mloc) override {
+    bind();
+    hipk::fill_gridcov(st_, A, lda, nx, ny, ell, kind, row0, mloc);
+    check_launch("fill_gridcov");
+  }
+  void colnorms(const double* Y, int64_t m, int64_t c, int64_t ld, double* host_out) override {
+    bind();
+    if (c > 64) throw Error(GSI_ERR_ARG, "colnorms: at most 64 columns at a time");
+    hipk::colnorms_sq(st_, Y, m, c, ld, scal_);
+    HIP_CHECK(hipMemcpyAsync(host_out, scal_, sizeof(double) * c, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    for (int64_t i = 0; i < c; ++i) host_out[i] = std::sqrt(host_out[i]);
+  }
+  void axpy(int64_t n, double a, const double* x, double* y) override { bind(); hipk::axpy(st_, n, a, x, y); }
+  double dot(int64_t n, const double* x, const double* y) override {
+    bind();
+    hipk::dot_dev(st_, n, x, y, scal_);
+    double v = 0.0;
+    HIP_CHECK(hipMemcpyAsync(&v, scal_, sizeof(double), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    return v;
+  }
+  double nrm2(int64_t n, const double* x) override { return std::sqrt(dot(n, x, x)); }
+  void scal_copy(int64_t n, double a, const double* x, double* y) override {
+    bind();
+    hipk::scal_copy(st_, n, a, x, y);
+  }
+
+  int take_error(std::string* msg) override {
+    bind();
+    int32_t h[16];
+    HIP_CHECK(hipMemcpyAsync(h, flags_, sizeof(h), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    HIP_CHECK(hipGetLastError());
+    if (h[0] != 0 || h[1] != 0) {
+      HIP_CHECK(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), st_));
+      if (h[0] != 0) {
+        if (msg) *msg = "SingularException(" + std::to_string(h[0]) + "): exactly zero pivot in lu()";
+        return GSI_ERR_SINGULAR;
+      }
+      if (msg) *msg = "PosDefException: matrix is not positive definite; Cholesky failed at " + std::to_string(h[1]);
+      return GSI_ERR_NOT_POSDEF;
+    }
+    return 0;
+  }
+
+  // ---- profiling ----
+  void profile(bool on) override { prof_ = on; }
+  void phase_begin(Phase p) override {
+    if (!prof_) return;
+    bind();
+    cur_.phase = p;
+    cur_.a = get_event();
+    cur_.b = get_event();
+    hipEventRecord(cur_.a, st_);
+  }
+  void phase_end(Phase) override {
+    if (!prof_) return;
+    hipEventRecord(cur_.b, st_);
+    records_.push_back(cur_);
+  }
+  void phase_reset() override {
+    bind();
+    hipStreamSynchronize(st_);
+    for (auto& r : records_) { ev_pool_.push_back(r.a); ev_pool_.push_back(r.b); }
+    records_.clear();
+    for (int i = 0; i < PH_COUNT; ++i) { acc_ms_[i] = 0.0; acc_n_[i] = 0; }
+  }
+  void phase_times(double* ms, int64_t* counts) override {
+    bind();
+    hipStreamSynchronize(st_);
+    for (auto& r : records_) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { acc_ms_[r.phase] += t; acc_n_[r.phase] += 1; }
+      ev_pool_.push_back(r.a);
+      ev_pool_.push_back(r.b);
+    }
+    records_.clear();
+    for (int i = 0; i < PH_COUNT; ++i) { ms[i] = acc_ms_[i]; counts[i] = acc_n_[i]; }
+  }
+
+  int device() const { return device_; }
+
+ private:
+  struct Rec { Phase phase; hipEvent_t a, b; };
+  hipEvent_t get_event() {
+    if (!ev_pool_.empty()) { hipEvent_t e = ev_pool_.back(); ev_pool_.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+  }
+  void check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Error(GSI_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  }
+  void grow(DevBuf& b, size_t bytes) {
+    if (bytes <= b.bytes) return;
+    HIP_CHECK(hipStreamSynchronize(st_));
+    if (b.p) hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); throw Error(GSI_ERR_OOM, "workspace hipMalloc failed"); }
+    b.bytes = bytes;
+  }
+  double* gemm_ws(size_t doubles) {
+    if (doubles == 0) return (double*)ws_gemm_.p;
+    grow(ws_gemm_, doubles * sizeof(double));
+    return (double*)ws_gemm_.p;
+  }
+
+  int device_;
+  std::string arch_;
+  hipStream_t st_ = nullptr;
+  int32_t* flags_ = nullptr;  // [0] lu info, [1] chol info, [8] jacobi rotation counter
+  double* scal_ = nullptr;
+  DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_;
+  std::mutex mu_;
+  std::vector<DevBuf> sizes_;
+  int64_t in_use_ = 0;
+  bool prof_ = false;
+  Rec cur_{};
+  std::vector<Rec> records_;
+  std::vector<hipEvent_t> ev_pool_;
+  double acc_ms_[PH_COUNT] = {0};
+  int64_t acc_n_[PH_COUNT] = {0};
+  int last_svd_sweeps_ = 0;
+};
+
+// ---- RCCL, bound lazily so a single-GPU user never needs librccl to resolve -----------------
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    api.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!api.h) api.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!api.h) return;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+  });
+  if (!api.h || !api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.AllGather)
+    throw Error(GSI_ERR_RCCL, "librccl.so could not be loaded: multi-GPU needs RCCL");
+  return api;
+}
+#define RCCL_CHECK(expr)                                                                       \
+  do {                                                                                         \
+    ncclResult_t _r = (expr);                                                                  \
+    if (_r != ncclSuccess)                                                                     \
+      throw Error(GSI_ERR_RCCL, std::string(#expr) + ": " +                                     \
+                                    (rccl().GetErrorString ? rccl().GetErrorString(_r) : "rccl error")); \
+  } while (0)
+
+class RcclComm : public Comm {
+ public:
+  RcclComm(HipBackend* be, int n, int r, const void* id) : be_(be) {
+    nranks = n;
+    rank = r;
+    static_assert(sizeof(ncclUniqueId) <= GSI_UNIQUE_ID_BYTES, "unique id does not fit the ABI slot");
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    be_->bind();
+    RCCL_CHECK(rccl().CommInitRank(&comm_, n, uid, r));
+  }
+  ~RcclComm() override {
+    if (comm_) {
+      be_->bind();
+      hipStreamSynchronize(be_->stream());
+      rccl().CommDestroy(comm_);
+    }
+  }
+  void allreduce_sum(double* buf, size_t count) override {
+    be_->bind();
+    RCCL_CHECK(rccl().AllReduce(buf, buf, count, ncclDouble, ncclSum, comm_, be_->stream()));
+  }
+  void allgather(const double* send, double* recv, size_t count) override {
+    be_->bind();
+    RCCL_CHECK(rccl().AllGather(send, recv, count, ncclDouble, comm_, be_->stream()));
+  }
+
+ private:
+  HipBackend* be_;
+  ncclComm_t comm_ = nullptr;
+};
+
+}  // namespace
+
+Backend* make_backend(int device_id) { return new HipBackend(device_id); }
+Comm* make_comm(Backend* be, int nranks, int rank, const void* unique_id) {
+  return new RcclComm(static_cast<HipBackend*>(be), nranks, rank, unique_id);
+}
+void comm_unique_id(void* id_out) {
+  ncclUniqueId uid;
+  RCCL_CHECK(rccl().GetUniqueId(&uid));
+  std::memset(id_out, 0, GSI_UNIQUE_ID_BYTES);
+  std::memcpy(id_out, &uid, sizeof(uid));
+}
+const char* backend_name() { return "hip-gfx950"; }
+
+}  // namespace gsi

@@ -1,0 +1,69 @@
+// hip_common.hpp -- declarations shared by the gfx950 kernel files and hip_backend.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+
+namespace gsi { namespace hipk {
+
+// ---- gemm_f64.hip ----
+size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K);
+void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, double alpha, const double* A,
+              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws);
+
+// ---- panel_lu.hip ----
+struct LuWork {
+  double* urow;     // [NB] pivot row of the active panel
+  double* pval;     // [maxblocks] partial arg-max values
+  int64_t* pidx;    // [maxblocks] partial arg-max rows
+  int32_t* ipiv;    // [l] pivot rows (0-based)
+  int32_t* info;    // [1] first exactly-zero pivot (1-based), 0 if none
+  int64_t maxblocks;
+};
+constexpr int LU_NB = 32;
+int64_t lu_max_blocks(int64_t m);
+void lu_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const LuWork& w, double* gemm_ws);
+
+// ---- panel_qr.hip ----
+constexpr int QR_NB = 16;
+struct QrWork {
+  double* coef;     // [2 + NB]: scale, tau, tw[NB]
+  double* part;     // [maxblocks * NB] partial sums
+  double* tau;      // [l]
+  double* T;        // [l * NB]   T factors, panel k at T + k*NB*NB
+  double* G;        // [NB*NB]    V'V
+  double* Vbuf;     // [m * NB]
+  double* Wt;       // [l * NB]
+  double* W2;       // [NB * l]
+  double* Qo;       // [m * l]
+  int64_t maxblocks;
+};
+int64_t qr_max_blocks(int64_t m);
+void qr_thinQ(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, double* R, const QrWork& w,
+              double* gemm_ws);
+
+// ---- jacobi_svd.hip ----
+struct SvdWork {
+  int32_t* rotcount;  // [1]
+  double* norms;      // [l]
+};
+// returns number of sweeps used
+int svd_small(hipStream_t st, double* G, int64_t l, double* U, double* S, const SvdWork& w);
+
+// ---- misc.hip ----
+void center_rows(hipStream_t st, double* S, int64_t n, int64_t N, int64_t ld);
+void scale_cols_sqrt(hipStream_t st, double* U, int64_t l, const double* S, int64_t K);
+void randn_fill(hipStream_t st, double* p, size_t count, uint64_t seed);
+void fill_gridcov(hipStream_t st, double* A, int64_t lda, int64_t nx, int64_t ny, double ell, int kind,
+                  int64_t row0, int64_t mloc);
+void colnorms_sq(hipStream_t st, const double* Y, int64_t m, int64_t c, int64_t ld, double* out_dev);
+void chol_upper(hipStream_t st, double* B, int64_t j, int32_t* info);
+void trsm_right_upper(hipStream_t st, double* F, int64_t m, int64_t j, int64_t ldf, const double* C);
+void axpy(hipStream_t st, int64_t n, double a, const double* x, double* y);
+void scal_copy(hipStream_t st, int64_t n, double a, const double* x, double* y);
+void dot_dev(hipStream_t st, int64_t n, const double* x, const double* y, double* out_dev);
+void extract_upper(hipStream_t st, const double* Y, int64_t ld, int64_t l, double* R);
+void pcga_params(hipStream_t st, const double* Z, int64_t n, int64_t K, const double* s, const double* X,
+                 double delta, double* out);
+
+}}  // namespace gsi::hipk

@@ -1,0 +1,160 @@
+// jacobi_svd.hip -- the small dense SVD inside `svd(B)` (RandMatFact.jl:86) on gfx950.
+// After the tall QR of B' only the l x l triangular factor R is left; this file computes
+// R = U S V' and returns U (l x l) and S, which is all randsvd needs (Z = Q_B U sqrt(S)).
+//
+// One-sided (Hestenes) Jacobi on the columns of R: right rotations orthogonalise the
+// columns, which converge to U*S -- high relative accuracy for the small singular values,
+// unlike an eigen-decomposition of R'R.  V is never accumulated.
+//
+// MI355X mapping: block Jacobi.  The columns are cut into blocks of SVD_W columns; a
+// round-robin tournament pairs the blocks, one workgroup (16 waves) per block pair per
+// round keeps its 2*SVD_W columns (<= 128 KB of the CU's 160 KB LDS) resident and runs a
+// full inner round-robin sweep over them out of LDS -- one wave per column pair, the three
+// inner products by wavefront shuffles -- then writes the block back.  l <= 2*SVD_W needs
+// a single workgroup and no inter-workgroup traffic at all.
+#include "hip_common.hpp"
+#include <cfloat>
+
+namespace gsi { namespace hipk {
+
+constexpr int SVD_W = 16;          // columns per block
+constexpr int SVD_C = 2 * SVD_W;   // columns resident per workgroup
+constexpr int SVD_THREADS = 1024;  // 16 waves = one per pair of an inner round
+
+// round-robin ("circle") tournament on n (even) players: pair q of round r
+__device__ __host__ inline void rr_pair(int n, int r, int q, int* a, int* b) {
+  if (q == 0) { *a = n - 1; *b = r % (n - 1); }
+  else {
+    *a = (r + q) % (n - 1);
+    *b = ((r - q) % (n - 1) + (n - 1)) % (n - 1);
+  }
+}
+
+__device__ inline double wave_allsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// grid.x = number of block pairs in this round
+__global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __restrict__ G, int l, int lp,
+                                                                   int nblk, int round, double tol,
+                                                                   int32_t* __restrict__ rotcount,
+                                                                   int inner_sweeps) {
+  extern __shared__ double cols[];  // [SVD_C][lp] followed by one int slot (single LDS object)
+  int& s_rot = *reinterpret_cast<int*>(cols + SVD_C * lp);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  int ba, bb;
+  if (nblk <= 2) { ba = 0; bb = 1; }
+  else rr_pair(nblk, round, blockIdx.x, &ba, &bb);
+  if (tid == 0) s_rot = 0;
+  // load: local column c <- global column (c < W ? ba*W + c : bb*W + c - W), zero beyond l
+  for (int e = tid; e < SVD_C * lp; e += SVD_THREADS) {
+    const int c = e / lp, r = e % lp;
+    const int gc = (c < SVD_W) ? ba * SVD_W + c : bb * SVD_W + (c - SVD_W);
+    cols[e] = (gc < l && r < l) ? G[r + (int64_t)gc * l] : 0.0;
+  }
+  __syncthreads();
+  int rots = 0;
+  for (int sw = 0; sw < inner_sweeps; ++sw) {
+    for (int r = 0; r < SVD_C - 1; ++r) {
+      int p, q;
+      rr_pair(SVD_C, r, wave, &p, &q);
+      double* gp = cols + p * lp;
+      double* gq = cols + q * lp;
+      double a = 0.0, b = 0.0, c = 0.0;
+      for (int i = lane; i < l; i += 64) {
+        const double x = gp[i], y = gq[i];
+        a += x * x; b += y * y; c += x * y;
+      }
+      a = wave_allsum(a); b = wave_allsum(b); c = wave_allsum(c);
+      if (a > 0.0 && b > 0.0 && fabs(c) > tol * sqrt(a * b)) {
+        const double zeta = (b - a) / (2.0 * c);
+        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t);
+        const double sn = cs * t;
+        for (int i = lane; i < l; i += 64) {
+          const double x = gp[i], y = gq[i];
+          gp[i] = cs * x - sn * y;
+          gq[i] = sn * x + cs * y;
+        }
+        if (lane == 0) ++rots;
+      }
+      __syncthreads();
+    }
+  }
+  if (lane == 0 && rots) atomicAdd(&s_rot, rots);
+  __syncthreads();
+  for (int e = tid; e < SVD_C * lp; e += SVD_THREADS) {
+    const int c = e / lp, r = e % lp;
+    const int gc = (c < SVD_W) ? ba * SVD_W + c : bb * SVD_W + (c - SVD_W);
+    if (gc < l && r < l) G[r + (int64_t)gc * l] = cols[e];
+  }
+  if (tid == 0 && s_rot) atomicAdd(rotcount, s_rot);
+}
+
+__global__ void jacobi_norms_kernel(const double* __restrict__ G, int l, double* __restrict__ norms) {
+  // one wave per column
+  const int col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= l) return;
+  double s = 0.0;
+  for (int i = lane; i < l; i += 64) { const double x = G[i + (int64_t)col * l]; s += x * x; }
+  s = wave_allsum(s);
+  if (lane == 0) norms[col] = sqrt(s);
+}
+
+// U[:, rank(c)] = G[:, c] / norm_c ; S[rank(c)] = norm_c ; rank by descending norm (stable)
+__global__ void jacobi_finish_kernel(const double* __restrict__ G, int l, const double* __restrict__ norms,
+                                     double* __restrict__ U, double* __restrict__ S) {
+  const int col = blockIdx.x;
+  const double nc = norms[col];
+  int rank = 0;
+  for (int j = 0; j < l; ++j) {
+    const double nj = norms[j];
+    if (nj > nc || (nj == nc && j < col)) ++rank;
+  }
+  const double inv = (nc > 0.0) ? 1.0 / nc : 0.0;
+  for (int i = threadIdx.x; i < l; i += blockDim.x) U[i + (int64_t)rank * l] = G[i + (int64_t)col * l] * inv;
+  if (threadIdx.x == 0) S[rank] = nc;
+}
+
+int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, const SvdWork& w) {
+  const int l = (int)l64;
+  const int lp = l;  // lanes stride rows: conflict-free without padding
+  int nblk = (l + SVD_W - 1) / SVD_W;
+  if (nblk < 2) nblk = 2;
+  if (nblk & 1) ++nblk;
+  const size_t shmem = (size_t)SVD_C * lp * sizeof(double) + 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)jacobi_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024 - 64);
+    attr_set = true;
+  }
+  const double tol = sqrt((double)l) * DBL_EPSILON;
+  const int max_sweeps = 40;
+  int sweeps = 0;
+  for (; sweeps < max_sweeps; ++sweeps) {
+    hipMemsetAsync(w.rotcount, 0, sizeof(int32_t), st);
+    if (nblk == 2) {
+      hipLaunchKernelGGL(jacobi_block_kernel, dim3(1), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk, 0, tol,
+                         w.rotcount, 2);
+    } else {
+      for (int r = 0; r < nblk - 1; ++r)
+        hipLaunchKernelGGL(jacobi_block_kernel, dim3(nblk / 2), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk,
+                           r, tol, w.rotcount, 1);
+    }
+    int32_t rot = 0;
+    hipMemcpyAsync(&rot, w.rotcount, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    hipStreamSynchronize(st);
+    if (rot == 0) { ++sweeps; break; }
+  }
+  hipLaunchKernelGGL(jacobi_norms_kernel, dim3((l + 3) / 4), dim3(256), 0, st, G, l, w.norms);
+  hipLaunchKernelGGL(jacobi_finish_kernel, dim3(l), dim3(64), 0, st, G, l, w.norms, U, S);
+  return sweeps;
+}
+
+}}  // namespace gsi::hipk

@@ -1,0 +1,322 @@
+// pipeline.cpp -- RandMatFact.jl's order of operations, row-sharded.
+// Each function cites the reference lines it follows.  All arithmetic happens in the
+// Backend; this file only sequences products, panel factorizations and collectives.
+//
+// Data distribution.  The operator A (m x n) is cut into contiguous row blocks, one per
+// rank.  Tall panels are either REPLICATED (every rank holds all rows; needed by the
+// partial-pivot LU, whose pivot sequence must equal LAPACK's over the whole panel) or
+// ROW-SHARDED (each rank its rows; the final TSQR).  Exchange steps:
+//   Y = A*X      local rows, then AllGather of the row shards when the LU follows
+//   Z = A'*Y     local partial product over the rank's rows, then AllReduce(sum)
+//   final Q      TSQR: local Householder QR, AllGather of the l x l R factors, replicated
+//                QR of the stack, local fix-up Q_g <- Q_g * Q2_g
+#include "pipeline.hpp"
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include "../../include/gsi_hip.h"
+
+namespace gsi {
+
+void default_shard(int64_t m, int nranks, int rank, int64_t* row0, int64_t* mloc) {
+  const int64_t pad = (m + nranks - 1) / nranks;
+  int64_t r0 = std::min<int64_t>((int64_t)rank * pad, m);
+  *row0 = r0;
+  *mloc = std::min<int64_t>(pad, m - r0);
+}
+
+void check_async_errors(Context& c) {
+  std::string msg;
+  const int code = c.be->take_error(&msg);
+  if (code != 0) throw Error(code, msg);
+}
+
+void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* Yloc, int64_t ldy) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  if (A.mloc == 0) return;
+  if (A.kind == OP_DENSE) {
+    ScopedPhase ph(be, PH_GEMM_N);
+    be->gemm_nn(A.mloc, l, A.n, 1.0, A.data.p, A.ld, X, ldx, 0.0, Yloc, ldy);   // RandMatFact.jl:55,70
+    return;
+  }
+  // LowRankCovMatrix: A*X = S (S'X) / (N-1)   (lowrank.jl:115-121 as two tall-skinny products)
+  Buf T(be, (size_t)A.N * l);
+  {
+    ScopedPhase ph(be, PH_GEMM_T);
+    be->gemm_tn(A.N, l, A.mloc, 1.0, A.data.p, A.ld, X + A.row0, ldx, 0.0, T.p, A.N);
+  }
+  if (c.comm) {
+    ScopedPhase ph(be, PH_COMM);
+    c.comm->allreduce_sum(T.p, (size_t)A.N * l);
+  }
+  {
+    ScopedPhase ph(be, PH_GEMM_N);
+    be->gemm_nn(A.mloc, l, A.N, 1.0 / (double)(A.N - 1), A.data.p, A.ld, T.p, A.N, 0.0, Yloc, ldy);
+  }
+}
+
+void gather_rows(Context& c, const Operator& A, const double* Yloc, int64_t ldy, int64_t l, double* Yfull) {
+  Backend* be = c.be.get();
+  if (!c.comm) {
+    if (Yloc != Yfull) be->copy2d(Yfull, A.m, Yloc, ldy, A.m, l);
+    return;
+  }
+  const int G = c.nranks();
+  const int64_t pad = (A.m + G - 1) / G;
+  Buf send(be, (size_t)pad * l), recv(be, (size_t)pad * l * G);
+  if (A.mloc < pad) be->fill_zero(send.p, (size_t)pad * l);
+  be->copy2d(send.p, pad, Yloc, ldy, A.mloc, l);
+  {
+    ScopedPhase ph(be, PH_COMM);
+    c.comm->allgather(send.p, recv.p, (size_t)pad * l);
+  }
+  for (int g = 0; g < G; ++g) {
+    int64_t r0, ml;
+    default_shard(A.m, G, g, &r0, &ml);
+    be->copy2d(Yfull + r0, A.m, recv.p + (size_t)g * pad * l, pad, ml, l);
+  }
+}
+
+void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, double* Z, int64_t ldz) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  if (A.kind == OP_DENSE) {
+    {
+      ScopedPhase ph(be, PH_GEMM_T);
+      if (A.mloc > 0)
+        be->gemm_tn(A.n, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, Z, ldz);   // RandMatFact.jl:67,85
+      else
+        for (int64_t cidx = 0; cidx < l; ++cidx) be->fill_zero(Z + cidx * ldz, (size_t)A.n);
+    }
+    if (c.comm) {
+      ScopedPhase ph(be, PH_COMM);
+      if (ldz == A.n) c.comm->allreduce_sum(Z, (size_t)A.n * l);
+      else throw Error(GSI_ERR_INTERNAL, "op_mul_t: strided output with a communicator");
+    }
+    return;
+  }
+  // adjoint(A::LowRankCovMatrix) === A  (lowrank.jl:38-40): A'*X = A*X, rows then gathered
+  Buf T(be, (size_t)A.N * l);
+  {
+    ScopedPhase ph(be, PH_GEMM_T);
+    be->gemm_tn(A.N, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, T.p, A.N);
+  }
+  if (c.comm) {
+    ScopedPhase ph(be, PH_COMM);
+    c.comm->allreduce_sum(T.p, (size_t)A.N * l);
+  }
+  if (!c.comm && ldz == A.m) {
+    ScopedPhase ph(be, PH_GEMM_N);
+    be->gemm_nn(A.mloc, l, A.N, 1.0 / (double)(A.N - 1), A.data.p, A.ld, T.p, A.N, 0.0, Z, ldz);
+    return;
+  }
+  Buf Yloc(be, (size_t)std::max<int64_t>(A.mloc, 1) * l);
+  {
+    ScopedPhase ph(be, PH_GEMM_N);
+    be->gemm_nn(A.mloc, l, A.N, 1.0 / (double)(A.N - 1), A.data.p, A.ld, T.p, A.N, 0.0, Yloc.p, A.mloc);
+  }
+  if (ldz != A.m) throw Error(GSI_ERR_INTERNAL, "op_mul_t: strided output for a sharded LowRankCovMatrix");
+  gather_rows(c, A, Yloc.p, A.mloc, l, Z);
+}
+
+static void lu_panel(Context& c, double* Y, int64_t rows, int64_t l) {
+  ScopedPhase ph(c.be.get(), PH_LU);
+  c.be->lu_L(Y, rows, l, rows, nullptr);   // F = lu(Y); Q = F.L   RandMatFact.jl:60-61,68-69,72-73
+}
+
+// thin orthonormal basis of the row-sharded panel Yloc (mloc x l, ld mloc), in place / swapped
+static void tsqr(Context& c, const Operator& A, Buf& Yloc, int64_t l) {
+  Backend* be = c.be.get();
+  const int G = c.nranks();
+  if (G == 1) {
+    ScopedPhase ph(be, PH_QR);
+    be->qr_thinQ(Yloc.p, A.mloc, l, A.mloc, nullptr);   // qr(Y, Val(true)) -> Matrix(F.Q)  :57-58,75-76
+    return;
+  }
+  bool all_tall = true;
+  for (int g = 0; g < G; ++g) {
+    int64_t r0, ml;
+    default_shard(A.m, G, g, &r0, &ml);
+    if (ml < l) all_tall = false;
+  }
+  if (!all_tall) {  // a shard shorter than the sketch width: factor the gathered panel everywhere
+    Buf Yfull(be, (size_t)A.m * l);
+    gather_rows(c, A, Yloc.p, A.mloc, l, Yfull.p);
+    {
+      ScopedPhase ph(be, PH_QR);
+      be->qr_thinQ(Yfull.p, A.m, l, A.m, nullptr);
+    }
+    be->copy2d(Yloc.p, A.mloc, Yfull.p + A.row0, A.m, A.mloc, l);
+    return;
+  }
+  Buf R(be, (size_t)l * l), Rall(be, (size_t)l * l * G), stack(be, (size_t)l * l * G);
+  {
+    ScopedPhase ph(be, PH_QR);
+    be->qr_thinQ(Yloc.p, A.mloc, l, A.mloc, R.p);
+  }
+  {
+    ScopedPhase ph(be, PH_COMM);
+    c.comm->allgather(R.p, Rall.p, (size_t)l * l);
+  }
+  const int64_t sl = (int64_t)G * l;
+  for (int g = 0; g < G; ++g) be->copy2d(stack.p + (int64_t)g * l, sl, Rall.p + (size_t)g * l * l, l, l, l);
+  {
+    ScopedPhase ph(be, PH_QR);
+    be->qr_thinQ(stack.p, sl, l, sl, nullptr);
+  }
+  Buf Qn(be, (size_t)A.mloc * l);
+  {
+    ScopedPhase ph(be, PH_SMALL_GEMM);
+    be->gemm_nn(A.mloc, l, l, 1.0, Yloc.p, A.mloc, stack.p + (int64_t)c.rank() * l, sl, 0.0, Qn.p, A.mloc);
+  }
+  Yloc = std::move(Qn);
+}
+
+Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  if (q < 0)   // RandMatFact.jl:62-64
+    throw Error(GSI_ERR_NEG_ITERS,
+                "parameter numiterations should be positive, but numiterations=" + std::to_string(q));
+  if (l < 1 || l > A.m || l > A.n) throw Error(GSI_ERR_ARG, "rangefinder: need 1 <= l <= min(size(A))");
+  const bool single = (c.nranks() == 1);
+  const int64_t m = A.m, n = A.n;
+  if (q == 0) {
+    Buf Yloc(be, (size_t)std::max<int64_t>(A.mloc, 1) * l);
+    op_mul(A, Omega, n, l, Yloc.p, A.mloc);                 // Y = A*Omega            :55
+    tsqr(c, A, Yloc, l);                                    //                        :57-58
+    return Yloc;
+  }
+  Buf Yfull(be, (size_t)m * l);                              // replicated m x l
+  Buf Z(be, (size_t)n * l);                                  // replicated n x l
+  Buf Yloc;                                                  // this rank's rows (multi-rank only)
+  if (!single) Yloc = Buf(be, (size_t)std::max<int64_t>(A.mloc, 1) * l);
+  double* yl = single ? Yfull.p : Yloc.p;
+  const int64_t ldyl = single ? m : A.mloc;
+  op_mul(A, Omega, n, l, yl, ldyl);                         // Y = A*Omega            :55
+  gather_rows(c, A, yl, ldyl, l, Yfull.p);
+  lu_panel(c, Yfull.p, m, l);                               // Q = lu(Y).L            :60-61
+  for (int64_t i = 1; i <= q; ++i) {                        //                        :66
+    op_mul_t(A, Yfull.p + A.row0, m, l, Z.p, n);            // Q = A'*Q               :67
+    lu_panel(c, Z.p, n, l);                                 // Q = lu(Q).L            :68-69
+    op_mul(A, Z.p, n, l, yl, ldyl);                         // Q = A*Q                :70
+    if (i < q) {
+      gather_rows(c, A, yl, ldyl, l, Yfull.p);
+      lu_panel(c, Yfull.p, m, l);                           //                        :72-73
+    }
+  }
+  if (single) {
+    tsqr(c, A, Yfull, l);                                   // pivoted-QR range       :75-76
+    return Yfull;
+  }
+  tsqr(c, A, Yloc, l);
+  return Yloc;
+}
+
+void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, double* V, double* S) {
+  Backend* be = c.be.get();
+  Buf R(be, (size_t)l * l), U(be, (size_t)l * l);
+  {
+    ScopedPhase ph(be, PH_QR);
+    be->qr_thinQ(W, n, l, n, R.p);                          // B' = Q_B R
+  }
+  {
+    ScopedPhase ph(be, PH_SVD);
+    be->svd_small(R.p, l, U.p, S);                          // R = U_R S V_R'
+    if (K_scale >= 0) be->scale_cols_sqrt(U.p, l, S, K_scale);   // Sh = sqrt([S[1:K]; zeros(p)])  :87
+  }
+  {
+    ScopedPhase ph(be, PH_SMALL_GEMM);
+    be->gemm_nn(n, l, l, 1.0, W, n, U.p, l, 0.0, V, n);     // Z = V*Sh = Q_B (U_R Sh)         :88
+  }
+}
+
+void randsvd(const Operator& A, const double* Omega, int64_t K, int64_t p, int64_t q, double* Z, double* S) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  if (K < 0 || p < 0 || K + p < 1) throw Error(GSI_ERR_ARG, "randsvd: need K >= 0, p >= 0, K + p >= 1");
+  const int64_t l = K + p;
+  Buf Q = rangefinder(A, Omega, l, q);                      // Q = rangefinder(A, K+p, q)     :84
+  Buf W(be, (size_t)A.n * l);
+  op_mul_t(A, Q.p, A.mloc, l, W.p, A.n);                    // B = Q'*A  (held as B' = A'Q)   :85
+  Q.reset();
+  svd_tall(c, W.p, A.n, l, K, Z, S);                        // (), S, V = svd(B); Z = V*Sh    :86-88
+}
+
+void eig_nystrom(const Operator& A, const double* Q, int64_t j, double* U, double* Sigma) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  if (A.m != A.n) throw Error(GSI_ERR_ARG, "eig_nystrom: A must be square");
+  if (j < 1 || j > A.n) throw Error(GSI_ERR_ARG, "eig_nystrom: need 1 <= size(Q,2) <= n");
+  const int64_t n = A.n;
+  Buf B1loc(be, (size_t)std::max<int64_t>(A.mloc, 1) * j), B1(be, (size_t)n * j), B2(be, (size_t)j * j);
+  op_mul(A, Q, n, j, B1loc.p, A.mloc);                      // B1 = A*Q                       :93
+  gather_rows(c, A, B1loc.p, A.mloc, j, B1.p);
+  {
+    ScopedPhase ph(be, PH_SMALL_GEMM);
+    be->gemm_tn(j, j, n, 1.0, Q, n, B1.p, n, 0.0, B2.p, j); // B2 = Q'*B1                     :94
+  }
+  {
+    ScopedPhase ph(be, PH_OTHER);
+    be->chol_upper(B2.p, j);                                // C = cholesky(Hermitian(B2)).U  :95
+    be->trsm_right_upper(B1.p, n, j, n, B2.p);              // F = B1*inv(C)                  :96
+  }
+  svd_tall(c, B1.p, n, j, -1, U, Sigma);                    // U, Sigmavec, V = svd(F)        :97
+}
+
+int64_t rangefinder_adaptive(const Operator& A, randn_fn rn, void* user, double epsilon, int64_t r,
+                             double* Q_host) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  if (c.nranks() != 1) throw Error(GSI_ERR_ARG, "adaptive rangefinder: single rank only");
+  if (A.kind != OP_DENSE) throw Error(GSI_ERR_ARG, "adaptive rangefinder needs a dense (strided) A, as the reference's gemv! does");
+  if (A.m != A.n) throw Error(GSI_ERR_ARG, "adaptive rangefinder: the reference's Yfull allocation assumes a square A (RandMatFact.jl:18)");
+  if (r < 1 || r > 64) throw Error(GSI_ERR_ARG, "adaptive rangefinder: need 1 <= r <= 64");
+  const int64_t m = A.m, n = A.n, kmax = std::min(m, n);
+  std::vector<double> host((size_t)n * r);
+  Buf Yfull(be, (size_t)n * (r + kmax)), Qfull(be, (size_t)m * kmax), om(be, (size_t)n * r),
+      Aom(be, (size_t)m), tmp(be, (size_t)std::max<int64_t>(kmax, 1));
+  be->fill_zero(Yfull.p, (size_t)n * (r + kmax));           //                                :18
+  be->fill_zero(Qfull.p, (size_t)m * kmax);                 //                                :23
+  rn(user, host.data(), n * r);                             // randn(n, r)                    :20
+  be->upload2d(om.p, n, host.data(), n, n, r);
+  be->gemm_nn(m, r, n, 1.0, A.data.p, A.ld, om.p, n, 0.0, Yfull.p, n);   // gemm!('N','N',1,A,randn,0,Y)
+  const double thresh = epsilon / std::sqrt(200.0 / M_PI);
+  std::vector<double> norms((size_t)r);
+  int64_t j = 0;
+  for (;;) {
+    be->colnorms(Yfull.p + j * n, n, r, n, norms.data());   // maximum(colnorms(view(Yfull,:,j+1:j+r)))   :26
+    double mx = 0.0;
+    for (double v : norms) mx = std::max(mx, v);
+    if (!(mx > thresh)) break;
+    if (j >= kmax) break;   // the reference would raise a BoundsError here
+    j += 1;
+    double* Yj = Yfull.p + (j - 1) * n;
+    double* Qj = Qfull.p + (j - 1) * m;
+    if (j > 1) {
+      be->gemm_tn(j - 1, 1, m, 1.0, Qfull.p, m, Yj, n, 0.0, tmp.p, kmax);      // QtYj = gemv('T',1,Q,Yj)   :30
+      // the reference's `Yj -= Q*QtYj` rebinds Yj to a new vector; the view in Yfull keeps the old
+      // values.  Column j of Yfull is never read again, so updating it in place is equivalent.
+      be->gemm_nn(m, 1, j - 1, -1.0, Qfull.p, m, tmp.p, kmax, 1.0, Yj, n);     // Yj - Q*QtYj               :31
+    }
+    const double nrm = be->nrm2(m, Yj);
+    be->axpy(m, 1.0 / nrm, Yj, Qj);                         // axpy!(1/norm(Yj), Yj, Qj)      :32-34
+    rn(user, host.data(), n);                               // randn!(omega)                  :36
+    be->upload2d(om.p, n, host.data(), n, n, 1);
+    be->gemm_nn(m, 1, n, 1.0, A.data.p, A.ld, om.p, n, 0.0, Aom.p, m);          // gemv!('N',1,A,omega,0,Aomega) :37
+    be->gemm_tn(j, 1, m, 1.0, Qfull.p, m, Aom.p, m, 0.0, tmp.p, kmax);          // QtAomega                 :38
+    double* ynew = Yfull.p + (r + j - 1) * n;
+    be->scal_copy(m, 1.0, Aom.p, ynew);
+    be->gemm_nn(m, 1, j, -1.0, Qfull.p, m, tmp.p, kmax, 1.0, ynew, n);          // ynew = Aomega - Q*QtAomega :39-40
+    for (int64_t i = j + 1; i <= j + r - 1; ++i) {          //                                :42-45
+      double* Yi = Yfull.p + (i - 1) * n;
+      const double d = be->dot(m, Qj, Yi);
+      be->axpy(m, -d, Qj, Yi);
+    }
+  }
+  if (j > 0) be->download2d(Q_host, m, Qfull.p, m, m, j);   // return Qfull[:, 1:j]           :47
+  return j;
+}
+
+}  // namespace gsi

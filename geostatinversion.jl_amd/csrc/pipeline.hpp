@@ -1,0 +1,75 @@
+// pipeline.hpp -- host-side order of operations of RandMatFact.jl over a gsi::Backend,
+// row-sharded over gsi::Comm ranks.  No kernel code here.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <vector>
+#include "backend.hpp"
+
+namespace gsi {
+
+// RAII panel in backend memory
+struct Buf {
+  Backend* be = nullptr;
+  double* p = nullptr;
+  size_t count = 0;
+  Buf() {}
+  Buf(Backend* b, size_t n) : be(b), p(b->alloc(n)), count(n) {}
+  Buf(const Buf&) = delete;
+  Buf& operator=(const Buf&) = delete;
+  Buf(Buf&& o) noexcept : be(o.be), p(o.p), count(o.count) { o.p = nullptr; }
+  Buf& operator=(Buf&& o) noexcept {
+    if (this != &o) { reset(); be = o.be; p = o.p; count = o.count; o.p = nullptr; }
+    return *this;
+  }
+  ~Buf() { reset(); }
+  void reset() { if (p) { be->release(p); p = nullptr; } }
+};
+
+struct Context {
+  std::unique_ptr<Backend> be;
+  std::unique_ptr<Comm> comm;  // null when single rank
+  int rank() const { return comm ? comm->rank : 0; }
+  int nranks() const { return comm ? comm->nranks : 1; }
+};
+
+enum OpKind { OP_DENSE = 0, OP_LOWRANK = 1 };
+
+// A linear operator m x n; this rank holds rows [row0, row0 + mloc).
+struct Operator {
+  Context* ctx = nullptr;
+  OpKind kind = OP_DENSE;
+  int64_t m = 0, n = 0, row0 = 0, mloc = 0;
+  Buf data;        // dense: mloc x n (ld mloc).  lowrank: samples shard mloc x N (ld mloc)
+  int64_t ld = 0;
+  int64_t N = 0;   // lowrank: number of samples
+};
+
+// block-row layout used whenever a caller does not supply one
+void default_shard(int64_t m, int nranks, int rank, int64_t* row0, int64_t* mloc);
+
+// Y_loc (mloc x l, ld ldy) = rows [row0,row0+mloc) of A * X, X replicated n x l (ld ldx)
+void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* Yloc, int64_t ldy);
+// Z (n x l, ld ldz, replicated) = A' * X where Xloc (mloc x l, ld ldx) are this rank's rows of X
+void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, double* Z, int64_t ldz);
+// Y (m x l, ld m, replicated) <- all ranks' row shards
+void gather_rows(Context& c, const Operator& A, const double* Yloc, int64_t ldy, int64_t l, double* Yfull);
+
+// rangefinder(A, l, numiterations)  RandMatFact.jl:50-80.  Omega replicated n x l (ld n).
+// Returns this rank's rows of Q (mloc x l, ld mloc).
+Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q);
+// randsvd(A, K, p, q)  RandMatFact.jl:83-90.  Z (n x (K+p), ld n) and S (K+p) replicated.
+void randsvd(const Operator& A, const double* Omega, int64_t K, int64_t p, int64_t q, double* Z, double* S);
+// eig_nystrom(A, Q)  RandMatFact.jl:92-102.  Q replicated n x j; U (m x j), Sigma (j) replicated.
+void eig_nystrom(const Operator& A, const double* Q, int64_t j, double* U, double* Sigma);
+// thin SVD of a replicated tall W (n x l, destroyed): V (n x l, may alias W) = left singular
+// vectors scaled by `scale_K` rule (K < 0: plain V; else V*sqrt(S) for i<K, 0 otherwise)
+void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, double* V, double* S);
+// rangefinder(A; epsilon, r)  RandMatFact.jl:15-48 (dense operator, single rank)
+typedef void (*randn_fn)(void* user, double* buf, int64_t count);
+int64_t rangefinder_adaptive(const Operator& A, randn_fn rn, void* user, double epsilon, int64_t r,
+                             double* Q_host);
+// throws Error if a kernel raised an asynchronous flag
+void check_async_errors(Context& c);
+
+}  // namespace gsi

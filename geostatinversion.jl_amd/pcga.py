@@ -1,0 +1,177 @@
+"""Host-side mirror of the consumers of the xi-basis: `pcgadirect` (src/direct.jl), `pcgalsqr`
+(src/lsqr.jl) and `rga` (src/GeostatInversion.jl:101-103).  The forward model is user code and runs
+on the host exactly as the reference's `pmap` does; the package's own n-sized algebra (the
+perturbation batch and the update s = X*beta + sum xis[i]*dot(eta_i, xi_bar)) runs on the GPU."""
+import numpy as np
+
+from . import _lib as L
+from .context import default_context
+from .lowrank import PCGALowRankMatrix
+
+SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
+
+
+def _lsqr(matvec, b, maxiter=None):
+    """IterativeSolvers.jl 0.9 `lsqr` defaults (atol = btol = sqrt(eps), conlim = 1e8,
+    maxiter = max(size)) for a symmetric operator -- Paige & Saunders 1982.  nobs-sized, host."""
+    b = np.asarray(b, dtype=np.float64)
+    n = b.shape[0]
+    tol = SQRT_EPS
+    maxiter = n if maxiter is None else maxiter
+    x = np.zeros(n)
+    u = b.copy()
+    beta = np.linalg.norm(u)
+    if beta == 0:
+        return x
+    u /= beta
+    v = matvec(u)
+    alpha = np.linalg.norm(v)
+    if alpha == 0:
+        return x
+    v /= alpha
+    w = v.copy()
+    rhobar, phibar, bnorm = alpha, beta, beta
+    Anorm = ddnorm = xxnorm = z = 0.0
+    cs2, sn2 = -1.0, 0.0
+    for _ in range(maxiter):
+        u = matvec(v) - alpha * u
+        beta = np.linalg.norm(u)
+        if beta > 0:
+            u /= beta
+            Anorm = np.sqrt(Anorm ** 2 + alpha ** 2 + beta ** 2)
+            v = matvec(u) - beta * v
+            alpha = np.linalg.norm(v)
+            if alpha > 0:
+                v /= alpha
+        rho = np.hypot(rhobar, beta)
+        cs, sn = rhobar / rho, beta / rho
+        theta = sn * alpha
+        rhobar = -cs * alpha
+        phi = cs * phibar
+        phibar = sn * phibar
+        tau = sn * phi
+        ddnorm += (np.linalg.norm(w) / rho) ** 2
+        x = x + (phi / rho) * w
+        w = v - (theta / rho) * w
+        delta = sn2 * rho
+        gambar = -cs2 * rho
+        rhs = phi - delta * z
+        zbar = rhs / gambar
+        xnorm = np.sqrt(xxnorm + zbar ** 2)
+        gamma = np.hypot(gambar, theta)
+        cs2, sn2 = gambar / gamma, theta / gamma
+        z = rhs / gamma
+        xxnorm += z ** 2
+        Acond = Anorm * np.sqrt(ddnorm)
+        rnorm = phibar
+        Arnorm = alpha * abs(tau)
+        test1 = rnorm / bnorm
+        test2 = Arnorm / (Anorm * rnorm) if Anorm * rnorm > 0 else 0.0
+        test3 = 1.0 / Acond if Acond > 0 else 0.0
+        t1 = test1 / (1.0 + Anorm * xnorm / bnorm)
+        rtol = tol + tol * Anorm * xnorm / bnorm
+        if 1 + test3 <= 1 or 1 + test2 <= 1 or 1 + t1 <= 1:
+            break
+        if test3 <= 1e-8 or test2 <= tol or test1 <= rtol:
+            break
+    return x
+
+
+class _Basis:
+    """xis as one n x K column-major block for the device kernels."""
+
+    def __init__(self, xis, ctx):
+        self.ctx = ctx or default_context()
+        self.Z = np.asfortranarray(np.stack([np.asarray(x, dtype=np.float64) for x in xis], axis=1))
+        self.n, self.K = self.Z.shape
+
+    def params(self, s, X, delta):
+        out = np.empty((self.n, self.K + 3), order="F")
+        lib, cx = self.ctx.lib, self.ctx
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        L.check(lib.gsi_pcga_params(cx.h, L.dptr(self.Z), self.n, self.K, s.ctypes.data_as(L.c_dp),
+                                    X.ctypes.data_as(L.c_dp), float(delta), L.dptr(out)), lib)
+        return out
+
+    def update(self, X, beta_bar, etas, xi_bar):
+        E = np.asfortranarray(np.stack(etas, axis=1))
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        xb = np.ascontiguousarray(xi_bar, dtype=np.float64)
+        out = np.empty(self.n)
+        lib, cx = self.ctx.lib, self.ctx
+        L.check(lib.gsi_pcga_update(cx.h, L.dptr(self.Z), self.n, self.K, X.ctypes.data_as(L.c_dp), float(beta_bar),
+                                    L.dptr(E), E.shape[0], xb.ctypes.data_as(L.c_dp), out.ctypes.data_as(L.c_dp)),
+                lib)
+        return out
+
+
+def _iteration_head(forwardmodel, basis, s, X, delta):
+    """direct.jl:38-46 / lsqr.jl:36-51."""
+    K = basis.K
+    P = basis.params(s, X, delta)                                     # paramstorun
+    results = [np.asarray(forwardmodel(np.ascontiguousarray(P[:, i])), dtype=np.float64) for i in range(K + 3)]
+    hs = results[K + 2]
+    etas = [(results[i] - hs) / delta for i in range(K)]
+    HX = (results[K] - hs) / delta
+    Hs = (results[K + 1] - hs) / delta
+    return etas, HX, Hs, hs
+
+
+def pcgadirect(forwardmodel, s0, X, xis, R, y, *, maxiters=5, delta=SQRT_EPS, xtol=1e-6,
+               callback=lambda s, obs_cal: None, ctx=None):
+    """`pcgadirect(forwardmodel, s0, X, xis, R, y; maxiters=5, delta=sqrt(eps), xtol=1e-6, callback)`
+    (direct.jl:21-67)."""
+    basis = _Basis(xis, ctx)
+    s = np.asarray(s0, dtype=np.float64)
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    Rd = R.toarray() if hasattr(R, "toarray") else np.asarray(R, dtype=np.float64)
+    converged, it = False, 0
+    while not converged and it < maxiters:
+        olds = s
+        etas, HX, Hs, hs = _iteration_head(forwardmodel, basis, s, X, delta)
+        callback(s, hs)                                               # :47
+        E = np.stack(etas, axis=1)
+        HQH = E @ E.T                                                 # :49-53
+        b = np.concatenate([y - hs + Hs, np.zeros(1)])                # :56
+        bigA = np.block([[HQH + Rd, HX[:, None]], [HX[None, :], np.zeros((1, 1))]])   # :57
+        x = np.linalg.pinv(bigA) @ b                                  # :58
+        s = basis.update(X, x[-1], etas, x[:-1])                      # :59-65
+        if np.linalg.norm(s - olds) < xtol:
+            converged = True
+        it += 1
+    return s
+
+
+def pcgalsqr(forwardmodel, s0, X, xis, R, y, *, maxiters=5, delta=SQRT_EPS, xtol=1e-6, ctx=None):
+    """`pcgalsqr(forwardmodel, s0, X, xis, R, y; maxiters=5, delta=sqrt(eps), xtol=1e-6)`
+    (lsqr.jl:20-63).  No `callback` keyword, as in the reference."""
+    basis = _Basis(xis, ctx)
+    s = np.asarray(s0, dtype=np.float64)
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    converged, it = False, 0
+    while not converged and it < maxiters:
+        olds = s
+        etas, HX, Hs, hs = _iteration_head(forwardmodel, basis, s, X, delta)
+        b = np.concatenate([y - hs + Hs, np.zeros(1)])                # :52
+        bigA = PCGALowRankMatrix(etas, HX, R)                         # :53
+        x = _lsqr(bigA.matvec, b)                                     # :54
+        s = basis.update(X, x[-1], etas, x[:-1])                      # :55-61
+        if np.linalg.norm(s - olds) < xtol:
+            converged = True
+        it += 1
+    return s
+
+
+def rga(forwardmodel, s0, X, xis, R, y, S, *, maxiters=5, delta=SQRT_EPS, xtol=1e-6, pcgafunc=pcgadirect,
+        callback=lambda s, obs_cal: None):
+    """`rga(...; pcgafunc=pcgadirect, callback)`  (GeostatInversion.jl:101-103)."""
+    S = np.asarray(S, dtype=np.float64)
+    Rd = R.toarray() if hasattr(R, "toarray") else np.asarray(R, dtype=np.float64)
+    return pcgafunc(lambda x: S @ forwardmodel(x), s0, X, xis, S @ Rd @ S.T, S @ np.asarray(y, dtype=np.float64),
+                    maxiters=maxiters, delta=delta, xtol=xtol, callback=callback)
+
+
+pcga = pcgadirect     # GeostatInversion.jl:105
