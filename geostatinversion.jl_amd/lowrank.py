@@ -50,6 +50,7 @@ class LowRankCovMatrix:
         return self
 
     eltype = np.float64                    # lowrank.jl:46-48
+    __array_ufunc__ = None                 # let `ndarray @ lrcm` reach __rmatmul__
 
     def matmul(self, B):
         """`*(A::LowRankCovMatrix, B::Matrix)` (lowrank.jl:115-121) / vector `*` (:135-139)."""

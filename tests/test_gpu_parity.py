@@ -94,7 +94,7 @@ def test_svd_tall(gsi, ctx, n, l):
     S, V = gsi.svd_tall(W)
     Uref, Sref, _ = np.linalg.svd(W, full_matrices=False)
     assert np.all(np.diff(S) <= 0)
-    assert np.abs(S - Sref).max() <= 1e-13 * Sref[0]
+    assert np.abs(S - Sref).max() <= 1e-12 * Sref[0]
     assert np.abs(V.T @ V - np.eye(l)).max() < 1e-12
     for i in range(l):
         if i + 1 < l and (Sref[i] - Sref[i + 1]) < 1e-6 * Sref[0]:
