@@ -75,50 +75,46 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(
   const int b_c = tid >> 5;
   const int b_k = tid & 31;
 
-  // Addresses are split into a wave-uniform 64-bit base (SGPRs) and a small per-thread 32-bit
-  // element offset, so every load is `global_load_dwordx2 v, v_off, s[base]` and no per-load
-  // 64-bit pointer has to stay live across the MFMA loop.
-  const uint32_t a_toff = TRANS_A ? (uint32_t)(a_k + (int64_t)a_r * lda) : (uint32_t)(a_r + (int64_t)a_k * lda);
-  const uint32_t b_toff = (uint32_t)(b_k + (int64_t)b_c * ldb);
+  // Addressing: ONE wave-uniform 64-bit base per operand (advanced per tile, lives in SGPRs) plus
+  // per-thread 32-bit BYTE offsets, so every load is `global_load_dwordx2 v, v_off, s[base]`.
+  // (Per-load 64-bit uniform bases overflow the SGPR file: hipcc then spills them to VGPR lanes
+  // and threads v_readlane/v_writelane chains between the MFMAs -- measured 95 vs 64 cycles/MFMA.)
+  const uint32_t a_off0 = 8u * (TRANS_A ? (uint32_t)(a_k + (int64_t)a_r * lda) : (uint32_t)(a_r + (int64_t)a_k * lda));
+  const uint32_t a_step_c = 8u * (uint32_t)((TRANS_A ? 8 : 4) * lda);
+  const uint32_t b_off0 = 8u * (uint32_t)(b_k + (int64_t)b_c * ldb);
+  const uint32_t b_step_c = 8u * (uint32_t)(8 * ldb);
+  const char* const Abase = reinterpret_cast<const char*>(TRANS_A ? A + r0 * lda : A + r0);
+  const char* const Bbase = reinterpret_cast<const char*>(B + c0 * ldb);
   // interior workgroups (all 64 rows and all NT*16 columns in range) take an unpredicated
   // load path on full-depth tiles; the branch is workgroup-uniform
   const bool wg_full = (r0 + BMT <= M) && (c0 + NT * 16 <= L);
   auto prefetch = [&](int64_t k0) {
+    const char* Ab = Abase + 8 * (TRANS_A ? k0 : k0 * lda);   // uniform
+    const char* Bb = Bbase + 8 * k0;                          // uniform
+    // launder the strides so the 28 per-load offsets are recomputed per tile (one VALU add each)
+    // instead of staying live in 28 VGPRs across the MFMA loop
+    uint32_t a_step = a_step_c, b_step = b_step_c;
+    asm volatile("" : "+s"(a_step), "+s"(b_step));
     if (wg_full && k0 + BK <= kend) {
-      if (TRANS_A) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) a_reg[it] = (A + (k0 + (r0 + 8 * it) * lda))[a_toff];
-      } else {
+      for (int it = 0; it < 8; ++it)
+        a_reg[it] = *reinterpret_cast<const double*>(Ab + (a_off0 + (uint32_t)it * a_step));
 #pragma unroll
-        for (int it = 0; it < 8; ++it) a_reg[it] = (A + (r0 + (k0 + 4 * it) * lda))[a_toff];
-      }
-#pragma unroll
-      for (int it = 0; it < 2 * NT; ++it) b_reg[it] = (B + (k0 + (c0 + 8 * it) * ldb))[b_toff];
+      for (int it = 0; it < 2 * NT; ++it)
+        b_reg[it] = *reinterpret_cast<const double*>(Bb + (b_off0 + (uint32_t)it * b_step));
       return;
     }
-    if (TRANS_A) {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const double* base = A + (k0 + (r0 + 8 * it) * lda);   // uniform
-        const int64_t r = r0 + a_r + 8 * it;
-        const int64_t k = k0 + a_k;
-        a_reg[it] = (r < M && k < kend) ? base[a_toff] : 0.0;
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const double* base = A + (r0 + (k0 + 4 * it) * lda);   // uniform
-        const int64_t r = r0 + a_r;
-        const int64_t k = k0 + a_k + 4 * it;
-        a_reg[it] = (r < M && k < kend) ? base[a_toff] : 0.0;
-      }
+    for (int it = 0; it < 8; ++it) {
+      const int64_t r = TRANS_A ? r0 + a_r + 8 * it : r0 + a_r;
+      const int64_t k = TRANS_A ? k0 + a_k : k0 + a_k + 4 * it;
+      a_reg[it] = (r < M && k < kend) ? *reinterpret_cast<const double*>(Ab + (a_off0 + (uint32_t)it * a_step)) : 0.0;
     }
 #pragma unroll
     for (int it = 0; it < 2 * NT; ++it) {
-      const double* base = B + (k0 + (c0 + 8 * it) * ldb);     // uniform
       const int64_t c = c0 + b_c + 8 * it;
       const int64_t k = k0 + b_k;
-      b_reg[it] = (c < L && k < kend) ? base[b_toff] : 0.0;
+      b_reg[it] = (c < L && k < kend) ? *reinterpret_cast<const double*>(Bb + (b_off0 + (uint32_t)it * b_step)) : 0.0;
     }
   };
 
