@@ -86,7 +86,7 @@ def load(path=None):
         raise ImportError(
             f"{p} not found: build it with `python {os.path.join(_HERE, 'build.py')}` (needs hipcc). "
             "This package has no CPU fallback.")
-    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(p, mode=C.RTLD_LOCAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res

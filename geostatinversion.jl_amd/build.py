@@ -62,7 +62,7 @@ def build(force=False, verbose=False):
                 if verbose and warn:
                     print(warn)
     if jobs or force or _newer(LIB, objs):
-        run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl"])
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,-Bsymbolic", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

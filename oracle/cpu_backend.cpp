@@ -1,0 +1,169 @@
+// cpu_backend.cpp -- TEST INFRASTRUCTURE ONLY.  A gsi::Backend over the C restatement
+// (gsi_oracle.c) so that the SAME pipeline.cpp / api.cpp that ship in libgsi_hip.so can be run
+// on a machine without a GPU: the C ABI surface, the row-sharded order of operations and the
+// collective sequence are then testable under `pytest -m "not gpu"` (world_size-2 gloo).
+// Built by oracle/Makefile into oracle/_build/libgsi_cpuref.so.  The product package never
+// loads this library (geostatinversion.jl_amd/_lib.py opens libgsi_hip.so only).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+#include "../include/gsi_hip.h"
+#include "../geostatinversion.jl_amd/csrc/backend.hpp"
+
+extern "C" {
+void gsio_gemm_nn(int64_t, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, double, double*, int64_t);
+void gsio_gemm_tn(int64_t, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, double, double*, int64_t);
+int gsio_lu_L(double*, int64_t, int64_t, int64_t, int32_t*);
+void gsio_qr_thinQ(double*, int64_t, int64_t, int64_t, int, double*, int32_t*);
+int gsio_svd_tall(double*, int64_t, int64_t, int64_t, double*);
+int gsio_chol_upper(double*, int64_t);
+void gsio_trsm_right_upper(double*, int64_t, int64_t, int64_t, const double*);
+void gsio_center_rows(double*, int64_t, int64_t, int64_t);
+
+// collectives supplied by the test harness (torch.distributed/gloo through ctypes callbacks)
+typedef void (*gsi_cpuref_allreduce_fn)(double* buf, int64_t count);
+typedef void (*gsi_cpuref_allgather_fn)(const double* send, double* recv, int64_t count);
+static gsi_cpuref_allreduce_fn g_allreduce = nullptr;
+static gsi_cpuref_allgather_fn g_allgather = nullptr;
+void gsi_cpuref_set_collectives(gsi_cpuref_allreduce_fn ar, gsi_cpuref_allgather_fn ag) {
+  g_allreduce = ar;
+  g_allgather = ag;
+}
+}
+
+namespace gsi {
+namespace {
+
+class CpuBackend : public Backend {
+ public:
+  const char* name() const override { return "cpu-reference (test only)"; }
+  double* alloc(size_t count) override {
+    if (count == 0) count = 1;
+    double* p = (double*)std::malloc(count * sizeof(double));
+    if (!p) throw Error(GSI_ERR_OOM, "malloc failed");
+    in_use_ += (int64_t)(count * sizeof(double));
+    sizes_.push_back({p, count * sizeof(double)});
+    return p;
+  }
+  void release(double* p) override {
+    if (!p) return;
+    for (size_t i = 0; i < sizes_.size(); ++i)
+      if (sizes_[i].first == p) { in_use_ -= (int64_t)sizes_[i].second; sizes_[i] = sizes_.back(); sizes_.pop_back(); break; }
+    std::free(p);
+  }
+  int64_t bytes_in_use() const override { return in_use_; }
+  void upload2d(double* d, int64_t ldd, const double* h, int64_t ldh, int64_t r, int64_t c) override { copy2d(d, ldd, h, ldh, r, c); }
+  void download2d(double* h, int64_t ldh, const double* s, int64_t lds, int64_t r, int64_t c) override { copy2d(h, ldh, s, lds, r, c); }
+  void copy2d(double* d, int64_t ldd, const double* s, int64_t lds, int64_t r, int64_t c) override {
+    for (int64_t j = 0; j < c; ++j) std::memmove(d + j * ldd, s + j * lds, sizeof(double) * (size_t)r);
+  }
+  void fill_zero(double* p, size_t count) override { std::memset(p, 0, count * sizeof(double)); }
+  void sync() override {}
+  void gemm_nn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda, const double* B,
+               int64_t ldb, double beta, double* C, int64_t ldc) override {
+    gsio_gemm_nn(m, l, k, alpha, A, lda, B, ldb, beta, C, ldc);
+  }
+  void gemm_tn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda, const double* B,
+               int64_t ldb, double beta, double* C, int64_t ldc) override {
+    gsio_gemm_tn(m, l, k, alpha, A, lda, B, ldb, beta, C, ldc);
+  }
+  void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv) override {
+    const int info = gsio_lu_L(Y, m, l, ld, ipiv);
+    if (info && !lu_info_) lu_info_ = info;
+  }
+  void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R) override {
+    gsio_qr_thinQ(Y, m, l, ld, 0, R, nullptr);   // unpivoted, like the HIP backend (same range)
+  }
+  void svd_small(double* G, int64_t l, double* U, double* S) override {
+    gsio_svd_tall(G, l, l, l, S);
+    std::memcpy(U, G, sizeof(double) * (size_t)l * (size_t)l);
+  }
+  void chol_upper(double* B, int64_t j) override {
+    const int info = gsio_chol_upper(B, j);
+    if (info && !chol_info_) chol_info_ = info;
+  }
+  void trsm_right_upper(double* F, int64_t m, int64_t j, int64_t ldf, const double* C) override {
+    gsio_trsm_right_upper(F, m, j, ldf, C);
+  }
+  void scale_cols_sqrt(double* U, int64_t l, const double* S, int64_t K) override {
+    for (int64_t c = 0; c < l; ++c) {
+      const double s = c < K ? std::sqrt(S[c]) : 0.0;
+      for (int64_t i = 0; i < l; ++i) U[i + c * l] *= s;
+    }
+  }
+  void center_rows(double* S, int64_t n, int64_t N, int64_t ld) override { gsio_center_rows(S, n, N, ld); }
+  void randn(double* p, size_t count, uint64_t seed) override {
+    std::mt19937_64 g(seed);
+    std::normal_distribution<double> d;
+    for (size_t i = 0; i < count; ++i) p[i] = d(g);
+  }
+  void fill_gridcov(double* A, int64_t lda, int64_t nx, int64_t ny, double ell, int kind, int64_t row0,
+                    int64_t mloc) override {
+    const int64_t n = nx * ny;
+    for (int64_t c = 0; c < n; ++c)
+      for (int64_t r = 0; r < mloc; ++r) {
+        const int64_t gi = row0 + r;
+        const double dx = (double)(gi / ny) - (double)(c / ny), dy = (double)(gi % ny) - (double)(c % ny);
+        const double d2 = dx * dx + dy * dy;
+        A[r + c * lda] = kind == 0 ? std::exp(-d2 / (2 * ell * ell)) : std::exp(-std::sqrt(d2) / ell);
+      }
+  }
+  void colnorms(const double* Y, int64_t m, int64_t c, int64_t ld, double* out) override {
+    for (int64_t j = 0; j < c; ++j) {
+      double s = 0.0;
+      for (int64_t i = 0; i < m; ++i) s += Y[i + j * ld] * Y[i + j * ld];
+      out[j] = std::sqrt(s);
+    }
+  }
+  void axpy(int64_t n, double a, const double* x, double* y) override { for (int64_t i = 0; i < n; ++i) y[i] += a * x[i]; }
+  double dot(int64_t n, const double* x, const double* y) override { double s = 0; for (int64_t i = 0; i < n; ++i) s += x[i] * y[i]; return s; }
+  double nrm2(int64_t n, const double* x) override { return std::sqrt(dot(n, x, x)); }
+  void scal_copy(int64_t n, double a, const double* x, double* y) override { for (int64_t i = 0; i < n; ++i) y[i] = a * x[i]; }
+  int take_error(std::string* msg) override {
+    if (lu_info_) {
+      if (msg) *msg = "SingularException(" + std::to_string(lu_info_) + "): exactly zero pivot in lu()";
+      lu_info_ = chol_info_ = 0;
+      return GSI_ERR_SINGULAR;
+    }
+    if (chol_info_) {
+      if (msg) *msg = "PosDefException: matrix is not positive definite; Cholesky failed at " + std::to_string(chol_info_);
+      chol_info_ = 0;
+      return GSI_ERR_NOT_POSDEF;
+    }
+    return 0;
+  }
+  void profile(bool) override {}
+  void phase_begin(Phase) override {}
+  void phase_end(Phase p) override { counts_[p] += 1; }
+  void phase_reset() override { for (auto& c : counts_) c = 0; }
+  void phase_times(double* ms, int64_t* counts) override { for (int i = 0; i < PH_COUNT; ++i) { ms[i] = 0.0; counts[i] = counts_[i]; } }
+
+ private:
+  std::vector<std::pair<double*, size_t>> sizes_;
+  int64_t in_use_ = 0;
+  int lu_info_ = 0, chol_info_ = 0;
+  int64_t counts_[PH_COUNT] = {0};
+};
+
+class CallbackComm : public Comm {
+ public:
+  CallbackComm(int n, int r) { nranks = n; rank = r; }
+  void allreduce_sum(double* buf, size_t count) override {
+    if (!g_allreduce) throw Error(GSI_ERR_RCCL, "cpuref: collectives not registered");
+    g_allreduce(buf, (int64_t)count);
+  }
+  void allgather(const double* send, double* recv, size_t count) override {
+    if (!g_allgather) throw Error(GSI_ERR_RCCL, "cpuref: collectives not registered");
+    g_allgather(send, recv, (int64_t)count);
+  }
+};
+}  // namespace
+
+Backend* make_backend(int) { return new CpuBackend(); }
+Comm* make_comm(Backend*, int nranks, int rank, const void*) { return new CallbackComm(nranks, rank); }
+void comm_unique_id(void* id_out) { std::memset(id_out, 0, GSI_UNIQUE_ID_BYTES); }
+const char* backend_name() { return "cpu-reference (test only)"; }
+}  // namespace gsi

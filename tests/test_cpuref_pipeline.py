@@ -1,0 +1,129 @@
+"""pipeline.cpp + api.cpp (the code that ships in libgsi_hip.so) driven through the C ABI on the
+CPU reference backend, against the scipy oracle and the golden vectors.  This checks the host-side
+order of operations, argument checking and error mapping without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from helpers import gaussian_cov, exact_rank_matrix, powerlaw_fields, rel_sv_err
+import cpuref
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def cx(gsi):
+    lib = cpuref.load_cpuref()
+    assert lib.gsi_backend_name().startswith(b"cpu-reference")
+    c = gsi.Context(0, lib=lib)
+    yield c
+    c.close()
+
+
+def test_golden_dense(gsi, cx):
+    g = np.load(os.path.join(GOLD, "dense_gauss_n192.npz"))
+    A = gaussian_cov(int(g["grid"][0]), int(g["grid"][1]), float(g["ell"]))
+    K, p, q = int(g["K"]), int(g["p"]), int(g["q"])
+    Z, S = gsi.randsvd(A, K, p, q, Omega=g["Omega"], return_S=True, ctx=cx)
+    assert rel_sv_err(S, g["S"], K) < 1e-9
+    assert orc.xis_error_up_to_sign(Z, g["Z"], K) < 1e-6
+    assert np.all(Z[:, K:] == 0)
+    L, piv = gsi.lu_L(A @ g["Omega"], return_pivots=True, ctx=cx)
+    assert np.array_equal(piv, g["lu_pivots"])
+    assert np.abs(L - g["lu_L"]).max() < 1e-11
+
+
+@pytest.mark.parametrize("q", [0, 3])
+def test_golden_exp(gsi, cx, q):
+    from helpers import exponential_cov
+    g = np.load(os.path.join(GOLD, "dense_exp_n144.npz"))
+    A = exponential_cov(12, 12, float(g["ell"]))
+    Z, S = gsi.randsvd(A, 7, 3, q, Omega=g["Omega"], return_S=True, ctx=cx)
+    assert rel_sv_err(S, g[f"S_q{q}"], 7) < 1e-9
+    assert orc.xis_error_up_to_sign(Z, g[f"Z_q{q}"], 7) < 1e-6
+
+
+def test_golden_lowrank(gsi, cx):
+    g = np.load(os.path.join(GOLD, "lowrank_n100_N24.npz"))
+    lrcm = gsi.LowRankCovMatrix(g["fields"], ctx=cx)
+    assert np.abs(lrcm.todense() - g["dense"]).max() < 1e-12 * np.abs(g["dense"]).max()
+    Z = gsi.randsvd(lrcm, int(g["K"]), int(g["p"]), int(g["q"]), Omega=g["Omega"])
+    assert orc.xis_error_up_to_sign(Z, g["xis"].T, int(g["K"])) < 1e-6
+    lrcm.close()
+
+
+@pytest.mark.parametrize("n,m", [(10, 2), (100, 10), (100, 25)])
+def test_rangefinders_exact_rank(gsi, cx, n, m):
+    """test/testrmf.jl:11-19 through the C ABI."""
+    rng = np.random.default_rng(n * m)
+    A = exact_rank_matrix(rng, n, m)
+    gsi.RandMatFact.seed(1)
+    Q = gsi.rangefinder(A, ctx=cx)
+    assert abs(Q.shape[1] - m) <= 1 and np.linalg.norm(A - Q @ Q.T @ A) < 1e-8
+    Q = gsi.rangefinder(A, m, 2, Omega=rng.standard_normal((n, m)), ctx=cx)
+    assert np.linalg.norm(A - Q @ Q.T @ A) < 1e-8
+
+
+def test_nystrom_kat(gsi, cx):
+    g = np.load(os.path.join(GOLD, "nystrom_kat.npz"))
+    gsi.RandMatFact.seed(2)
+    Q = gsi.rangefinder(g["A"], ctx=cx)
+    U, Sig = gsi.eig_nystrom(g["A"], Q, ctx=cx)
+    assert np.linalg.norm(Sig ** 2 - g["eigenvalues"]) < 1e-8
+
+
+def test_error_mapping(gsi, cx):
+    with pytest.raises(gsi.GsiError) as ei:
+        gsi.rangefinder(np.eye(6), 2, -3, Omega=np.ones((6, 2)), ctx=cx)
+    assert ei.value.code == 2 and "numiterations=-3" in str(ei.value)
+    with pytest.raises(gsi.GsiError) as ei:
+        gsi.lu_L(np.zeros((5, 2)), ctx=cx)
+    assert ei.value.code == 3
+    with pytest.raises(gsi.GsiError) as ei:
+        gsi.rangefinder(np.eye(6), 9, 1, Omega=np.ones((6, 9)), ctx=cx)
+    assert ei.value.code == 1
+    with pytest.raises(gsi.GsiError) as ei:
+        gsi.eig_nystrom(-np.eye(4), np.eye(4)[:, :2], ctx=cx)       # not positive definite
+    assert ei.value.code == 7
+    with pytest.raises(ValueError):
+        gsi.randsvd(np.eye(6), 2, 1, 1, Omega=np.ones((5, 3)), ctx=cx)
+
+
+def test_operator_products_and_sizes(gsi, cx):
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((30, 20))
+    op = gsi.dense_operator(cx, A)
+    assert op.shape == (30, 20) and op.size(1) == 30 and op.size(2) == 20
+    X = rng.standard_normal((20, 4))
+    assert np.allclose(op.matmul(X), A @ X)
+    Y = rng.standard_normal((30, 3))
+    assert np.allclose(op.rmatmul_t(Y), A.T @ Y)
+    with pytest.raises(IndexError):
+        op.size(3)
+    op.close()
+
+
+def test_pcga_consumers(gsi, cx):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(31)
+    M, N, mu = 8, 64, 10.0
+    x = rng.standard_normal(N)
+    Q0 = rng.standard_normal((M, N))
+    Qc = Q0.T @ Q0
+    w, V = np.linalg.eigh(Qc)
+    truep = (V * np.sqrt(np.clip(w, 0, None))) @ V.T @ rng.standard_normal(N) + mu
+    forward = lambda pv: pv * x
+    Om = rng.standard_normal((N, M + 1))
+    Z = gsi.randsvd(Qc, M, 1, 3, Omega=Om, ctx=cx)
+    xis = [np.ascontiguousarray(Z[:, i]) for i in range(M)]
+    X = np.full(N, mu)
+    R = 1e-8 * sp.identity(N, format="csc")
+    y = forward(truep) + 1e-4 * rng.standard_normal(N)
+    got = gsi.pcgadirect(forward, X.copy(), X, xis, R, y, ctx=cx)
+    ref = orc.pcgadirect(forward, X.copy(), X, xis, R, y)
+    assert np.linalg.norm(got - truep) / np.linalg.norm(truep) < 2e-2
+    assert np.linalg.norm(got - ref) < 1e-6 * np.linalg.norm(ref)
+    got = gsi.pcgalsqr(forward, X.copy(), X, xis, R, y, ctx=cx)
+    assert np.linalg.norm(got - truep) / np.linalg.norm(truep) < 2e-2

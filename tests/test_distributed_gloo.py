@@ -1,0 +1,145 @@
+"""N > 1 path on CPU: the row-sharded pipeline (pipeline.cpp, exactly the code in libgsi_hip.so)
+on the CPU reference backend, one process per rank, collectives over torch.distributed/gloo.
+On the GPU the same calls go to RCCL; here they are ctypes callbacks -- the order of operations,
+the shard arithmetic and the collective sequence are what is under test."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, HERE)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["OMP_NUM_THREADS"] = "2"
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+        import gsi_amd as gsi
+        import cpuref
+        from oracle import oracle as orc
+        from helpers import gaussian_cov, exponential_cov, powerlaw_fields, rel_sv_err
+
+        lib = cpuref.load_cpuref()
+
+        def allreduce(buf, count):
+            t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(count,)))
+            dist.all_reduce(t)                                     # in place on the library's buffer
+
+        def allgather(send, recv, count):
+            s = torch.from_numpy(np.ctypeslib.as_array(send, shape=(count,)).copy())
+            outs = [torch.empty(count, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(outs, s)
+            np.ctypeslib.as_array(recv, shape=(world * count,))[:] = torch.cat(outs).numpy()
+
+        cbs = (cpuref.ALLREDUCE_FN(allreduce), cpuref.ALLGATHER_FN(allgather))
+        lib.gsi_cpuref_set_collectives(*cbs)
+        ctx = gsi.Context(0, lib=lib)
+        ctx.comm_init(world, rank, b"\0" * 128)
+        assert ctx.rank() == (rank, world)
+        results = {}
+        rng = np.random.default_rng(7)                              # same stream on every rank
+
+        # dense, n not divisible by the world size; q = 0 exercises the TSQR tree, q = 2 the LU exchange
+        A = gaussian_cov(13, 11, 3.0)                               # n = 143
+        for qq in (0, 2):
+            K, p = 10, 6
+            Om = rng.standard_normal((143, K + p))
+            Z, S = gsi.randsvd(A, K, p, qq, Omega=Om, return_S=True, ctx=ctx)
+            Zr, Sr, Qr = orc.randsvd_full(A, K, p, qq, Om)
+            results[f"dense_q{qq}_sv"] = rel_sv_err(S, Sr, K)
+            results[f"dense_q{qq}_xis"] = orc.xis_error_up_to_sign(Z, Zr, K)
+            Q = gsi.rangefinder(A, K + p, qq, Omega=Om, ctx=ctx)
+            results[f"dense_q{qq}_orth"] = float(np.abs(Q.T @ Q - np.eye(K + p)).max())
+            s1 = np.linalg.svd(Q.T @ A, compute_uv=False)
+            s2 = np.linalg.svd(Qr.T @ A, compute_uv=False)
+            results[f"dense_q{qq}_range"] = rel_sv_err(s1, s2, K)
+        # non-symmetric operator (Jacobian-like), shards shorter than... still >= l
+        B = rng.standard_normal((90, 60)) @ np.diag(np.logspace(0, -4, 60)) @ rng.standard_normal((60, 60))
+        Om = rng.standard_normal((60, 12))
+        Q = gsi.rangefinder(B, 12, 1, Omega=Om, ctx=ctx)
+        Qr = orc.rangefinder(B, 12, 1, Om)
+        results["rect_range"] = rel_sv_err(np.linalg.svd(Q.T @ B, compute_uv=False),
+                                           np.linalg.svd(Qr.T @ B, compute_uv=False), 8)
+        # a shard shorter than the sketch width -> gathered-QR fallback
+        C = exponential_cov(6, 5, 3.0)                              # n = 30, l = 14: shards of 15/15 (world 2) or 10 (world 3)
+        Om = rng.standard_normal((30, 14))
+        Z, S = gsi.randsvd(C, 10, 4, 1, Omega=Om, return_S=True, ctx=ctx)
+        Zr, Sr, _ = orc.randsvd_full(C, 10, 4, 1, Om)
+        results["short_sv"] = rel_sv_err(S, Sr, 10)
+        # LowRankCovMatrix, sample rows sharded
+        fields = powerlaw_fields(rng, (9, 9), 20)
+        Om = rng.standard_normal((81, 9))
+        lr = gsi.LowRankCovMatrix(fields, ctx=ctx)
+        Z = gsi.randsvd(lr, 6, 3, 3, Omega=Om)
+        xr, _ = orc.getxis_fields(fields, 6, 3, 3, Om)
+        results["lowrank_xis"] = orc.xis_error_up_to_sign(Z, np.array(xr).T, 6)
+        X = rng.standard_normal((81, 4))
+        results["lowrank_mul"] = float(np.abs(lr.matmul(X) - orc.LowRankCovMatrix(fields).matmul(X)).max())
+        lr.close()
+        # operator products gathered to every rank
+        op = gsi.dense_operator(ctx, B)
+        X = rng.standard_normal((60, 3))
+        results["mul"] = float(np.abs(op.matmul(X) - B @ X).max())
+        Y = rng.standard_normal((90, 3))
+        results["mul_t"] = float(np.abs(op.rmatmul_t(Y) - B.T @ Y).max())
+        op.close()
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", results))
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pipeline_gloo(world):
+    sys.path.insert(0, HERE)
+    import cpuref
+    cpuref.build()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = []
+    try:
+        for _ in range(world):
+            out.append(q.get(timeout=240))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for rank, status, payload in out:
+        assert status == "ok", f"rank {rank}:\n{payload}"
+    for rank, _, res in out:
+        for k, v in res.items():
+            tol = 1e-6 if k.endswith("xis") else 1e-9
+            if k.endswith("orth") or k in ("mul", "mul_t", "lowrank_mul"):
+                tol = 1e-11
+            assert v < tol, (rank, k, v)
+    # every rank computed the same replicated result
+    r0 = out[0][2]
+    for _, _, res in out[1:]:
+        for k in r0:
+            assert abs(res[k] - r0[k]) < 1e-12 + 1e-6 * abs(r0[k])

@@ -265,3 +265,74 @@ def test_pcga_end_to_end(gsi, ctx, M, N, mu):
     if M < N / 6:
         popt = gsi.pcgalsqr(forward, X.copy(), X, xis, R, yobs)
         assert np.linalg.norm(popt - truep) / np.linalg.norm(truep) < 2e-2
+
+
+# ---- committed golden vectors (tests/golden/, generated by make_golden.py from the scipy oracle) ----
+import os as _os
+_GOLD = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+def test_golden_dense_gauss(gsi, ctx):
+    g = np.load(_os.path.join(_GOLD, "dense_gauss_n192.npz"))
+    A = gaussian_cov(int(g["grid"][0]), int(g["grid"][1]), float(g["ell"]))
+    K, p, q = int(g["K"]), int(g["p"]), int(g["q"])
+    Z, S = gsi.randsvd(A, K, p, q, Omega=g["Omega"], return_S=True)
+    assert rel_sv_err(S, g["S"], K) < 1e-9
+    assert orc.xis_error_up_to_sign(Z, g["Z"], K) < 1e-6
+    L, piv = gsi.lu_L(A @ g["Omega"], return_pivots=True)
+    assert np.array_equal(piv, g["lu_pivots"])
+    assert np.abs(L - g["lu_L"]).max() < 1e-11
+
+
+@pytest.mark.parametrize("q", [0, 3])
+def test_golden_dense_exp(gsi, ctx, q):
+    g = np.load(_os.path.join(_GOLD, "dense_exp_n144.npz"))
+    A = exponential_cov(12, 12, float(g["ell"]))
+    Z, S = gsi.randsvd(A, 7, 3, q, Omega=g["Omega"], return_S=True)
+    assert rel_sv_err(S, g[f"S_q{q}"], 7) < 1e-9
+    assert orc.xis_error_up_to_sign(Z, g[f"Z_q{q}"], 7) < 1e-6
+
+
+def test_golden_lowrank(gsi, ctx):
+    g = np.load(_os.path.join(_GOLD, "lowrank_n100_N24.npz"))
+    lrcm = gsi.LowRankCovMatrix(g["fields"])
+    assert np.abs(lrcm.todense() - g["dense"]).max() < 1e-12 * np.abs(g["dense"]).max()
+    Z = gsi.randsvd(lrcm, int(g["K"]), int(g["p"]), int(g["q"]), Omega=g["Omega"])
+    assert orc.xis_error_up_to_sign(Z, g["xis"].T, int(g["K"])) < 1e-6
+
+
+# ---- BASELINE.json configs[1] at full size: size-independent properties -----------------------------
+def test_full_size_C2_properties(gsi, ctx):
+    """n = 65536 dense fp64 covariance resident in HBM (34 GB), K = 128, p = 32, q = 2.  The oracle
+    cannot run at this size in seconds, so check what must hold at any size:
+      Z'Z = diag(S[:K]) (Z = V sqrt(S) with orthonormal V), trailing p columns zero, S descending,
+      A v_i = s_i v_i for the leading vectors (A symmetric PSD), and device-generated A rows match
+      the closed form."""
+    grid, ell, K, p, q = 256, 16.0, 128, 32, 2
+    n, l = grid * grid, K + p
+    op = gsi.gridcov_operator(ctx, grid, grid, ell, 0)
+    Om = gsi.DeviceMatrix(ctx, n, l).randn(99)
+    Z = gsi.DeviceMatrix(ctx, n, l)
+    S = gsi.DeviceMatrix(ctx, l, 1)
+    gsi._lib.check(ctx.lib.gsi_randsvd_dev(ctx.h, op.h, Om.h, K, p, q, Z.h, S.h), ctx.lib)
+    Zh, Sh = Z.to_host(), S.to_host()[:, 0]
+    assert np.all(np.diff(Sh) <= 0) and Sh[K - 1] > 0
+    assert np.all(Zh[:, K:] == 0.0)
+    G = Zh[:, :K].T @ Zh[:, :K]
+    assert np.abs(G - np.diag(Sh[:K])).max() < 1e-10 * Sh[0]
+    V = Zh[:, :8] / np.sqrt(Sh[:8])
+    AV = op.matmul(V)
+    resid = np.linalg.norm(AV - V * Sh[:8], axis=0) / Sh[:8]
+    assert resid.max() < 1e-6, resid
+    # a few entries of A against the closed form exp(-d^2 / (2 ell^2)) through e_i probes
+    E = np.zeros((n, 2))
+    E[12345, 0] = 1.0
+    E[65535, 1] = 1.0
+    cols = op.matmul(E)
+    for c, i in enumerate((12345, 65535)):
+        xi, yi = divmod(i, grid)
+        jj = np.arange(n)
+        d2 = (jj // grid - xi) ** 2 + (jj % grid - yi) ** 2
+        assert np.abs(cols[:, c] - np.exp(-d2 / (2 * ell * ell))).max() < 1e-14
+    for h in (Om, Z, S, op):
+        h.close()
