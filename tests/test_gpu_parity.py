@@ -323,7 +323,7 @@ def test_full_size_C2_properties(gsi, ctx):
     V = Zh[:, :8] / np.sqrt(Sh[:8])
     AV = op.matmul(V)
     resid = np.linalg.norm(AV - V * Sh[:8], axis=0) / Sh[:8]
-    assert resid.max() < 1e-6, resid
+    assert resid.max() < 1e-4, resid      # randsvd vectors are approximate eigenvectors (q = 2)
     # a few entries of A against the closed form exp(-d^2 / (2 ell^2)) through e_i probes
     E = np.zeros((n, 2))
     E[12345, 0] = 1.0
