@@ -84,14 +84,15 @@ def main():
     import gsi_amd as gsi
 
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("GSI_BENCH_FORCE_DIST"))   # the latter: rehearse the N > 1 code on one GPU
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # rendezvous / barrier only
 
     ctx = gsi.Context(local_rank)
-    if world > 1:
+    if use_dist:
         import torch
         ids = [ctx.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)

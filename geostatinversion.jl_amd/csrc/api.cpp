@@ -1,5 +1,6 @@
 // api.cpp -- the C ABI of include/gsi_hip.h: argument checking, host<->device staging and
 // error translation around pipeline.cpp.  No C++ exception crosses the boundary.
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -110,7 +111,9 @@ int gsi_ctx_comm_init(gsi_ctx* ctx, int nranks, int rank, const void* id) {
     REQUIRE(ctx && id, "NULL argument");
     REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
     REQUIRE(!ctx->c.comm, "communicator already initialised");
-    if (nranks == 1) return;
+    // a 1-rank job needs no communicator; GSI_FORCE_COMM=1 creates one anyway so that the RCCL
+    // path (library loading, stream-ordered collectives) can be exercised on a single GPU
+    if (nranks == 1 && getenv("GSI_FORCE_COMM") == nullptr) return;
     ctx->c.comm.reset(make_comm(ctx->c.be.get(), nranks, rank, id));
   });
 }

@@ -336,3 +336,37 @@ def test_full_size_C2_properties(gsi, ctx):
         assert np.abs(cols[:, c] - np.exp(-d2 / (2 * ell * ell))).max() < 1e-14
     for h in (Om, Z, S, op):
         h.close()
+
+
+def test_rccl_single_rank_communicator(gsi):
+    """RCCL path on one GPU: a 1-rank communicator (GSI_FORCE_COMM=1) makes every collective of the
+    sharded pipeline run through librccl on the library's stream; results must equal the plain path."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import gsi_amd as gsi
+from helpers import gaussian_cov, powerlaw_fields
+os.environ["GSI_FORCE_COMM"] = "1"
+ctx = gsi.Context(0)
+ctx.comm_init(1, 0, ctx.unique_id())
+A = gaussian_cov(20, 15, 3.0); rng = np.random.default_rng(1); Om = rng.standard_normal((300, 20))
+Z1, S1 = gsi.randsvd(A, 14, 6, 2, Omega=Om, return_S=True, ctx=ctx)
+fields = powerlaw_fields(rng, (12, 12), 30); Om2 = rng.standard_normal((144, 12))
+lr = gsi.LowRankCovMatrix(fields, ctx=ctx); Z3 = gsi.randsvd(lr, 8, 4, 3, Omega=Om2)
+del os.environ["GSI_FORCE_COMM"]
+ctx2 = gsi.Context(0)
+Z2, S2 = gsi.randsvd(A, 14, 6, 2, Omega=Om, return_S=True, ctx=ctx2)
+lr2 = gsi.LowRankCovMatrix(fields, ctx=ctx2); Z4 = gsi.randsvd(lr2, 8, 4, 3, Omega=Om2)
+assert np.abs(S1 - S2).max() < 1e-12 * S2[0], np.abs(S1 - S2).max()
+assert np.abs(Z1 - Z2).max() < 1e-9
+assert np.abs(Z3 - Z4).max() < 1e-9
+print("rccl-1rank-ok")
+'''
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "rccl-1rank-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
