@@ -38,7 +38,7 @@ __device__ inline double wave_allsum(double v) {
 
 // grid.x = number of block pairs in this round
 __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __restrict__ G, int l, int lp,
-                                                                   int nblk, int round, double tol,
+                                                                   int nblk, int round, double tol2,
                                                                    int32_t* __restrict__ rotcount,
                                                                    int inner_sweeps) {
   extern __shared__ double cols[];  // [SVD_C][lp] followed by one int slot (single LDS object)
@@ -70,10 +70,15 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
         a += x * x; b += y * y; c += x * y;
       }
       a = wave_allsum(a); b = wave_allsum(b); c = wave_allsum(c);
-      if (a > 0.0 && b > 0.0 && fabs(c) > tol * sqrt(a * b)) {
-        const double zeta = (b - a) / (2.0 * c);
-        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = 1.0 / sqrt(1.0 + t * t);
+      if (a > 0.0 && b > 0.0 && c * c > tol2 * (a * b)) {
+        // Rutishauser rotation, t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (b-a)/(2c),
+        // rewritten as t = sign(d*e) |e| / (|d| + hypot(d, e)): one sqrt, one division and one
+        // reciprocal square root instead of three of each (fp64 sqrt/div are ~25-instruction
+        // sequences on gfx950 and this chain is the latency of every inner round)
+        const double d = b - a, e = 2.0 * c;
+        const double r = sqrt(d * d + e * e);
+        const double t = copysign(fabs(e), d * e) / (fabs(d) + r);
+        const double cs = rsqrt(1.0 + t * t);
         const double sn = cs * t;
         for (int i = lane; i < l; i += 64) {
           const double x = gp[i], y = gq[i];
@@ -135,17 +140,18 @@ int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, cons
     attr_set = true;
   }
   const double tol = sqrt((double)l) * DBL_EPSILON;
+  const double tol2 = tol * tol;
   const int max_sweeps = 40;
   int sweeps = 0;
   for (; sweeps < max_sweeps; ++sweeps) {
     hipMemsetAsync(w.rotcount, 0, sizeof(int32_t), st);
     if (nblk == 2) {
-      hipLaunchKernelGGL(jacobi_block_kernel, dim3(1), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk, 0, tol,
+      hipLaunchKernelGGL(jacobi_block_kernel, dim3(1), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk, 0, tol2,
                          w.rotcount, 2);
     } else {
       for (int r = 0; r < nblk - 1; ++r)
         hipLaunchKernelGGL(jacobi_block_kernel, dim3(nblk / 2), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk,
-                           r, tol, w.rotcount, 1);
+                           r, tol2, w.rotcount, 1);
     }
     int32_t rot = 0;
     hipMemcpyAsync(&rot, w.rotcount, sizeof(int32_t), hipMemcpyDeviceToHost, st);

@@ -91,23 +91,29 @@ __global__ __launch_bounds__(256) void qr_step_kernel(double* __restrict__ Y, in
   }
 }
 
-// one workgroup (64 threads): reduce partials, form reflector j (LAPACK dlarfg), update row j
-__global__ __launch_bounds__(64) void qr_house_kernel(double* __restrict__ Y, int64_t ld, int64_t jb, int b,
-                                                      int64_t j, const double* __restrict__ part,
-                                                      int nblocks, double* __restrict__ coef,
-                                                      double* __restrict__ tau_out) {
+// one workgroup (256 threads): reduce partials, form reflector j (LAPACK dlarfg), update row j
+__global__ __launch_bounds__(256) void qr_house_kernel(double* __restrict__ Y, int64_t ld, int64_t jb, int b,
+                                                       int64_t j, const double* __restrict__ part,
+                                                       int nblocks, double* __restrict__ coef,
+                                                       double* __restrict__ tau_out) {
+  __shared__ double s_part[16][QR_NB];
   __shared__ double s_sum[QR_NB];
   __shared__ double s_hh[3];  // scale, tau, beta
   const int tid = threadIdx.x;
   const int nlive = (int)(jb + b - j);
-  // 4 lanes per live column, fixed order
-  const int k = tid >> 2, sub = tid & 3;
+  // thread (k = tid % 16, g = tid / 16): fixed-order partial sums over blocks g, g+16, ...
+  const int k = tid & (QR_NB - 1), g = tid >> 4;
   double v = 0.0;
   if (k < nlive)
-    for (int p = sub; p < nblocks; p += 4) v += part[(int64_t)p * QR_NB + k];
-  v += __shfl_down(v, 2, 64);
-  v += __shfl_down(v, 1, 64);
-  if (sub == 0 && k < QR_NB) s_sum[k] = v;
+    for (int p = g; p < nblocks; p += 16) v += part[(int64_t)p * QR_NB + k];
+  s_part[g][k] = v;
+  __syncthreads();
+  if (tid < QR_NB) {
+    double s = 0.0;
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) s += s_part[gg][tid];
+    s_sum[tid] = s;
+  }
   __syncthreads();
   if (tid == 0) {
     const double alpha = Y[j + j * ld];
@@ -240,7 +246,7 @@ void qr_thinQ(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, doubl
       hipLaunchKernelGGL(qr_step_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, Y, ld, m, jb, b, j,
                          do_update, do_reduce, w.coef, rpt, w.part);
       if (do_reduce)
-        hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(64), 0, st, Y, ld, jb, b, j, w.part, (int)nblocks,
+        hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(256), 0, st, Y, ld, jb, b, j, w.part, (int)nblocks,
                            w.coef, w.tau);
     }
     const int64_t mr = m - jb;
