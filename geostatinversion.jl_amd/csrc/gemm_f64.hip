@@ -29,10 +29,10 @@
 //    1280 cycles of matrix work.  Everything fits 256 VGPRs, so hipcc keeps the accumulators in
 //    VGPR-form MFMAs (with more it switches to AGPR accumulators and copies all of them
 //    AGPR<->VGPR around the loop back edge).
-//  * LDS: two buffers of (A tile + B tile) = 2 x ~41 KB of the CU's 160 KB; images padded so
+//  * LDS: two buffers of (A tile + B tile) = 2 x ~78 KB of the CU's 160 KB; images padded so
 //    fragment reads are conflict-free for ds_read_b64 (bank = (addr/4) mod 64):
-//        B tile  bs[c][k], row stride 18 doubles   A tile (NN) as[k][r], row stride 144
-//        A tile (TN) at[r][k], row stride 18
+//        B tile  bs[c][k], row stride 34 doubles   A tile (NN) as[k][r], row stride 144
+//        A tile (TN) at[r][k], row stride 34
 //  * loads are `global_load_dwordx2 v, v_off, s[base]`: one uniform 64-bit base per operand
 //    in SGPRs + per-thread 32-bit byte offsets (per-load 64-bit bases overflow the SGPR file
 //    and end up as v_readlane/v_writelane chains between the MFMAs).
@@ -49,11 +49,11 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BMT = 128;   // C rows per workgroup (4 row groups x 32)
 constexpr int NTHREADS = 512;
-constexpr int BK = 16;     // reduction depth per LDS tile
-constexpr int BKP = 18;    // padded k stride (doubles) of the [col][k] images (BKP/2 odd)
+constexpr int BK = 32;     // reduction depth per LDS tile
+constexpr int BKP = 34;    // padded k stride (doubles) of the [col][k] images (BKP/2 odd)
 constexpr int BMP = 144;   // padded row stride (doubles) of the NN A image [k][r]
 constexpr int NTMAX = 10;  // 16-column tiles per workgroup pass (160 columns)
-constexpr int A_LOADS = BMT * BK / NTHREADS;   // 4 doubles per thread per tile
+constexpr int A_LOADS = BMT * BK / NTHREADS;   // 8 doubles per thread per tile
 
 template <int NT, bool TRANS_A>
 __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   const int rg = wave & 3;    // row group: C rows 32*rg .. 32*rg+31 of the workgroup tile
   const int ch = wave >> 2;   // column half: 16-column tiles ch*NTW .. of the workgroup's NT
   constexpr int NTW = (NT + 1) / 2;
-  constexpr int B_LOADS = (NT + 1) / 2;
+  constexpr int B_LOADS = NT;   // NT*16 columns x 32 k / 512 threads
   const int jl = lane & 15;   // MFMA "column" index -> C row within a 16-row tile
   const int kk = lane >> 4;   // MFMA k index within a k4 step
   const int64_t r0 = (int64_t)(blockIdx.x / nchunks_x) * BMT;   // column chunk folded into x: chunk-mates are dispatched together
@@ -91,17 +91,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 
   // per-thread load coordinates
   // NN A tile: element (k = tid/128 + 4*it, r = tid%128)    -> 512 B contiguous per wave
-  // TN A tile: element (r = tid/16 + 32*it, k = tid%16)     -> 128 B contiguous per 16 lanes
-  // B tile   : element (c = tid/16 + 32*it, k = tid%16)
-  const int a_r = TRANS_A ? (tid >> 4) : (tid & 127);
-  const int a_k = TRANS_A ? (tid & 15) : (tid >> 7);
-  const int b_c = tid >> 4;
-  const int b_k = tid & 15;
+  // TN A tile: element (r = tid/32 + 16*it, k = tid%32)     -> 256 B contiguous per 32 lanes
+  // B tile   : element (c = tid/32 + 16*it, k = tid%32)
+  const int a_r = TRANS_A ? (tid >> 5) : (tid & 127);
+  const int a_k = TRANS_A ? (tid & 31) : (tid >> 7);
+  const int b_c = tid >> 5;
+  const int b_k = tid & 31;
 
   const uint32_t a_off0 = 8u * (TRANS_A ? (uint32_t)(a_k + (int64_t)a_r * lda) : (uint32_t)(a_r + (int64_t)a_k * lda));
-  const uint32_t a_step_c = 8u * (uint32_t)((TRANS_A ? 32 : 4) * lda);
+  const uint32_t a_step_c = 8u * (uint32_t)((TRANS_A ? 16 : 4) * lda);
   const uint32_t b_off0 = 8u * (uint32_t)(b_k + (int64_t)b_c * ldb);
-  const uint32_t b_step_c = 8u * (uint32_t)(32 * ldb);
+  const uint32_t b_step_c = 8u * (uint32_t)(16 * ldb);
   const char* const Abase = reinterpret_cast<const char*>(TRANS_A ? A + r0 * lda : A + r0);
   const char* const Bbase = reinterpret_cast<const char*>(B + c0 * ldb);
   // interior workgroups (all 128 rows and all NT*16 columns in range) take an unpredicated
@@ -122,21 +122,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
         a_reg[set][it] = *reinterpret_cast<const double*>(Ab + (a_off0 + (uint32_t)it * a_step));
 #pragma unroll
       for (int it = 0; it < B_LOADS; ++it)
-        if ((NT % 2 == 0) || b_c + 32 * it < NT * 16)
-          b_reg[set][it] = *reinterpret_cast<const double*>(Bb + (b_off0 + (uint32_t)it * b_step));
+        b_reg[set][it] = *reinterpret_cast<const double*>(Bb + (b_off0 + (uint32_t)it * b_step));
       return;
     }
 #pragma unroll
     for (int it = 0; it < A_LOADS; ++it) {
-      const int64_t r = TRANS_A ? r0 + a_r + 32 * it : r0 + a_r;
+      const int64_t r = TRANS_A ? r0 + a_r + 16 * it : r0 + a_r;
       const int64_t k = TRANS_A ? k0 + a_k : k0 + a_k + 4 * it;
       a_reg[set][it] = (r < M && k < kend) ? *reinterpret_cast<const double*>(Ab + (a_off0 + (uint32_t)it * a_step)) : 0.0;
     }
 #pragma unroll
     for (int it = 0; it < B_LOADS; ++it) {
-      const int64_t c = c0 + b_c + 32 * it;
+      const int64_t c = c0 + b_c + 16 * it;
       const int64_t k = k0 + b_k;
-      b_reg[set][it] = (b_c + 32 * it < NT * 16 && c < L && k < kend) ? *reinterpret_cast<const double*>(Bb + (b_off0 + (uint32_t)it * b_step)) : 0.0;
+      b_reg[set][it] = (c < L && k < kend) ? *reinterpret_cast<const double*>(Bb + (b_off0 + (uint32_t)it * b_step)) : 0.0;
     }
   };
 
@@ -146,14 +145,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     double* b_s = a_s + A_ELEMS;
     if (TRANS_A) {
 #pragma unroll
-      for (int it = 0; it < A_LOADS; ++it) a_s[(a_r + 32 * it) * BKP + a_k] = a_reg[set][it];
+      for (int it = 0; it < A_LOADS; ++it) a_s[(a_r + 16 * it) * BKP + a_k] = a_reg[set][it];
     } else {
 #pragma unroll
       for (int it = 0; it < A_LOADS; ++it) a_s[(a_k + 4 * it) * BMP + a_r] = a_reg[set][it];
     }
 #pragma unroll
     for (int it = 0; it < B_LOADS; ++it)
-      if ((NT % 2 == 0) || b_c + 32 * it < NT * 16) b_s[(b_c + 32 * it) * BKP + b_k] = b_reg[set][it];
+      b_s[(b_c + 16 * it) * BKP + b_k] = b_reg[set][it];
   };
 
   // Fragments of one k4 step: 2 A fragments (rows 32w + jl, 32w + 16 + jl) and NT B fragments.
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
       if (s == 0 && ch == 0) chores();
-      if (s == 2 && ch != 0) chores();
+      if (s == BK / 8 && ch != 0) chores();
       const bool last = (s + 1 == BK / 4);
       // the one barrier per tile: tile t+1 becomes visible, and after this step's MFMAs nobody
       // reads buffer `cur` any more (its last fragments are already in registers)

@@ -56,7 +56,12 @@ void run(int wgs_per_cu, int iters) {
   hipFree(d);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {  // sustained mode: ~N seconds of back-to-back launches for power/clock sampling
+    const int secs = atoi(argv[1]);
+    for (int i = 0; i < secs * 28; ++i) run<10>(2, 40000);
+    return 0;
+  }
   for (int rep = 0; rep < 2; ++rep) {
     run<4>(1, 20000);
     run<10>(1, 8000);

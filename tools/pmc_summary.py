@@ -2,7 +2,7 @@
 import collections, csv, glob, json, sys
 tag = sys.argv[1]
 out = {}
-for d in (f"pmc_{tag}_a", f"pmc_{tag}_b"):
+for d in (f"pmc_{tag}_a", f"pmc_{tag}_b", f"pmc_{tag}_c"):
     fs = glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv")
     if not fs:
         continue
