@@ -59,7 +59,7 @@ template <int NT, bool TRANS_A>
 __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     int64_t M, int64_t L, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* __restrict__ C, int64_t ldc, double alpha,
-    double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x) {
+    double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, int wide) {
   constexpr int A_ELEMS = TRANS_A ? BMT * BKP : BK * BMP;
   constexpr int B_ELEMS = NT * 16 * BKP;
   constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
@@ -71,7 +71,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   const int rg = wave & 3;    // row group: C rows 32*rg .. 32*rg+31 of the workgroup tile
   const int ch = wave >> 2;   // column half: 16-column tiles ch*NTW .. of the workgroup's NT
   constexpr int NTW = (NT + 1) / 2;
-  constexpr int B_LOADS = NT;   // NT*16 columns x 32 k / 512 threads
   const int jl = lane & 15;   // MFMA "column" index -> C row within a 16-row tile
   const int kk = lane >> 4;   // MFMA k index within a k4 step
   const int64_t r0 = (int64_t)(blockIdx.x / nchunks_x) * BMT;   // column chunk folded into x: chunk-mates are dispatched together
@@ -86,22 +85,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[h][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  double a_reg[2][A_LOADS];   // two register sets: tiles of even / odd index, loaded two tiles ahead
-  double b_reg[2][B_LOADS];
+  // Staging registers: two sets (tiles of even / odd index, loaded two tiles ahead).  Every thread
+  // owns PAIRS of elements adjacent along the contiguous dimension, so that with 16-byte-aligned
+  // operands (wide != 0: base pointers 16-B aligned, even leading dimensions) each pair is one
+  // global_load_dwordx4 and one ds_write_b128 -- half the VMEM / LDS-write instructions.
+  constexpr int A_PAIRS = A_LOADS / 2;          // 4
+  constexpr int B_PAIRS = (NT + 1) / 2;         // NT*16 columns x 16 k-pairs / 512 threads
+  double2 a_reg[2][A_PAIRS];
+  double2 b_reg[2][B_PAIRS];
 
-  // per-thread load coordinates
-  // NN A tile: element (k = tid/128 + 4*it, r = tid%128)    -> 512 B contiguous per wave
-  // TN A tile: element (r = tid/32 + 16*it, k = tid%32)     -> 256 B contiguous per 32 lanes
-  // B tile   : element (c = tid/32 + 16*it, k = tid%32)
-  const int a_r = TRANS_A ? (tid >> 5) : (tid & 127);
-  const int a_k = TRANS_A ? (tid & 31) : (tid >> 7);
-  const int b_c = tid >> 5;
-  const int b_k = tid & 31;
+  // NN A tile: pair (r = 2*(tid%64),  k = tid/64 + 8*it)     -> 1 KB contiguous per wave
+  // TN A tile: pair (k = 2*(tid%16),  r = tid/16 + 32*it)    -> 256 B contiguous per 16 lanes
+  // B tile   : pair (k = 2*(tid%16),  c = tid/16 + 32*it)
+  const int a_r = TRANS_A ? (tid >> 4) : 2 * (tid & 63);
+  const int a_k = TRANS_A ? 2 * (tid & 15) : (tid >> 6);
+  const int b_c = tid >> 4;
+  const int b_k = 2 * (tid & 15);
 
   const uint32_t a_off0 = 8u * (TRANS_A ? (uint32_t)(a_k + (int64_t)a_r * lda) : (uint32_t)(a_r + (int64_t)a_k * lda));
-  const uint32_t a_step_c = 8u * (uint32_t)((TRANS_A ? 16 : 4) * lda);
+  const uint32_t a_step_c = 8u * (uint32_t)((TRANS_A ? 32 : 8) * lda);
   const uint32_t b_off0 = 8u * (uint32_t)(b_k + (int64_t)b_c * ldb);
-  const uint32_t b_step_c = 8u * (uint32_t)(16 * ldb);
+  const uint32_t b_step_c = 8u * (uint32_t)(32 * ldb);
+  // byte distance between the two elements of a pair when they cannot be fetched as one 16-B load
   const char* const Abase = reinterpret_cast<const char*>(TRANS_A ? A + r0 * lda : A + r0);
   const char* const Bbase = reinterpret_cast<const char*>(B + c0 * ldb);
   // interior workgroups (all 128 rows and all NT*16 columns in range) take an unpredicated
@@ -116,26 +121,36 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     // instead of staying live in VGPRs across the MFMA loop
     uint32_t a_step = a_step_c, b_step = b_step_c;
     asm volatile("" : "+s"(a_step), "+s"(b_step));
-    if (wg_full && k0 + BK <= kend) {
+    if (wide && wg_full && k0 + BK <= kend) {
 #pragma unroll
-      for (int it = 0; it < A_LOADS; ++it)
-        a_reg[set][it] = *reinterpret_cast<const double*>(Ab + (a_off0 + (uint32_t)it * a_step));
+      for (int it = 0; it < A_PAIRS; ++it)
+        a_reg[set][it] = *reinterpret_cast<const double2*>(Ab + (a_off0 + (uint32_t)it * a_step));
 #pragma unroll
-      for (int it = 0; it < B_LOADS; ++it)
-        b_reg[set][it] = *reinterpret_cast<const double*>(Bb + (b_off0 + (uint32_t)it * b_step));
+      for (int it = 0; it < B_PAIRS; ++it)
+        if ((NT % 2 == 0) || b_c + 32 * it < NT * 16)
+          b_reg[set][it] = *reinterpret_cast<const double2*>(Bb + (b_off0 + (uint32_t)it * b_step));
       return;
     }
+    // general path: element-wise, predicated (edges, odd leading dimensions, unaligned views)
 #pragma unroll
-    for (int it = 0; it < A_LOADS; ++it) {
-      const int64_t r = TRANS_A ? r0 + a_r + 16 * it : r0 + a_r;
-      const int64_t k = TRANS_A ? k0 + a_k : k0 + a_k + 4 * it;
-      a_reg[set][it] = (r < M && k < kend) ? *reinterpret_cast<const double*>(Ab + (a_off0 + (uint32_t)it * a_step)) : 0.0;
+    for (int it = 0; it < A_PAIRS; ++it) {
+      const char* p = Ab + (a_off0 + (uint32_t)it * a_step);
+      const int64_t r = TRANS_A ? r0 + a_r + 32 * it : r0 + a_r;
+      const int64_t k = TRANS_A ? k0 + a_k : k0 + a_k + 8 * it;
+      const bool ok0 = (r < M && k < kend);
+      const bool ok1 = TRANS_A ? (r < M && k + 1 < kend) : (r + 1 < M && k < kend);
+      a_reg[set][it].x = ok0 ? *reinterpret_cast<const double*>(p) : 0.0;
+      a_reg[set][it].y = ok1 ? *reinterpret_cast<const double*>(p + 8) : 0.0;
     }
 #pragma unroll
-    for (int it = 0; it < B_LOADS; ++it) {
-      const int64_t c = c0 + b_c + 16 * it;
+    for (int it = 0; it < B_PAIRS; ++it) {
+      const char* p = Bb + (b_off0 + (uint32_t)it * b_step);
+      const int cl = b_c + 32 * it;
+      const int64_t c = c0 + cl;
       const int64_t k = k0 + b_k;
-      b_reg[set][it] = (c < L && k < kend) ? *reinterpret_cast<const double*>(Bb + (b_off0 + (uint32_t)it * b_step)) : 0.0;
+      const bool okc = (cl < NT * 16) && (c < L);
+      b_reg[set][it].x = (okc && k < kend) ? *reinterpret_cast<const double*>(p) : 0.0;
+      b_reg[set][it].y = (okc && k + 1 < kend) ? *reinterpret_cast<const double*>(p + 8) : 0.0;
     }
   };
 
@@ -145,14 +160,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     double* b_s = a_s + A_ELEMS;
     if (TRANS_A) {
 #pragma unroll
-      for (int it = 0; it < A_LOADS; ++it) a_s[(a_r + 16 * it) * BKP + a_k] = a_reg[set][it];
+      for (int it = 0; it < A_PAIRS; ++it)
+        *reinterpret_cast<double2*>(a_s + (a_r + 32 * it) * BKP + a_k) = a_reg[set][it];
     } else {
 #pragma unroll
-      for (int it = 0; it < A_LOADS; ++it) a_s[(a_k + 4 * it) * BMP + a_r] = a_reg[set][it];
+      for (int it = 0; it < A_PAIRS; ++it)
+        *reinterpret_cast<double2*>(a_s + (a_k + 8 * it) * BMP + a_r) = a_reg[set][it];
     }
 #pragma unroll
-    for (int it = 0; it < B_LOADS; ++it)
-      b_s[(b_c + 16 * it) * BKP + b_k] = b_reg[set][it];
+    for (int it = 0; it < B_PAIRS; ++it)
+      if ((NT % 2 == 0) || b_c + 32 * it < NT * 16)
+        *reinterpret_cast<double2*>(b_s + (b_c + 32 * it) * BKP + b_k) = b_reg[set][it];
   };
 
   // Fragments of one k4 step: 2 A fragments (rows 32w + jl, 32w + 16 + jl) and NT B fragments.
@@ -276,7 +294,7 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t L, int nsplit, const dou
 template <int NT, bool TRANS_A>
 static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A,
                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha,
-                      double beta, double* slabs, int64_t kchunk, int nchunks_x) {
+                      double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide) {
   constexpr size_t shmem = 2 * ((TRANS_A ? BMT * BKP : BK * BMP) + NT * 16 * BKP) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
@@ -285,16 +303,16 @@ static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_f64_kernel<NT, TRANS_A>), grid, dim3(NTHREADS), shmem, st, M, L, K, A, lda, B, ldb, C,
-                     ldc, alpha, beta, slabs, kchunk, nchunks_x);
+                     ldc, alpha, beta, slabs, kchunk, nchunks_x, wide);
 }
 
 template <bool TRANS_A>
 static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K,
                             const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
-                            int64_t ldc, double alpha, double beta, double* slabs, int64_t kchunk, int nchunks_x) {
+                            int64_t ldc, double alpha, double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide) {
 #define GSI_CASE(N)                                                                             \
   case N:                                                                                       \
-    launch_nt<N, TRANS_A>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x); \
+    launch_nt<N, TRANS_A>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide); \
     break;
   switch (nt) {
     GSI_CASE(1) GSI_CASE(2) GSI_CASE(3) GSI_CASE(4) GSI_CASE(5)
@@ -338,10 +356,12 @@ void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, doub
   const int ns_eff = (K > 0) ? (int)((K + kchunk - 1) / kchunk) : 1;
   dim3 grid((unsigned)(rowblocks * nchunks), (unsigned)ns_eff, 1);
   double* slabs = (ns_eff > 1) ? ws : nullptr;
+  // 16-byte loads need 16-B aligned bases and even leading dimensions (sub-panel views often are not)
+  const int wide = (((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && (lda & 1) == 0 && (ldb & 1) == 0) ? 1 : 0;
   if (transA)
-    launch_dispatch<true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks);
+    launch_dispatch<true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide);
   else
-    launch_dispatch<false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks);
+    launch_dispatch<false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide);
   if (ns_eff > 1) {
     const int64_t total = M * L;
     int blocks = (int)((total + 255) / 256);
