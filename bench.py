@@ -168,6 +168,7 @@ def main():
             "roofline": roofline,
             "phases_ms_per_step": {k: v[0] / args.steps for k, v in phases.items()},
             "phase_launch_groups_per_step": {k: v[1] / args.steps for k, v in phases.items()},
+            "path_counters": ctx.counters(),
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, err, xerr = cpu_baseline_and_parity(gsi, ctx, K, p, q)

@@ -69,6 +69,11 @@ class Context:
         L.check(self.lib.gsi_ctx_phase_times(self.h, ms, cnt), self.lib)
         return {name: (ms[i], cnt[i]) for i, name in enumerate(L.PHASES)}
 
+    def counters(self):
+        out = (C.c_int64 * 4)()
+        L.check(self.lib.gsi_ctx_counters(self.h, out), self.lib)
+        return {"cholqr2": out[0], "householder": out[1], "jacobi_sweeps": out[2]}
+
     def device_bytes(self):
         b = C.c_int64()
         L.check(self.lib.gsi_ctx_device_bytes(self.h, C.byref(b)), self.lib)

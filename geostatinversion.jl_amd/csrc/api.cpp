@@ -500,6 +500,12 @@ int gsi_ctx_phase_times(gsi_ctx* ctx, double* ms_out, int64_t* count_out) {
     ctx->c.be->phase_times(ms_out, count_out);
   });
 }
+int gsi_ctx_counters(gsi_ctx* ctx, int64_t* out4) {
+  return guarded([&] {
+    REQUIRE(ctx && out4, "NULL argument");
+    ctx->c.be->counters(out4);
+  });
+}
 int gsi_ctx_device_bytes(gsi_ctx* ctx, int64_t* bytes) {
   return guarded([&] {
     REQUIRE(ctx && bytes, "NULL argument");

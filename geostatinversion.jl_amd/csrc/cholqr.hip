@@ -1,0 +1,191 @@
+// cholqr.hip -- CholeskyQR2 for the tall-skinny panels of the range finder (the thin-Q step of
+// `qr(Y, Val(true))`, RandMatFact.jl:57-58,75-76, and the QR half of `svd(B)`, :86).
+//
+// Why: Householder on an m x l panel costs ~l/NB sweeps of the panel plus 2 launches per column; at
+// the metric's nominal size (m = 10^6, l = 320) that is ~100 GB of HBM traffic per factorization.
+// CholeskyQR2 is two rounds of { G = Y'Y (one read of Y, MFMA), R = chol(G) (l x l), Y <- Y R^-1
+// (blocked triangular solve = MFMA GEMMs) }: ~6 panel passes, all through the contraction kernel of
+// gemm_f64.hip.  The computed Q has the same range as Y (all the reference keeps of its pivoted QR),
+// is orthonormal to machine precision after the second round, and W = Q (R2 R1) holds to O(eps)|W|,
+// so singular values keep the absolute O(eps sigma_1) accuracy of a Householder QR.
+//
+// Safety: the method needs cond(Y) < ~1e7.  The first Cholesky can break down (or silently lose
+// everything) beyond that, and the reference's own tests produce exactly rank-deficient sketches
+// (SURVEY.md H7).  Both rounds therefore raise a device flag on a non-positive / negligible pivot and
+// the second round checks |Q1'Q1 - I|_max; on any doubt the caller restores the panel and runs the
+// Householder path (panel_qr.hip).  Decision = one 4-byte read per factorization.
+#include "hip_common.hpp"
+#include <cfloat>
+
+namespace gsi { namespace hipk {
+
+constexpr int CQ_TB = 32;   // column block of the triangular solve
+
+// ---- R = chol(G) upper, in place, one workgroup, right-looking on the L2-resident l x l matrix ----
+// flag |= 1 when a pivot is <= tiny * max diagonal (numerically rank deficient / not positive definite)
+__global__ __launch_bounds__(1024) void cq_chol_kernel(double* __restrict__ G, int l, int32_t* __restrict__ flag) {
+  __shared__ double s_d;
+  __shared__ double s_max;
+  __shared__ double s_row[1024];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    double mx = 0.0;
+    for (int i = 0; i < l; ++i) mx = fmax(mx, G[i + (int64_t)i * l]);
+    s_max = mx;
+  }
+  __syncthreads();
+  const double tiny = s_max * (double)l * DBL_EPSILON * 16.0;
+  for (int k = 0; k < l; ++k) {
+    if (tid == 0) {
+      double d = G[k + (int64_t)k * l];
+      if (!(d > tiny)) { atomicOr(flag, 1); d = 1.0; }
+      s_d = sqrt(d);
+    }
+    __syncthreads();
+    const double d = s_d;
+    // row k of U
+    for (int c = k + tid; c < l; c += 1024) {
+      const double v = (c == k) ? d : G[k + (int64_t)c * l] / d;
+      G[k + (int64_t)c * l] = v;
+      s_row[c - k < 1024 ? c - k : 0] = v;   // l <= 1024: row fits
+    }
+    __syncthreads();
+    // trailing update of the upper triangle: G[r][c] -= U[k][r] * U[k][c], k < r <= c
+    const int t = l - k - 1;
+    const int64_t total = (int64_t)t * t;
+    for (int64_t e = tid; e < total; e += 1024) {
+      const int rr = (int)(e % t), cc = (int)(e / t);
+      if (rr <= cc) G[(k + 1 + rr) + (int64_t)(k + 1 + cc) * l] -= s_row[1 + rr] * s_row[1 + cc];
+    }
+    __syncthreads();
+  }
+  for (int64_t e = tid; e < (int64_t)l * l; e += 1024) {
+    const int r = (int)(e % l), c = (int)(e / l);
+    if (r > c) G[e] = 0.0;
+  }
+}
+
+// ---- inverses of the CQ_TB x CQ_TB diagonal blocks of the upper-triangular R (one block per workgroup) ----
+__global__ __launch_bounds__(64) void cq_trinv_blocks_kernel(const double* __restrict__ R, int l,
+                                                             double* __restrict__ Rinv /* nblk x TB x TB */) {
+  __shared__ double B[CQ_TB * CQ_TB];
+  __shared__ double X[CQ_TB * CQ_TB];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const int j0 = blk * CQ_TB;
+  const int b = (l - j0 < CQ_TB) ? (l - j0) : CQ_TB;
+  for (int e = tid; e < CQ_TB * CQ_TB; e += 64) {
+    const int r = e % CQ_TB, c = e / CQ_TB;
+    B[e] = (r < b && c < b) ? R[(j0 + r) + (int64_t)(j0 + c) * l] : (r == c ? 1.0 : 0.0);
+    X[e] = 0.0;
+  }
+  __syncthreads();
+  // column c of the inverse: back substitution U x = e_c (thread = one column)
+  if (tid < CQ_TB) {
+    const int c = tid;
+    for (int r = c; r >= 0; --r) {
+      double s = (r == c) ? 1.0 : 0.0;
+      for (int p = r + 1; p <= c; ++p) s -= B[r + p * CQ_TB] * X[p + c * CQ_TB];
+      X[r + c * CQ_TB] = s / B[r + r * CQ_TB];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < CQ_TB * CQ_TB; e += 64) Rinv[(int64_t)blk * CQ_TB * CQ_TB + e] = X[e];
+}
+
+// ---- Y[:, j0:j0+b] <- Y[:, j0:j0+b] * X  (X upper triangular b x b, ld CQ_TB); thread = one row ----
+__global__ __launch_bounds__(256) void cq_right_mult_kernel(double* __restrict__ Y, int64_t m, int64_t ld,
+                                                            int64_t j0, int b, const double* __restrict__ X) {
+  __shared__ double Xs[CQ_TB * CQ_TB];
+  for (int e = threadIdx.x; e < CQ_TB * CQ_TB; e += 256) Xs[e] = X[e];
+  __syncthreads();
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m; r += (int64_t)gridDim.x * 256) {
+    double x[CQ_TB];
+    double* row = Y + r + j0 * ld;
+#pragma unroll
+    for (int c = 0; c < CQ_TB; ++c) x[c] = (c < b) ? row[c * ld] : 0.0;
+#pragma unroll
+    for (int c = CQ_TB - 1; c >= 0; --c) {
+      if (c < b) {
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < CQ_TB; ++p)
+          if (p <= c) s += x[p] * Xs[p + c * CQ_TB];
+        row[c * ld] = s;
+      }
+    }
+  }
+}
+
+// ---- flag |= 2 when max |G - I| > thresh (second-round Gram matrix of a would-be orthonormal Q1) ----
+__global__ __launch_bounds__(256) void cq_orth_check_kernel(const double* __restrict__ G, int l, double thresh,
+                                                            int32_t* __restrict__ flag) {
+  const int64_t total = (int64_t)l * l;
+  bool bad = false;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e % l), c = (int)(e / l);
+    const double v = G[e] - (r == c ? 1.0 : 0.0);
+    if (!(fabs(v) <= thresh)) bad = true;   // also catches NaN
+  }
+  if (bad) atomicOr(flag, 2);
+}
+
+// ---- R = R2 * R1 (both upper triangular l x l) ----
+__global__ void cq_triprod_kernel(const double* __restrict__ R2, const double* __restrict__ R1, int l,
+                                  double* __restrict__ R) {
+  const int64_t total = (int64_t)l * l;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e % l), c = (int)(e / l);
+    double s = 0.0;
+    if (r <= c)
+      for (int p = r; p <= c; ++p) s += R2[r + (int64_t)p * l] * R1[p + (int64_t)c * l];
+    R[e] = s;
+  }
+}
+
+static inline int grid_for(int64_t total, int cap = 2048) {
+  int64_t g = (total + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+size_t cholqr_small_doubles(int64_t l) {
+  const int64_t nblk = (l + CQ_TB - 1) / CQ_TB;
+  return (size_t)(3 * l * l + nblk * CQ_TB * CQ_TB + 64);
+}
+
+// One CholeskyQR2 attempt on Y (m x l, ld), in place.  `small` holds cholqr_small_doubles(l) doubles;
+// flag is a zeroed device int.  On return (stream-ordered) flag == 0 means success; R (may be null)
+// receives R2*R1.  The caller must have saved Y if it wants to fall back.
+void cholqr2(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld, double* R, double* small,
+             int32_t* flag, double* gemm_ws) {
+  const int l = (int)l64;
+  const int nblk = (l + CQ_TB - 1) / CQ_TB;
+  double* R1 = small;
+  double* R2 = small + (size_t)l * l;
+  double* Gt = small + 2 * (size_t)l * l;
+  double* Rinv = small + 3 * (size_t)l * l;
+  for (int pass = 0; pass < 2; ++pass) {
+    double* Rp = pass == 0 ? R1 : R2;
+    gemm_f64(st, true, l, l, m, 1.0, Y, ld, Y, ld, 0.0, Rp, l, gemm_ws);          // G = Y'Y
+    if (pass == 1)
+      hipLaunchKernelGGL(cq_orth_check_kernel, dim3(grid_for((int64_t)l * l, 64)), dim3(256), 0, st, Rp, l, 0.1,
+                         flag);
+    hipLaunchKernelGGL(cq_chol_kernel, dim3(1), dim3(1024), 0, st, Rp, l, flag);    // R = chol(G)
+    hipLaunchKernelGGL(cq_trinv_blocks_kernel, dim3(nblk), dim3(64), 0, st, Rp, l, Rinv);
+    for (int jb = 0; jb < nblk; ++jb) {                                             // Y <- Y R^-1, blocked
+      const int64_t j0 = (int64_t)jb * CQ_TB;
+      const int b = (int)((l - j0 < CQ_TB) ? (l - j0) : CQ_TB);
+      if (j0 > 0)
+        gemm_f64(st, false, m, b, j0, -1.0, Y, ld, Rp + j0 * (int64_t)l, l, 1.0, Y + j0 * ld, ld, gemm_ws);
+      hipLaunchKernelGGL(cq_right_mult_kernel, dim3(grid_for(m, 1024)), dim3(256), 0, st, Y, m, ld, j0, b,
+                         Rinv + (size_t)jb * CQ_TB * CQ_TB);
+    }
+  }
+  (void)Gt;
+  if (R != nullptr)
+    hipLaunchKernelGGL(cq_triprod_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, R2, R1, l, R);
+}
+
+}}  // namespace gsi::hipk

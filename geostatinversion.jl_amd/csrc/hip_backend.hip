@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -175,23 +177,37 @@ class HipBackend : public Backend {
     auto take = [&](size_t c) { size_t o = cnt; cnt += (c + 7) & ~(size_t)7; return o; };
     const size_t o_coef = take(2 + NB + 2), o_part = take((size_t)nb * NB), o_tau = take(l),
                  o_T = take((size_t)npan * NB * NB), o_G = take(NB * NB), o_V = take((size_t)m * NB),
-                 o_Wt = take((size_t)l * NB), o_W2 = take((size_t)l * NB), o_Q = take((size_t)m * l);
+                 o_Wt = take((size_t)l * NB), o_W2 = take((size_t)l * NB), o_small = take(hipk::cholqr_small_doubles(l)),
+                 o_Q = take((size_t)m * l);
     grow(ws_qr_, cnt * sizeof(double));
     double* base = (double*)ws_qr_.p;
     hipk::QrWork w;
     w.coef = base + o_coef; w.part = base + o_part; w.tau = base + o_tau; w.T = base + o_T; w.G = base + o_G;
     w.Vbuf = base + o_V; w.Wt = base + o_Wt; w.W2 = base + o_W2; w.Qo = base + o_Q; w.maxblocks = nb;
-    // gemm shapes inside: (t x NB, K = m), (NB x NB, K = m), (m x t, K = NB)
-    size_t g1 = hipk::gemm_workspace_doubles(l, NB, m);
-    size_t g2 = hipk::gemm_workspace_doubles(NB, NB, m);
-    size_t g3 = 0;
-    for (int64_t t = NB; t <= l; t += NB) {
-      size_t g = hipk::gemm_workspace_doubles(t, NB, m);
-      if (g > g3) g3 = g;
-    }
-    size_t gmax = g1 > g2 ? g1 : g2;
-    if (g3 > gmax) gmax = g3;
+    // gemm shapes inside: (t x NB, K = m), (NB x NB, K = m), (m x t, K = NB), (l x l, K = m), (m x 32, K <= l)
+    size_t gmax = hipk::gemm_workspace_doubles(l, NB, m);
+    gmax = std::max(gmax, hipk::gemm_workspace_doubles(NB, NB, m));
+    gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, l, m));
+    for (int64_t t = NB; t <= l; t += NB) gmax = std::max(gmax, hipk::gemm_workspace_doubles(t, NB, m));
     double* ws = gemm_ws(gmax + 64);
+    // First choice: CholeskyQR2 (a handful of MFMA GEMM passes).  It needs a numerically full-rank,
+    // moderately conditioned panel; the kernels raise a flag otherwise and we redo the panel with
+    // Householder reflectors from the saved copy.
+    static const bool no_cholqr = (getenv("GSI_NO_CHOLQR") != nullptr);
+    if (!no_cholqr && l <= 1024 && m >= 2 * l) {
+      HIP_CHECK(hipMemcpy2DAsync(w.Qo, m * sizeof(double), Y, ld * sizeof(double), m * sizeof(double), l,
+                                 hipMemcpyDeviceToDevice, st_));
+      HIP_CHECK(hipMemsetAsync(flags_ + 9, 0, sizeof(int32_t), st_));
+      hipk::cholqr2(st_, Y, m, l, ld, R, base + o_small, flags_ + 9, ws);
+      check_launch("cholqr2");
+      int32_t f = 0;
+      HIP_CHECK(hipMemcpyAsync(&f, flags_ + 9, sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      if (f == 0) { ++n_cholqr_; return; }
+      HIP_CHECK(hipMemcpy2DAsync(Y, ld * sizeof(double), w.Qo, m * sizeof(double), m * sizeof(double), l,
+                                 hipMemcpyDeviceToDevice, st_));
+    }
+    ++n_householder_;
     hipk::qr_thinQ(st_, Y, m, l, ld, R, w, ws);
     check_launch("qr_thinQ");
   }
@@ -310,6 +326,9 @@ class HipBackend : public Backend {
     for (int i = 0; i < PH_COUNT; ++i) { ms[i] = acc_ms_[i]; counts[i] = acc_n_[i]; }
   }
 
+  void counters(int64_t* out4) override {
+    out4[0] = n_cholqr_; out4[1] = n_householder_; out4[2] = last_svd_sweeps_; out4[3] = 0;
+  }
   int device() const { return device_; }
 
  private:
@@ -356,6 +375,7 @@ class HipBackend : public Backend {
   double acc_ms_[PH_COUNT] = {0};
   int64_t acc_n_[PH_COUNT] = {0};
   int last_svd_sweeps_ = 0;
+  int64_t n_cholqr_ = 0, n_householder_ = 0;
 };
 
 // ---- RCCL, bound lazily so a single-GPU user never needs librccl to resolve -----------------

@@ -20,7 +20,7 @@ struct LuWork {
   int32_t* info;    // [1] first exactly-zero pivot (1-based), 0 if none
   int64_t maxblocks;
 };
-constexpr int LU_NB = 32;
+constexpr int LU_NB = 16;
 int64_t lu_max_blocks(int64_t m);
 void lu_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const LuWork& w, double* gemm_ws);
 
@@ -41,6 +41,11 @@ struct QrWork {
 int64_t qr_max_blocks(int64_t m);
 void qr_thinQ(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, double* R, const QrWork& w,
               double* gemm_ws);
+
+// ---- cholqr.hip ----
+size_t cholqr_small_doubles(int64_t l);
+void cholqr2(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, double* R, double* small_ws,
+             int32_t* flag, double* gemm_ws);
 
 // ---- jacobi_svd.hip ----
 struct SvdWork {

@@ -370,3 +370,35 @@ print("rccl-1rank-ok")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "rccl-1rank-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- CholeskyQR2 fast path and its Householder fall-back -------------------------------------------------
+@pytest.mark.parametrize("cond,expect_fast", [(1e0, True), (1e4, True), (1e10, False)])
+def test_qr_paths(gsi, ctx, cond, expect_fast):
+    rng = np.random.default_rng(int(np.log10(cond)) + 3)
+    m, l = 4096, 96
+    U, _ = np.linalg.qr(rng.standard_normal((m, l)))
+    V, _ = np.linalg.qr(rng.standard_normal((l, l)))
+    Y = (U * np.logspace(0, -np.log10(cond), l)) @ V.T
+    before = ctx.counters()
+    Q, R = gsi.qr_thinQ(Y, return_R=True)
+    after = ctx.counters()
+    assert (after["cholqr2"] - before["cholqr2"] == 1) == expect_fast
+    assert (after["householder"] - before["householder"] == 1) == (not expect_fast)
+    assert np.abs(Q.T @ Q - np.eye(l)).max() < 1e-13
+    assert np.abs(Q @ R - Y).max() < 1e-13 * l
+    assert np.abs(np.tril(R, -1)).max() == 0.0
+    s = np.linalg.svd(R, compute_uv=False)
+    sref = np.linalg.svd(Y, compute_uv=False)
+    assert np.abs(s - sref).max() < 1e-13 * sref[0]       # absolute O(eps*sigma_1), like Householder / dgesdd
+
+
+def test_qr_rank_deficient_falls_back(gsi, ctx):
+    rng = np.random.default_rng(12)
+    Y = exact_rank_matrix(rng, 2000, 7)[:, :40]
+    before = ctx.counters()
+    Q = gsi.qr_thinQ(Y)
+    after = ctx.counters()
+    assert after["householder"] - before["householder"] == 1
+    assert np.abs(Q.T @ Q - np.eye(40)).max() < 1e-13
+    assert np.linalg.norm(Y - Q @ (Q.T @ Y)) < 1e-11 * np.linalg.norm(Y)
