@@ -21,75 +21,89 @@ namespace gsi { namespace hipk {
 
 constexpr int CQ_TB = 32;   // column block of the triangular solve
 
-// ---- R = chol(G) upper, in place, one workgroup, right-looking on the L2-resident l x l matrix ----
-// flag |= 1 when a pivot is <= tiny * max diagonal (numerically rank deficient / not positive definite)
-__global__ __launch_bounds__(1024) void cq_chol_kernel(double* __restrict__ G, int l, int32_t* __restrict__ flag) {
-  __shared__ double s_d;
-  __shared__ double s_max;
-  __shared__ double s_row[1024];
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    double mx = 0.0;
-    for (int i = 0; i < l; ++i) mx = fmax(mx, G[i + (int64_t)i * l]);
-    s_max = mx;
-  }
+// ---- blocked upper Cholesky of the small l x l Gram matrix ----------------------------------------------
+// tiny[0] = 16 l eps max_i G_ii : pivots below it mean "numerically rank deficient" (flag |= 1)
+__global__ __launch_bounds__(256) void cq_diagmax_kernel(const double* __restrict__ G, int l, double* __restrict__ tiny) {
+  __shared__ double s[256];
+  double mx = 0.0;
+  for (int i = threadIdx.x; i < l; i += 256) mx = fmax(mx, G[i + (int64_t)i * l]);
+  s[threadIdx.x] = mx;
   __syncthreads();
-  const double tiny = s_max * (double)l * DBL_EPSILON * 16.0;
-  for (int k = 0; k < l; ++k) {
-    if (tid == 0) {
-      double d = G[k + (int64_t)k * l];
-      if (!(d > tiny)) { atomicOr(flag, 1); d = 1.0; }
-      s_d = sqrt(d);
-    }
-    __syncthreads();
-    const double d = s_d;
-    // row k of U
-    for (int c = k + tid; c < l; c += 1024) {
-      const double v = (c == k) ? d : G[k + (int64_t)c * l] / d;
-      G[k + (int64_t)c * l] = v;
-      s_row[c - k < 1024 ? c - k : 0] = v;   // l <= 1024: row fits
-    }
-    __syncthreads();
-    // trailing update of the upper triangle: G[r][c] -= U[k][r] * U[k][c], k < r <= c
-    const int t = l - k - 1;
-    const int64_t total = (int64_t)t * t;
-    for (int64_t e = tid; e < total; e += 1024) {
-      const int rr = (int)(e % t), cc = (int)(e / t);
-      if (rr <= cc) G[(k + 1 + rr) + (int64_t)(k + 1 + cc) * l] -= s_row[1 + rr] * s_row[1 + cc];
-    }
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + st]);
     __syncthreads();
   }
-  for (int64_t e = tid; e < (int64_t)l * l; e += 1024) {
-    const int r = (int)(e % l), c = (int)(e / l);
-    if (r > c) G[e] = 0.0;
-  }
+  if (threadIdx.x == 0) tiny[0] = s[0] * (double)l * DBL_EPSILON * 16.0;
 }
 
-// ---- inverses of the CQ_TB x CQ_TB diagonal blocks of the upper-triangular R (one block per workgroup) ----
-__global__ __launch_bounds__(64) void cq_trinv_blocks_kernel(const double* __restrict__ R, int l,
-                                                             double* __restrict__ Rinv /* nblk x TB x TB */) {
-  __shared__ double B[CQ_TB * CQ_TB];
-  __shared__ double X[CQ_TB * CQ_TB];
-  const int blk = blockIdx.x, tid = threadIdx.x;
-  const int j0 = blk * CQ_TB;
-  const int b = (l - j0 < CQ_TB) ? (l - j0) : CQ_TB;
-  for (int e = tid; e < CQ_TB * CQ_TB; e += 64) {
+// One block column jb: U11 = chol(G11) and X = U11^-1 in LDS, then the block row U12 = U11^-T G12.
+// The trailing update G22 -= U12' U12 is an MFMA GEMM issued by the host.  One workgroup.
+__global__ __launch_bounds__(256) void cq_chol_block_kernel(double* __restrict__ G, int l, int j0, int b,
+                                                            const double* __restrict__ tiny_p,
+                                                            double* __restrict__ Xout /* TB x TB */,
+                                                            int32_t* __restrict__ flag) {
+  __shared__ double U[CQ_TB][CQ_TB + 1];
+  __shared__ double X[CQ_TB][CQ_TB + 1];
+  const int tid = threadIdx.x;
+  const double tiny = tiny_p[0];
+  for (int e = tid; e < CQ_TB * CQ_TB; e += 256) {
     const int r = e % CQ_TB, c = e / CQ_TB;
-    B[e] = (r < b && c < b) ? R[(j0 + r) + (int64_t)(j0 + c) * l] : (r == c ? 1.0 : 0.0);
-    X[e] = 0.0;
+    U[r][c] = (r < b && c < b) ? G[(j0 + r) + (int64_t)(j0 + c) * l] : (r == c ? 1.0 : 0.0);
+    X[r][c] = 0.0;
   }
   __syncthreads();
-  // column c of the inverse: back substitution U x = e_c (thread = one column)
-  if (tid < CQ_TB) {
+  for (int k = 0; k < b; ++k) {
+    if (tid == 0) {
+      double d = U[k][k];
+      if (!(d > tiny)) { atomicOr(flag, 1); d = 1.0; }
+      U[k][k] = sqrt(d);
+    }
+    __syncthreads();
+    if (tid > k && tid < b) U[k][tid] /= U[k][k];
+    __syncthreads();
+    for (int e = tid; e < CQ_TB * CQ_TB; e += 256) {
+      const int r = e % CQ_TB, c = e / CQ_TB;
+      if (r > k && r <= c && c < b) U[r][c] -= U[k][r] * U[k][c];
+    }
+    __syncthreads();
+  }
+  // X = U^-1 (upper): column c by back substitution, thread = column
+  if (tid < b) {
     const int c = tid;
     for (int r = c; r >= 0; --r) {
       double s = (r == c) ? 1.0 : 0.0;
-      for (int p = r + 1; p <= c; ++p) s -= B[r + p * CQ_TB] * X[p + c * CQ_TB];
-      X[r + c * CQ_TB] = s / B[r + r * CQ_TB];
+      for (int p = r + 1; p <= c; ++p) s -= U[r][p] * X[p][c];
+      X[r][c] = s / U[r][r];
     }
+  } else if (tid < CQ_TB) {
+    X[tid][tid] = 1.0;
   }
   __syncthreads();
-  for (int e = tid; e < CQ_TB * CQ_TB; e += 64) Rinv[(int64_t)blk * CQ_TB * CQ_TB + e] = X[e];
+  for (int e = tid; e < CQ_TB * CQ_TB; e += 256) {
+    const int r = e % CQ_TB, c = e / CQ_TB;
+    Xout[r + c * CQ_TB] = X[r][c];
+    if (r < b && c < b) G[(j0 + r) + (int64_t)(j0 + c) * l] = (r <= c) ? U[r][c] : 0.0;
+  }
+  // block row: U12[:, c] = X' * G12[:, c]  (thread = one trailing column), and zero the block below U11
+  for (int c = j0 + b + tid; c < l; c += 256) {
+    double g[CQ_TB];
+#pragma unroll
+    for (int r = 0; r < CQ_TB; ++r) g[r] = (r < b) ? G[(j0 + r) + (int64_t)c * l] : 0.0;
+#pragma unroll
+    for (int r = 0; r < CQ_TB; ++r) {
+      if (r < b) {
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < CQ_TB; ++p)
+          if (p <= r) s += X[p][r] * g[p];
+        G[(j0 + r) + (int64_t)c * l] = s;
+      }
+    }
+  }
+  for (int e = tid; e < b * (l - j0 - b); e += 256) {   // strictly-lower part of this block column -> 0
+    const int c = j0 + e % b, r = j0 + b + e / b;
+    G[r + (int64_t)c * l] = 0.0;
+  }
 }
 
 // ---- Y[:, j0:j0+b] <- Y[:, j0:j0+b] * X  (X upper triangular b x b, ld CQ_TB); thread = one row ----
@@ -172,8 +186,19 @@ void cholqr2(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld, doub
     if (pass == 1)
       hipLaunchKernelGGL(cq_orth_check_kernel, dim3(grid_for((int64_t)l * l, 64)), dim3(256), 0, st, Rp, l, 0.1,
                          flag);
-    hipLaunchKernelGGL(cq_chol_kernel, dim3(1), dim3(1024), 0, st, Rp, l, flag);    // R = chol(G)
-    hipLaunchKernelGGL(cq_trinv_blocks_kernel, dim3(nblk), dim3(64), 0, st, Rp, l, Rinv);
+    // R = chol(G), blocked: per 32-column block one small kernel (diagonal block + its inverse + block
+    // row) and one MFMA GEMM for the trailing update; the block inverses are what the solve below needs
+    hipLaunchKernelGGL(cq_diagmax_kernel, dim3(1), dim3(256), 0, st, Rp, l, Gt);
+    for (int jb = 0; jb < nblk; ++jb) {
+      const int j0 = jb * CQ_TB;
+      const int b = (l - j0 < CQ_TB) ? (l - j0) : CQ_TB;
+      hipLaunchKernelGGL(cq_chol_block_kernel, dim3(1), dim3(256), 0, st, Rp, l, j0, b, Gt,
+                         Rinv + (size_t)jb * CQ_TB * CQ_TB, flag);
+      const int t = l - j0 - b;
+      if (t > 0)
+        gemm_f64(st, true, t, t, b, -1.0, Rp + j0 + (int64_t)(j0 + b) * l, l, Rp + j0 + (int64_t)(j0 + b) * l, l, 1.0,
+                 Rp + (j0 + b) + (int64_t)(j0 + b) * l, l, gemm_ws);
+    }
     for (int jb = 0; jb < nblk; ++jb) {                                             // Y <- Y R^-1, blocked
       const int64_t j0 = (int64_t)jb * CQ_TB;
       const int b = (int)((l - j0 < CQ_TB) ? (l - j0) : CQ_TB);
@@ -183,7 +208,6 @@ void cholqr2(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld, doub
                          Rinv + (size_t)jb * CQ_TB * CQ_TB);
     }
   }
-  (void)Gt;
   if (R != nullptr)
     hipLaunchKernelGGL(cq_triprod_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, R2, R1, l, R);
 }

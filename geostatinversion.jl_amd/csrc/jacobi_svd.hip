@@ -19,7 +19,7 @@ namespace gsi { namespace hipk {
 
 constexpr int SVD_W = 16;          // columns per block
 constexpr int SVD_C = 2 * SVD_W;   // columns resident per workgroup
-constexpr int SVD_THREADS = 1024;  // 16 waves = one per pair of an inner round
+constexpr int SVD_THREADS = 256;   // 4 waves; a 16-lane quarter wave per column pair of an inner round
 
 // round-robin ("circle") tournament on n (even) players: pair q of round r
 __device__ __host__ inline void rr_pair(int n, int r, int q, int* a, int* b) {
@@ -35,6 +35,12 @@ __device__ inline double wave_allsum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// sum over the 16 lanes of a quarter wave (stays inside one DPP row)
+__device__ inline double quarter_allsum(double v) {
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+  return v;
+}
 
 // grid.x = number of block pairs in this round
 __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __restrict__ G, int l, int lp,
@@ -46,6 +52,7 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int quarter = lane >> 4, l16 = lane & 15;
   int ba, bb;
   if (nblk <= 2) { ba = 0; bb = 1; }
   else rr_pair(nblk, round, blockIdx.x, &ba, &bb);
@@ -61,36 +68,40 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   for (int sw = 0; sw < inner_sweeps; ++sw) {
     for (int r = 0; r < SVD_C - 1; ++r) {
       int p, q;
-      rr_pair(SVD_C, r, wave, &p, &q);
+      rr_pair(SVD_C, r, 4 * wave + quarter, &p, &q);
       double* gp = cols + p * lp;
       double* gq = cols + q * lp;
       double a = 0.0, b = 0.0, c = 0.0;
-      for (int i = lane; i < l; i += 64) {
+      for (int i = l16; i < l; i += 16) {
         const double x = gp[i], y = gq[i];
         a += x * x; b += y * y; c += x * y;
       }
-      a = wave_allsum(a); b = wave_allsum(b); c = wave_allsum(c);
+      a = quarter_allsum(a); b = quarter_allsum(b); c = quarter_allsum(c);
       if (a > 0.0 && b > 0.0 && c * c > tol2 * (a * b)) {
         // Rutishauser rotation, t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (b-a)/(2c),
-        // rewritten as t = sign(d*e) |e| / (|d| + hypot(d, e)): one sqrt, one division and one
-        // reciprocal square root instead of three of each (fp64 sqrt/div are ~25-instruction
-        // sequences on gfx950 and this chain is the latency of every inner round)
+        // rewritten as t = sign(d*e) |e| / (|d| + hypot(d, e)).  The angle only has to be approximately
+        // optimal -- what must hold to fp64 rounding is cs^2 + sn^2 = 1 -- so t comes from the
+        // one-instruction v_rsq_f64 / v_rcp_f64 approximations and only cs gets Newton steps.
         const double d = b - a, e = 2.0 * c;
-        const double r = sqrt(d * d + e * e);
-        const double t = copysign(fabs(e), d * e) / (fabs(d) + r);
-        const double cs = rsqrt(1.0 + t * t);
+        const double q2 = d * d + e * e;
+        const double r = q2 * __builtin_amdgcn_rsq(q2);                      // ~ hypot(d, e)
+        const double t = copysign(fabs(e), d * e) * __builtin_amdgcn_rcp(fabs(d) + r);
+        const double w = 1.0 + t * t;
+        double cs = __builtin_amdgcn_rsq(w);
+        cs = cs * (1.5 - 0.5 * w * cs * cs);                                 // Newton: 1/sqrt(w) to fp64
+        cs = cs * (1.5 - 0.5 * w * cs * cs);
         const double sn = cs * t;
-        for (int i = lane; i < l; i += 64) {
+        for (int i = l16; i < l; i += 16) {
           const double x = gp[i], y = gq[i];
           gp[i] = cs * x - sn * y;
           gq[i] = sn * x + cs * y;
         }
-        if (lane == 0) ++rots;
+        if (l16 == 0) ++rots;
       }
       __syncthreads();
     }
   }
-  if (lane == 0 && rots) atomicAdd(&s_rot, rots);
+  if (l16 == 0 && rots) atomicAdd(&s_rot, rots);
   __syncthreads();
   for (int e = tid; e < SVD_C * lp; e += SVD_THREADS) {
     const int c = e / lp, r = e % lp;
@@ -128,7 +139,8 @@ __global__ void jacobi_finish_kernel(const double* __restrict__ G, int l, const 
 
 int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, const SvdWork& w) {
   const int l = (int)l64;
-  const int lp = l;  // lanes stride rows: conflict-free without padding
+  int lp = l;   // column stride (doubles): lp % 32 == 16 spreads the quarter waves of a 32-lane group over both bank halves
+  while ((lp & 31) != 16) ++lp;
   int nblk = (l + SVD_W - 1) / SVD_W;
   if (nblk < 2) nblk = 2;
   if (nblk & 1) ++nblk;
