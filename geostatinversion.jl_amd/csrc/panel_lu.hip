@@ -12,8 +12,10 @@
 //                 per-workgroup arg-max of |Y[j:m, j]|                       (HBM/L2-bound)
 //     lu_pivot  : one workgroup: fixed-order reduction of the partial arg-maxes, the row
 //                 interchange across all l columns, and the pivot row for the next step
-//   per panel: lu_trsm (U12 = L11^-1 A12, one workgroup) and the trailing update
-//   A22 -= L21*U12 through the MFMA gemm kernel.
+//   per block: lu_trsm (U12 = L11^-1 A12) and the trailing update A22 -= L21*U12 through the
+//   MFMA gemm kernel.  Blocks of LU_NB columns are split recursively down to LU_LEAF columns
+//   (dgetrf2 style), so a sweep touches at most LU_LEAF live columns: the HBM traffic of the
+//   sweeps is n*l*LU_LEAF*8 B instead of n*l*LU_NB*8 B.
 // Everything is stream-ordered; the host never looks at a pivot.  An exactly zero pivot
 // (Julia: SingularException) is recorded in the sticky *info flag, which the backend reads
 // and clears at the end of the entry point.
@@ -39,13 +41,13 @@ __global__ __launch_bounds__(256) void lu_step_kernel(double* __restrict__ Y, in
   __shared__ int64_t s_idx[4];
   const int tid = threadIdx.x;
   const int nlive = (int)(jb + b - j);  // columns j .. jb+b-1
-  double u[LU_NB];
+  double u[LU_LEAF];
   double rpiv = 0.0;
   if (do_update) {
     const double piv = urow[j - 1 - jb];
     rpiv = (piv != 0.0) ? 1.0 / piv : 0.0;
 #pragma unroll
-    for (int k = 0; k < LU_NB; ++k) u[k] = (k < nlive) ? urow[j - jb + k] : 0.0;
+    for (int k = 0; k < LU_LEAF; ++k) u[k] = (k < nlive) ? urow[j - jb + k] : 0.0;
   }
   double best = -1.0;
   int64_t besti = -1;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void lu_step_kernel(double* __restrict__ Y, in
         const double lij = (rpiv != 0.0) ? row[(j - 1) * ld] * rpiv : row[(j - 1) * ld];
         row[(j - 1) * ld] = lij;
 #pragma unroll
-        for (int k = 0; k < LU_NB; ++k) {
+        for (int k = 0; k < LU_LEAF; ++k) {
           if (k < nlive) {
             const double v = row[(j + k) * ld] - lij * u[k];
             row[(j + k) * ld] = v;
@@ -145,9 +147,9 @@ __global__ __launch_bounds__(256) void lu_pivot_kernel(double* __restrict__ Y, i
   for (int k = tid; k < b; k += 256) urow[k] = Y[j + (jb + k) * ld];
 }
 
-// U12 = L11^-1 * A12 for the b x (l - jb - b) block right of the panel; thread = one column
-__global__ __launch_bounds__(256) void lu_trsm_kernel(double* __restrict__ Y, int64_t ld, int64_t l,
-                                                      int64_t jb, int b) {
+// U12 = L11^-1 * A12 for rows jb..jb+b of the columns [c_begin, c_end); thread = one column
+__global__ __launch_bounds__(256) void lu_trsm_kernel(double* __restrict__ Y, int64_t ld, int64_t c_begin,
+                                                      int64_t c_end, int64_t jb, int b) {
   __shared__ double L11[LU_NB * LU_NB];
   const int tid = threadIdx.x;
   for (int e = tid; e < b * b; e += 256) {
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void lu_trsm_kernel(double* __restrict__ Y, in
     L11[r + c * LU_NB] = Y[(jb + r) + (jb + c) * ld];
   }
   __syncthreads();
-  for (int64_t c = jb + b + (int64_t)blockIdx.x * 256 + tid; c < l; c += (int64_t)gridDim.x * 256) {
+  for (int64_t c = c_begin + (int64_t)blockIdx.x * 256 + tid; c < c_end; c += (int64_t)gridDim.x * 256) {
     double x[LU_NB];
     double* col = Y + jb + c * ld;
 #pragma unroll
@@ -187,33 +189,60 @@ __global__ void lu_extract_L_kernel(double* __restrict__ Y, int64_t ld, int64_t 
   }
 }
 
+namespace {
+struct LuCtx {
+  hipStream_t st; double* Y; int64_t m, l, ld; const LuWork* w; double* gemm_ws; int rpt; int64_t rows_per_block;
+};
+
+// per-column sweeps over the leaf [jb, jb+b): 2 launches per column
+void lu_leaf(const LuCtx& c, int64_t jb, int b) {
+  for (int64_t j = jb; j <= jb + b; ++j) {
+    const int do_update = (j > jb) ? 1 : 0;
+    const int do_argmax = (j < jb + b) ? 1 : 0;
+    const int64_t rows = c.m - j;
+    if (rows <= 0) break;
+    const int64_t nblocks = (rows + c.rows_per_block - 1) / c.rows_per_block;
+    hipLaunchKernelGGL(lu_step_kernel, dim3((unsigned)nblocks), dim3(256), 0, c.st, c.Y, c.ld, c.m, jb, b, j,
+                       do_update, do_argmax, c.w->urow, c.rpt, c.w->pval, c.w->pidx);
+    if (do_argmax)
+      hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(256), 0, c.st, c.Y, c.ld, c.m, c.l, jb, b, j, c.w->pval,
+                         c.w->pidx, (int)nblocks, c.w->urow, c.w->ipiv, c.w->info);
+  }
+}
+
+// columns [c0, c1) right of the factored block [jb, jb+b): U12 = L11^-1 A12, A22 -= L21 U12
+void lu_update_right(const LuCtx& c, int64_t jb, int b, int64_t c0, int64_t c1) {
+  const int64_t t = c1 - c0;
+  if (t <= 0) return;
+  const int tb = (int)((t + 255) / 256);
+  hipLaunchKernelGGL(lu_trsm_kernel, dim3(tb), dim3(256), 0, c.st, c.Y, c.ld, c0, c1, jb, b);
+  const int64_t mr = c.m - jb - b;
+  if (mr > 0)
+    gemm_f64(c.st, false, mr, t, b, -1.0, c.Y + (jb + b) + jb * c.ld, c.ld, c.Y + jb + c0 * c.ld, c.ld, 1.0,
+             c.Y + (jb + b) + c0 * c.ld, c.ld, c.gemm_ws);
+}
+
+// recursive halving (dgetrf2 style) of the block [j0, j0+w), w <= LU_NB: the per-column sweeps only
+// ever touch <= LU_LEAF live columns, the rest of the block is brought up to date by small GEMMs
+void lu_rec(const LuCtx& c, int64_t j0, int w) {
+  if (w <= LU_LEAF) { lu_leaf(c, j0, w); return; }
+  const int w1 = ((w / 2 + LU_LEAF - 1) / LU_LEAF) * LU_LEAF >= w ? w / 2 : ((w / 2 + LU_LEAF - 1) / LU_LEAF) * LU_LEAF;
+  lu_rec(c, j0, w1);
+  lu_update_right(c, j0, w1, j0 + w1, j0 + w);
+  lu_rec(c, j0 + w1, w - w1);
+}
+}  // namespace
+
 void lu_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const LuWork& w, double* gemm_ws) {
-  int rpt = (int)((m + 256 * 1024 - 1) / (256 * 1024));
-  if (rpt < 1) rpt = 1;
-  const int64_t rows_per_block = 256 * (int64_t)rpt;
+  LuCtx c;
+  c.st = st; c.Y = Y; c.m = m; c.l = l; c.ld = ld; c.w = &w; c.gemm_ws = gemm_ws;
+  c.rpt = (int)((m + 256 * 1024 - 1) / (256 * 1024));
+  if (c.rpt < 1) c.rpt = 1;
+  c.rows_per_block = 256 * (int64_t)c.rpt;
   for (int64_t jb = 0; jb < l; jb += LU_NB) {
     const int b = (int)((l - jb < LU_NB) ? (l - jb) : LU_NB);
-    for (int64_t j = jb; j <= jb + b; ++j) {
-      const int do_update = (j > jb) ? 1 : 0;
-      const int do_argmax = (j < jb + b) ? 1 : 0;
-      const int64_t rows = m - j;
-      if (rows <= 0) break;
-      int64_t nblocks = (rows + rows_per_block - 1) / rows_per_block;
-      hipLaunchKernelGGL(lu_step_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, Y, ld, m, jb, b, j,
-                         do_update, do_argmax, w.urow, rpt, w.pval, w.pidx);
-      if (do_argmax)
-        hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(256), 0, st, Y, ld, m, l, jb, b, j, w.pval, w.pidx,
-                           (int)nblocks, w.urow, w.ipiv, w.info);
-    }
-    const int64_t t = l - jb - b;
-    if (t > 0) {
-      int tb = (int)((t + 255) / 256);
-      hipLaunchKernelGGL(lu_trsm_kernel, dim3(tb), dim3(256), 0, st, Y, ld, l, jb, b);
-      const int64_t mr = m - jb - b;
-      if (mr > 0)
-        gemm_f64(st, false, mr, t, b, -1.0, Y + (jb + b) + jb * ld, ld, Y + jb + (jb + b) * ld, ld, 1.0,
-                 Y + (jb + b) + (jb + b) * ld, ld, gemm_ws);
-    }
+    lu_rec(c, jb, b);
+    lu_update_right(c, jb, b, jb + b, l);
   }
   int eb = (int)((l * l + 255) / 256);
   if (eb > 1024) eb = 1024;
