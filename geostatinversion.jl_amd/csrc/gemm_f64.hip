@@ -47,13 +47,18 @@ namespace gsi { namespace hipk {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int BMT = 128;   // C rows per workgroup (4 row groups x 32)
+constexpr int MT = 2;                 // 16-row tiles per wave (wave tile = 16*MT rows x NT/2*16 columns)
+constexpr int BMT = 4 * 16 * MT;      // C rows per workgroup (4 row groups)
 constexpr int NTHREADS = 512;
-constexpr int BK = 32;     // reduction depth per LDS tile
-constexpr int BKP = 34;    // padded k stride (doubles) of the [col][k] images (BKP/2 odd)
-constexpr int BMP = 144;   // padded row stride (doubles) of the NN A image [k][r]
-constexpr int NTMAX = 10;  // 16-column tiles per workgroup pass (160 columns)
-constexpr int A_LOADS = BMT * BK / NTHREADS;   // 8 doubles per thread per tile
+constexpr int BK = 32;                // reduction depth per LDS tile
+constexpr int BKP = BK + 2;           // padded k stride (doubles) of the [col][k] images (BKP/2 odd)
+constexpr int BMP = BMT + 16;         // padded row stride (doubles) of the NN A image [k][r]
+constexpr int NTMAX = 10;             // 16-column tiles per workgroup pass (160 columns)
+constexpr int NSETS = 2;              // staging register sets: tiles are fetched NSETS tiles ahead
+constexpr int A_PAIRS = BMT * BK / (2 * NTHREADS);   // 16-byte pairs per thread per A tile
+constexpr int KSTEP_NN = 2 * NTHREADS / BMT;          // NN A tile: k advance per pair slot
+constexpr int RSTEP = 2 * NTHREADS / BK;              // TN A tile / B tile: row (column) advance per pair slot
+static_assert(A_PAIRS * 2 * NTHREADS == BMT * BK, "tile does not divide over the threads");
 
 template <int NT, bool TRANS_A>
 __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int rg = wave & 3;    // row group: C rows 32*rg .. 32*rg+31 of the workgroup tile
+  const int rg = wave & 3;    // row group: C rows 16*MT*rg .. of the workgroup tile
   const int ch = wave >> 2;   // column half: 16-column tiles ch*NTW .. of the workgroup's NT
   constexpr int NTW = (NT + 1) / 2;
   const int jl = lane & 15;   // MFMA "column" index -> C row within a 16-row tile
@@ -79,33 +84,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
   const int64_t ntiles = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
 
-  double4_t acc[2][NTW];
+  double4_t acc[MT][NTW];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < MT; ++h)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[h][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  // Staging registers: two sets (tiles of even / odd index, loaded two tiles ahead).  Every thread
-  // owns PAIRS of elements adjacent along the contiguous dimension, so that with 16-byte-aligned
-  // operands (wide != 0: base pointers 16-B aligned, even leading dimensions) each pair is one
+  // Staging registers: NSETS sets (tiles are loaded NSETS tiles ahead).  Every thread owns PAIRS of
+  // elements adjacent along the contiguous dimension, so that with 16-byte-aligned operands
+  // (wide != 0: base pointers 16-B aligned, even leading dimensions) each pair is one
   // global_load_dwordx4 and one ds_write_b128 -- half the VMEM / LDS-write instructions.
-  constexpr int A_PAIRS = A_LOADS / 2;          // 4
-  constexpr int B_PAIRS = (NT + 1) / 2;         // NT*16 columns x 16 k-pairs / 512 threads
-  double2 a_reg[2][A_PAIRS];
-  double2 b_reg[2][B_PAIRS];
+  constexpr int B_PAIRS = (NT * 16 + RSTEP - 1) / RSTEP;
+  constexpr bool B_RAGGED = (NT * 16) % RSTEP != 0;
+  double2 a_reg[NSETS][A_PAIRS];
+  double2 b_reg[NSETS][B_PAIRS];
 
-  // NN A tile: pair (r = 2*(tid%64),  k = tid/64 + 8*it)     -> 1 KB contiguous per wave
-  // TN A tile: pair (k = 2*(tid%16),  r = tid/16 + 32*it)    -> 256 B contiguous per 16 lanes
-  // B tile   : pair (k = 2*(tid%16),  c = tid/16 + 32*it)
-  const int a_r = TRANS_A ? (tid >> 4) : 2 * (tid & 63);
-  const int a_k = TRANS_A ? 2 * (tid & 15) : (tid >> 6);
-  const int b_c = tid >> 4;
-  const int b_k = 2 * (tid & 15);
+  // NN A tile: pair (r = 2*(tid % (BMT/2)), k = tid/(BMT/2) + KSTEP_NN*it)
+  // TN A tile: pair (k = 2*(tid % (BK/2)),  r = tid/(BK/2) + RSTEP*it)
+  // B tile   : pair (k = 2*(tid % (BK/2)),  c = tid/(BK/2) + RSTEP*it)
+  const int a_r = TRANS_A ? (tid / (BK / 2)) : 2 * (tid % (BMT / 2));
+  const int a_k = TRANS_A ? 2 * (tid % (BK / 2)) : (tid / (BMT / 2));
+  const int b_c = tid / (BK / 2);
+  const int b_k = 2 * (tid % (BK / 2));
 
   const uint32_t a_off0 = 8u * (TRANS_A ? (uint32_t)(a_k + (int64_t)a_r * lda) : (uint32_t)(a_r + (int64_t)a_k * lda));
-  const uint32_t a_step_c = 8u * (uint32_t)((TRANS_A ? 32 : 8) * lda);
+  const uint32_t a_step_c = 8u * (uint32_t)((TRANS_A ? RSTEP : KSTEP_NN) * lda);
   const uint32_t b_off0 = 8u * (uint32_t)(b_k + (int64_t)b_c * ldb);
-  const uint32_t b_step_c = 8u * (uint32_t)(32 * ldb);
+  const uint32_t b_step_c = 8u * (uint32_t)(RSTEP * ldb);
   // byte distance between the two elements of a pair when they cannot be fetched as one 16-B load
   const char* const Abase = reinterpret_cast<const char*>(TRANS_A ? A + r0 * lda : A + r0);
   const char* const Bbase = reinterpret_cast<const char*>(B + c0 * ldb);
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
         a_reg[set][it] = *reinterpret_cast<const double2*>(Ab + (a_off0 + (uint32_t)it * a_step));
 #pragma unroll
       for (int it = 0; it < B_PAIRS; ++it)
-        if ((NT % 2 == 0) || b_c + 32 * it < NT * 16)
+        if (!B_RAGGED || b_c + RSTEP * it < NT * 16)
           b_reg[set][it] = *reinterpret_cast<const double2*>(Bb + (b_off0 + (uint32_t)it * b_step));
       return;
     }
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 #pragma unroll
     for (int it = 0; it < A_PAIRS; ++it) {
       const char* p = Ab + (a_off0 + (uint32_t)it * a_step);
-      const int64_t r = TRANS_A ? r0 + a_r + 32 * it : r0 + a_r;
-      const int64_t k = TRANS_A ? k0 + a_k : k0 + a_k + 8 * it;
+      const int64_t r = TRANS_A ? r0 + a_r + RSTEP * it : r0 + a_r;
+      const int64_t k = TRANS_A ? k0 + a_k : k0 + a_k + KSTEP_NN * it;
       const bool ok0 = (r < M && k < kend);
       const bool ok1 = TRANS_A ? (r < M && k + 1 < kend) : (r + 1 < M && k < kend);
       a_reg[set][it].x = ok0 ? *reinterpret_cast<const double*>(p) : 0.0;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 #pragma unroll
     for (int it = 0; it < B_PAIRS; ++it) {
       const char* p = Bb + (b_off0 + (uint32_t)it * b_step);
-      const int cl = b_c + 32 * it;
+      const int cl = b_c + RSTEP * it;
       const int64_t c = c0 + cl;
       const int64_t k = k0 + b_k;
       const bool okc = (cl < NT * 16) && (c < L);
@@ -161,30 +166,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     if (TRANS_A) {
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it)
-        *reinterpret_cast<double2*>(a_s + (a_r + 32 * it) * BKP + a_k) = a_reg[set][it];
+        *reinterpret_cast<double2*>(a_s + (a_r + RSTEP * it) * BKP + a_k) = a_reg[set][it];
     } else {
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it)
-        *reinterpret_cast<double2*>(a_s + (a_k + 8 * it) * BMP + a_r) = a_reg[set][it];
+        *reinterpret_cast<double2*>(a_s + (a_k + KSTEP_NN * it) * BMP + a_r) = a_reg[set][it];
     }
 #pragma unroll
     for (int it = 0; it < B_PAIRS; ++it)
-      if ((NT % 2 == 0) || b_c + 32 * it < NT * 16)
-        *reinterpret_cast<double2*>(b_s + (b_c + 32 * it) * BKP + b_k) = b_reg[set][it];
+      if (!B_RAGGED || b_c + RSTEP * it < NT * 16)
+        *reinterpret_cast<double2*>(b_s + (b_c + RSTEP * it) * BKP + b_k) = b_reg[set][it];
   };
 
   // Fragments of one k4 step: 2 A fragments (rows 32w + jl, 32w + 16 + jl) and NT B fragments.
   // The B fragments are reloaded in place for the NEXT k4 step right after the two MFMAs that
   // consume them have issued (rolling single buffer), the A fragments one step ahead into a second
   // pair: every LDS read has a full k4 step (1280 MFMA cycles at NT = 10) to land.
-  double fa[2], fan[2];
+  double fa[MT], fan[MT];
   double fb[NTW];
   const int t0 = ch * NTW;                       // first 16-column tile of this wave
   const int ntw = (NT - t0 < NTW) ? ((NT - t0 > 0) ? NT - t0 : 0) : NTW;   // tiles this wave owns (wave-uniform)
   auto a_frag = [&](int buf, int s, int h) -> double {
     const double* a_s = smem + buf * BUF_ELEMS;
-    return TRANS_A ? a_s[(32 * rg + 16 * h + jl) * BKP + 4 * s + kk]
-                   : a_s[(4 * s + kk) * BMP + 32 * rg + 16 * h + jl];
+    return TRANS_A ? a_s[(16 * MT * rg + 16 * h + jl) * BKP + 4 * s + kk]
+                   : a_s[(4 * s + kk) * BMP + 16 * MT * rg + 16 * h + jl];
   };
   auto b_frag = [&](int buf, int s, int t) -> double {
     const double* b_s = smem + buf * BUF_ELEMS + A_ELEMS;
@@ -196,13 +201,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   // one tile of the pipeline; PAR = parity of t (compile time: selects LDS buffer and register set)
   auto do_tile = [&](int64_t t, auto PAR) {
     constexpr int cur = decltype(PAR)::value;
-    using Other = std::integral_constant<int, cur ^ 1>;
+    using NextSet = std::integral_constant<int, (NSETS == 2) ? (cur ^ 1) : 0>;
     // The two waves of a SIMD (column halves ch = 0 / 1 of the same rows) run the same program;
     // their LDS-write / VMEM chores are staggered by half a tile so that one partner is always in
     // a pure MFMA stretch (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
     auto chores = [&]() {
-      if (t + 1 < ntiles) stage(cur ^ 1, Other{});                      // tile t+1: registers -> other LDS buffer
-      if (t + 3 < ntiles) prefetch(kbeg + (t + 3) * BK, Other{});       // tile t+3: HBM -> the set just drained
+      if (t + 1 < ntiles) stage(cur ^ 1, NextSet{});                                 // tile t+1: registers -> other LDS buffer
+      if (t + 1 + NSETS < ntiles) prefetch(kbeg + (t + 1 + NSETS) * BK, NextSet{});  // HBM -> the set just drained
     };
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
@@ -215,28 +220,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
       const int nbuf = last ? (cur ^ 1) : cur;
       const int ns = last ? 0 : s + 1;
       const bool more = !last || (t + 1 < ntiles);
-      if (more) { fan[0] = a_frag(nbuf, ns, 0); fan[1] = a_frag(nbuf, ns, 1); }
+      if (more) {
+#pragma unroll
+        for (int h = 0; h < MT; ++h) fan[h] = a_frag(nbuf, ns, h);
+      }
 #pragma unroll
       for (int tt = 0; tt < NTW; ++tt) {
         if ((NT % 2 == 0) || tt < ntw) {
-          acc[0][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tt], fa[0], acc[0][tt], 0, 0, 0);
-          acc[1][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tt], fa[1], acc[1][tt], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < MT; ++h)
+            acc[h][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tt], fa[h], acc[h][tt], 0, 0, 0);
           if (more) fb[tt] = b_frag(nbuf, ns, tt);
         }
       }
-      fa[0] = fan[0];
-      fa[1] = fan[1];
+#pragma unroll
+      for (int h = 0; h < MT; ++h) fa[h] = fan[h];
     }
   };
 
   if (ntiles > 0) {
     prefetch(kbeg, Set0{});
-    if (ntiles > 1) prefetch(kbeg + BK, Set1{});
+    if (NSETS == 2 && ntiles > 1) prefetch(kbeg + BK, Set1{});
     stage(0, Set0{});
-    if (ntiles > 2) prefetch(kbeg + 2 * BK, Set0{});
+    if (ntiles > NSETS) prefetch(kbeg + NSETS * BK, Set0{});
     __syncthreads();
-    fa[0] = a_frag(0, 0, 0);
-    fa[1] = a_frag(0, 0, 1);
+#pragma unroll
+    for (int h = 0; h < MT; ++h) fa[h] = a_frag(0, 0, h);
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
       if ((NT % 2 == 0) || t < ntw) fb[t] = b_frag(0, 0, t);
@@ -250,8 +259,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 
   // epilogue: lane holds D[i = kk + 4*reg][j = jl]  ->  C[row][col = c0 + 16*(t0+t) + kk + 4*reg]
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int64_t row = r0 + 32 * rg + 16 * h + jl;
+  for (int h = 0; h < MT; ++h) {
+    const int64_t row = r0 + 16 * MT * rg + 16 * h + jl;
     if (row < M) {
       double* W = (slabs != nullptr) ? slabs + (int64_t)blockIdx.y * M * L : nullptr;
 #pragma unroll
