@@ -149,13 +149,18 @@ class HipBackend : public Backend {
   void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv_host) override {
     bind();
     const int64_t nb = hipk::lu_max_blocks(m);
-    const size_t need = sizeof(double) * (hipk::LU_NB + nb) + sizeof(int64_t) * nb + sizeof(int32_t) * (l + 4) + 64;
+    const size_t per_set = sizeof(double) * (size_t)nb + sizeof(int64_t) * (size_t)nb +
+                           sizeof(double) * (size_t)nb * (hipk::LU_LEAF + 1) + sizeof(double) * 16;
+    const size_t need = 2 * per_set + sizeof(int32_t) * (l + 4) + 256;
     grow(ws_lu_, need);
     char* base = (char*)ws_lu_.p;
     hipk::LuWork w;
-    w.urow = (double*)base; base += sizeof(double) * hipk::LU_NB;
-    w.pval = (double*)base; base += sizeof(double) * nb;
-    w.pidx = (int64_t*)base; base += sizeof(int64_t) * nb;
+    for (int s = 0; s < 2; ++s) {
+      w.pval[s] = (double*)base; base += sizeof(double) * nb;
+      w.pidx[s] = (int64_t*)base; base += sizeof(int64_t) * nb;
+      w.cand[s] = (double*)base; base += sizeof(double) * nb * (hipk::LU_LEAF + 1);
+      w.rowsave[s] = (double*)base; base += sizeof(double) * 16;
+    }
     w.ipiv = (int32_t*)base;
     w.info = flags_ + 0;
     w.maxblocks = nb;

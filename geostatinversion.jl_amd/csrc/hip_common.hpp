@@ -13,11 +13,13 @@ void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, doub
 
 // ---- panel_lu.hip ----
 struct LuWork {
-  double* urow;     // [NB] pivot row of the active panel
-  double* pval;     // [maxblocks] partial arg-max values
-  int64_t* pidx;    // [maxblocks] partial arg-max rows
-  int32_t* ipiv;    // [l] pivot rows (0-based)
-  int32_t* info;    // [1] first exactly-zero pivot (1-based), 0 if none
+  // ping-pong sets (column parity): what the sweep of column j leaves for the sweep of column j+1
+  double* pval[2];     // [maxblocks] per-workgroup arg-max values of column j
+  int64_t* pidx[2];    // [maxblocks] per-workgroup arg-max rows
+  double* cand[2];     // [maxblocks * LU_LEAF] live-column values of each workgroup's candidate row
+  double* rowsave[2];  // [LU_LEAF] live-column values of row j (the row the pivot will be swapped with)
+  int32_t* ipiv;       // [l] pivot rows (0-based)
+  int32_t* info;       // [1] first exactly-zero pivot (1-based), 0 if none
   int64_t maxblocks;
 };
 constexpr int LU_NB = 32;     // outer block (trailing update through the MFMA GEMM)

@@ -8,10 +8,9 @@
 // Blocked right-looking factorization, block width LU_NB:
 //   per column j of the active panel (thread = one row, loop over the <= NB live columns,
 //   so every global access is a coalesced column segment):
-//     lu_step   : apply the rank-1 update of column j-1 to the live panel columns, then the
-//                 per-workgroup arg-max of |Y[j:m, j]|                       (HBM/L2-bound)
-//     lu_pivot  : one workgroup: fixed-order reduction of the partial arg-maxes, the row
-//                 interchange across all l columns, and the pivot row for the next step
+//     lu_sweep  : ONE launch per column: finish column j-1 (redundant fixed-order reduction of the
+//                 per-workgroup arg-maxes, row interchange by workgroup 0), apply its rank-1 update
+//                 to the live leaf columns, leave the arg-max of |Y[j:m, j]|       (HBM/L2-bound)
 //   per block: lu_trsm (U12 = L11^-1 A12) and the trailing update A22 -= L21*U12 through the
 //   MFMA gemm kernel.  Blocks of LU_NB columns are split recursively down to LU_LEAF columns
 //   (dgetrf2 style), so a sweep touches at most LU_LEAF live columns: the HBM traffic of the
@@ -31,120 +30,151 @@ int64_t lu_max_blocks(int64_t m) {
   return (m + 256 * rpt - 1) / (256 * rpt) + 1;
 }
 
-// rows [j, m): update with column j-1 (if do_update), then arg-max over column j (if do_argmax)
-__global__ __launch_bounds__(256) void lu_step_kernel(double* __restrict__ Y, int64_t ld, int64_t m,
-                                                      int64_t jb, int b, int64_t j, int do_update,
-                                                      int do_argmax, const double* __restrict__ urow,
-                                                      int rows_per_thread, double* __restrict__ pval,
-                                                      int64_t* __restrict__ pidx) {
-  __shared__ double s_val[4];
-  __shared__ int64_t s_idx[4];
+__device__ inline bool lu_better(double ov, int64_t oi, double v, int64_t i) {
+  // idamax order: larger |value| wins, first (smallest) row index on ties
+  return ov > v || (ov == v && oi >= 0 && (i < 0 || oi < i));
+}
+
+// ONE launch per column.  For column j of the leaf [jb, jb+b) this kernel
+//   (1) finishes column j-1 (if do_update): every workgroup redundantly reduces the per-workgroup
+//       arg-maxes the previous launch left (fixed order -> identical everywhere), reads the pivot
+//       row's live values from the winner's published candidate row and the old row j-1 from
+//       `rowsave` (both written by the PREVIOUS launch and read-only here, so no workgroup races
+//       with the row interchange), workgroup 0 performs the interchange (non-live columns by a
+//       swap, live columns by writing the pivot row into row j-1; the thread that owns the pivot's
+//       old position computes with the old row j-1 and stores there), records ipiv/info;
+//   (2) scales column j-1 and applies its rank-1 update to the live columns j..jb+b-1 of rows >= j;
+//   (3) (if do_argmax) leaves the per-workgroup arg-max of |column j|, the candidate row's live
+//       values and row j's live values for the next launch.
+// Thread = one row (rows_per_thread rows for very tall panels); every global access is a coalesced
+// column segment.
+__global__ __launch_bounds__(256) void lu_sweep_kernel(
+    double* __restrict__ Y, int64_t ld, int64_t m, int64_t l, int64_t jb, int b, int64_t j, int do_update,
+    int do_argmax, int rows_per_thread, const double* __restrict__ pval_in, const int64_t* __restrict__ pidx_in,
+    const double* __restrict__ cand_in, const double* __restrict__ rowsave_in, int nblocks_prev,
+    double* __restrict__ pval_out, int64_t* __restrict__ pidx_out, double* __restrict__ cand_out,
+    double* __restrict__ rowsave_out, int32_t* __restrict__ ipiv, int32_t* __restrict__ info) {
+  __shared__ double s_val[256];
+  __shared__ int64_t s_idx[256];
+  __shared__ int s_blk[256];
+  __shared__ double s_u[LU_LEAF + 1];    // pivot row: [0] = pivot, [1+k] = live column j+k
+  __shared__ double s_old[LU_LEAF + 1];  // old row j-1, same layout
   const int tid = threadIdx.x;
-  const int nlive = (int)(jb + b - j);  // columns j .. jb+b-1
-  double u[LU_LEAF];
+  const int nlive = (int)(jb + b - j);   // live columns j .. jb+b-1
+  const int64_t jp = j - 1;
+  int64_t r = -1;
   double rpiv = 0.0;
   if (do_update) {
-    const double piv = urow[j - 1 - jb];
+    // (1) redundant, fixed-order reduction of the previous column's partial arg-maxes
+    double best = -1.0;
+    int64_t besti = -1;
+    int bblk = -1;
+    for (int p = tid; p < nblocks_prev; p += 256) {
+      const double ov = pval_in[p];
+      const int64_t oi = pidx_in[p];
+      if (lu_better(ov, oi, best, besti)) { best = ov; besti = oi; bblk = p; }
+    }
+    s_val[tid] = best; s_idx[tid] = besti; s_blk[tid] = bblk;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (tid < st && lu_better(s_val[tid + st], s_idx[tid + st], s_val[tid], s_idx[tid])) {
+        s_val[tid] = s_val[tid + st]; s_idx[tid] = s_idx[tid + st]; s_blk[tid] = s_blk[tid + st];
+      }
+      __syncthreads();
+    }
+    r = s_idx[0];
+    const int wblk = s_blk[0];
+    const bool valid = (r >= jp && r < m && wblk >= 0);
+    if (!valid) r = jp;   // all-NaN column: no interchange
+    const int nl1 = nlive + 1;
+    if (tid < nl1) {
+      s_old[tid] = rowsave_in[tid];
+      s_u[tid] = valid ? cand_in[(int64_t)wblk * (LU_LEAF + 1) + tid] : rowsave_in[tid];
+    }
+    const double bestv = s_val[0];
+    __syncthreads();
+    const double piv = s_u[0];
     rpiv = (piv != 0.0) ? 1.0 / piv : 0.0;
-#pragma unroll
-    for (int k = 0; k < LU_LEAF; ++k) u[k] = (k < nlive) ? urow[j - jb + k] : 0.0;
+    if (blockIdx.x == 0) {
+      if (tid == 0) {
+        ipiv[jp] = (int32_t)r;
+        if (!(bestv > 0.0) && *info == 0) *info = (int32_t)(jp + 1);
+      }
+      if (r != jp) {
+        for (int64_t c = tid; c < l; c += 256) {
+          if (c < jp || c >= jb + b) {          // not live: plain interchange
+            const double a0 = Y[jp + c * ld];
+            const double a1 = Y[r + c * ld];
+            Y[jp + c * ld] = a1;
+            Y[r + c * ld] = a0;
+          }
+        }
+        if (tid < nl1) Y[jp + (jp + tid) * ld] = s_u[tid];   // pivot row moves up into row j-1
+      }
+    }
   }
+  // (2) + (3)
   double best = -1.0;
   int64_t besti = -1;
+  double besta[LU_LEAF];
+#pragma unroll
+  for (int k = 0; k < LU_LEAF; ++k) besta[k] = 0.0;
   const int64_t base = j + (int64_t)blockIdx.x * 256 * rows_per_thread;
   for (int rr = 0; rr < rows_per_thread; ++rr) {
     const int64_t i = base + tid + 256 * (int64_t)rr;
     if (i < m) {
-      double yj = 0.0;
+      double* row = Y + i;
+      double a[LU_LEAF];
       if (do_update) {
-        double* row = Y + i;
-        const double lij = (rpiv != 0.0) ? row[(j - 1) * ld] * rpiv : row[(j - 1) * ld];
-        row[(j - 1) * ld] = lij;
+        const bool moved = (i == r);           // this position receives the old row j-1
+        const double x0 = moved ? s_old[0] : row[jp * ld];
+        const double lij = (rpiv != 0.0) ? x0 * rpiv : x0;
+        row[jp * ld] = lij;
 #pragma unroll
         for (int k = 0; k < LU_LEAF; ++k) {
           if (k < nlive) {
-            const double v = row[(j + k) * ld] - lij * u[k];
-            row[(j + k) * ld] = v;
-            if (k == 0) yj = v;
+            const double xk = moved ? s_old[1 + k] : row[(j + k) * ld];
+            a[k] = xk - lij * s_u[1 + k];
+            row[(j + k) * ld] = a[k];
           }
         }
-      } else if (do_argmax) {
-        yj = Y[i + j * ld];
+      } else {
+#pragma unroll
+        for (int k = 0; k < LU_LEAF; ++k)
+          if (k < nlive) a[k] = row[(j + k) * ld];
       }
       if (do_argmax) {
-        const double a = fabs(yj);
-        if (a > best) { best = a; besti = i; }
+        if (i == j) {
+#pragma unroll
+          for (int k = 0; k < LU_LEAF; ++k)
+            if (k < nlive) rowsave_out[k] = a[k];
+        }
+        const double av = fabs(a[0]);
+        if (av > best) {
+          best = av; besti = i;
+#pragma unroll
+          for (int k = 0; k < LU_LEAF; ++k) besta[k] = (k < nlive) ? a[k] : 0.0;
+        }
       }
     }
   }
   if (!do_argmax) return;
-  // wave reduction: larger value wins, smaller row index on ties (idamax: first maximum)
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double ov = __shfl_down(best, off, 64);
-    const int64_t oi = __shfl_down(besti, off, 64);
-    if (ov > best || (ov == best && oi >= 0 && (besti < 0 || oi < besti))) { best = ov; besti = oi; }
-  }
-  if ((tid & 63) == 0) { s_val[tid >> 6] = best; s_idx[tid >> 6] = besti; }
+  __syncthreads();   // s_val / s_idx reuse
+  s_val[tid] = best; s_idx[tid] = besti;
   __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < 4; ++w) {
-      const double ov = s_val[w];
-      const int64_t oi = s_idx[w];
-      if (ov > best || (ov == best && oi >= 0 && (besti < 0 || oi < besti))) { best = ov; besti = oi; }
-    }
-    pval[blockIdx.x] = best;
-    pidx[blockIdx.x] = besti;
-  }
-}
-
-// one workgroup: final arg-max, row interchange j <-> r over all l columns, pivot row out
-__global__ __launch_bounds__(256) void lu_pivot_kernel(double* __restrict__ Y, int64_t ld, int64_t m,
-                                                       int64_t l, int64_t jb, int b, int64_t j,
-                                                       const double* __restrict__ pval,
-                                                       const int64_t* __restrict__ pidx, int nblocks,
-                                                       double* __restrict__ urow, int32_t* __restrict__ ipiv,
-                                                       int32_t* __restrict__ info) {
-  __shared__ double s_val[256];
-  __shared__ int64_t s_idx[256];
-  const int tid = threadIdx.x;
-  double best = -1.0;
-  int64_t besti = -1;
-  for (int p = tid; p < nblocks; p += 256) {
-    const double ov = pval[p];
-    const int64_t oi = pidx[p];
-    if (ov > best || (ov == best && oi >= 0 && (besti < 0 || oi < besti))) { best = ov; besti = oi; }
-  }
-  s_val[tid] = best;
-  s_idx[tid] = besti;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) {
-      const double ov = s_val[tid + s];
-      const int64_t oi = s_idx[tid + s];
-      if (ov > s_val[tid] || (ov == s_val[tid] && oi >= 0 && (s_idx[tid] < 0 || oi < s_idx[tid]))) {
-        s_val[tid] = ov;
-        s_idx[tid] = oi;
-      }
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st && lu_better(s_val[tid + st], s_idx[tid + st], s_val[tid], s_idx[tid])) {
+      s_val[tid] = s_val[tid + st]; s_idx[tid] = s_idx[tid + st];
     }
     __syncthreads();
   }
-  int64_t r = s_idx[0];
-  if (r < 0 || r >= m) r = j;  // all-NaN / empty column: no interchange
-  if (tid == 0) {
-    ipiv[j] = (int32_t)r;
-    if (!(s_val[0] > 0.0) && *info == 0) *info = (int32_t)(j + 1);
+  const int64_t wi = s_idx[0];
+  if (tid == 0) { pval_out[blockIdx.x] = s_val[0]; pidx_out[blockIdx.x] = wi; }
+  if (wi >= 0 && wi == besti) {       // the (unique) thread that owns the workgroup's candidate row
+#pragma unroll
+    for (int k = 0; k < LU_LEAF; ++k)
+      if (k < nlive) cand_out[(int64_t)blockIdx.x * (LU_LEAF + 1) + k] = besta[k];
   }
-  if (r != j) {
-    for (int64_t c = tid; c < l; c += 256) {
-      const double a = Y[j + c * ld];
-      const double bb = Y[r + c * ld];
-      Y[j + c * ld] = bb;
-      Y[r + c * ld] = a;
-    }
-  }
-  __syncthreads();
-  for (int k = tid; k < b; k += 256) urow[k] = Y[j + (jb + k) * ld];
 }
 
 // U12 = L11^-1 * A12 for rows jb..jb+b of the columns [c_begin, c_end); thread = one column
@@ -194,19 +224,20 @@ struct LuCtx {
   hipStream_t st; double* Y; int64_t m, l, ld; const LuWork* w; double* gemm_ws; int rpt; int64_t rows_per_block;
 };
 
-// per-column sweeps over the leaf [jb, jb+b): 2 launches per column
+// per-column sweeps over the leaf [jb, jb+b): one launch per column (+1 to finish the last one)
 void lu_leaf(const LuCtx& c, int64_t jb, int b) {
+  int nblocks_prev = 0;
   for (int64_t j = jb; j <= jb + b; ++j) {
     const int do_update = (j > jb) ? 1 : 0;
     const int do_argmax = (j < jb + b) ? 1 : 0;
     const int64_t rows = c.m - j;
-    if (rows <= 0) break;
-    const int64_t nblocks = (rows + c.rows_per_block - 1) / c.rows_per_block;
-    hipLaunchKernelGGL(lu_step_kernel, dim3((unsigned)nblocks), dim3(256), 0, c.st, c.Y, c.ld, c.m, jb, b, j,
-                       do_update, do_argmax, c.w->urow, c.rpt, c.w->pval, c.w->pidx);
-    if (do_argmax)
-      hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(256), 0, c.st, c.Y, c.ld, c.m, c.l, jb, b, j, c.w->pval,
-                         c.w->pidx, (int)nblocks, c.w->urow, c.w->ipiv, c.w->info);
+    int64_t nblocks = (rows > 0) ? (rows + c.rows_per_block - 1) / c.rows_per_block : 1;   // >= 1: workgroup 0 finishes column j-1
+    const int pin = (int)((j - 1) & 1), pout = (int)(j & 1);
+    hipLaunchKernelGGL(lu_sweep_kernel, dim3((unsigned)nblocks), dim3(256), 0, c.st, c.Y, c.ld, c.m, c.l, jb, b, j,
+                       do_update, do_argmax, c.rpt, c.w->pval[pin & 1], c.w->pidx[pin & 1], c.w->cand[pin & 1],
+                       c.w->rowsave[pin & 1], nblocks_prev, c.w->pval[pout], c.w->pidx[pout], c.w->cand[pout],
+                       c.w->rowsave[pout], c.w->ipiv, c.w->info);
+    nblocks_prev = (int)nblocks;
   }
 }
 
