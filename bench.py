@@ -12,7 +12,7 @@ roofline       = the dominant kernel (the fp64 MFMA contraction A*X / A'*X): 2 n
                  launch / its average launch duration, HIP events on the library's stream inside
                  the timed region; peak = 78.6 TFLOP/s dense fp64 MFMA
 cpu_baseline   = the numpy/scipy oracle (same LAPACK/BLAS call sequence as the Julia reference) on
-                 a bounded sample of the same workload (n = 16384), all host cores; the same sample
+                 a bounded sample of the same workload (n = 25600), all host cores; the same sample
                  gives `sv_rel_err` (top-K singular values, GPU vs oracle, same Omega)
 """
 import argparse
@@ -34,13 +34,18 @@ def algorithmic_bytes(n, l, q):
     return P * (8.0 * n * n + 16.0 * n * l)
 
 
-def cpu_baseline_and_parity(gsi, ctx, K, p, q, grid=128, ell=8.0):
+def cpu_baseline_and_parity(gsi, ctx, K, p, q, grid=160, ell=10.0):
     """Oracle timed on the host on a bounded sample; GPU result on the same inputs for parity."""
     import numpy as np
     from oracle import oracle as orc
-    from helpers import gaussian_cov, rel_sv_err
+    from helpers import rel_sv_err
     n, l = grid * grid, K + p
-    A = gaussian_cov(grid, grid, ell)
+    gx = np.repeat(np.arange(grid, dtype=np.float64), grid)          # point i = (i // grid, i % grid)
+    gy = np.tile(np.arange(grid, dtype=np.float64), grid)
+    A = (gx[:, None] - gx[None, :]) ** 2
+    A += (gy[:, None] - gy[None, :]) ** 2
+    A *= -1.0 / (2.0 * ell * ell)
+    np.exp(A, out=A)
     rng = np.random.default_rng(0)
     Omega = rng.standard_normal((n, l))
     t0 = time.perf_counter()
