@@ -136,7 +136,7 @@ int gsi_op_dense(gsi_ctx* ctx, gsi_op** op, const double* A_rows, int64_t m, int
     std::unique_ptr<gsi_op> o(new gsi_op());
     Operator& A = o->op;
     A.ctx = &ctx->c; A.kind = OP_DENSE; A.m = m; A.n = n; A.row0 = row0; A.mloc = m_local;
-    A.ld = m_local > 0 ? m_local : 1;
+    A.ld = m_local > 0 ? ((m_local + 15) / 16) * 16 : 16;   // padded: 16-byte aligned column starts
     A.data = Buf(ctx->c.be.get(), (size_t)A.ld * n);
     ctx->c.be->upload2d(A.data.p, A.ld, A_rows, lda, m_local, n);
     *op = o.release();
@@ -153,7 +153,7 @@ int gsi_op_lowrank(gsi_ctx* ctx, gsi_op** op, const double* samples, int64_t n, 
     std::unique_ptr<gsi_op> o(new gsi_op());
     Operator& A = o->op;
     A.ctx = &ctx->c; A.kind = OP_LOWRANK; A.m = n; A.n = n; A.row0 = row0; A.mloc = n_local; A.N = N;
-    A.ld = n_local > 0 ? n_local : 1;
+    A.ld = n_local > 0 ? ((n_local + 15) / 16) * 16 : 16;
     A.data = Buf(ctx->c.be.get(), (size_t)A.ld * N);
     ctx->c.be->upload2d(A.data.p, A.ld, samples, lds, n_local, N);
     if (center) ctx->c.be->center_rows(A.data.p, n_local, N, A.ld);   // lowrank.jl:17-27
@@ -172,7 +172,7 @@ int gsi_op_dense_gridcov(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, doub
     std::unique_ptr<gsi_op> o(new gsi_op());
     Operator& A = o->op;
     A.ctx = &ctx->c; A.kind = OP_DENSE; A.m = n; A.n = n; A.row0 = row0; A.mloc = m_local;
-    A.ld = m_local > 0 ? m_local : 1;
+    A.ld = m_local > 0 ? ((m_local + 15) / 16) * 16 : 16;
     A.data = Buf(ctx->c.be.get(), (size_t)A.ld * n);
     ctx->c.be->fill_gridcov(A.data.p, A.ld, nx, ny, ell, kind, row0, m_local);
     *op = o.release();

@@ -17,8 +17,6 @@
 
 namespace gsi { namespace hipk {
 
-constexpr int SVD_W = 16;          // columns per block
-constexpr int SVD_C = 2 * SVD_W;   // columns resident per workgroup
 constexpr int SVD_THREADS = 256;   // 4 waves; a 16-lane quarter wave per column pair of an inner round
 
 // round-robin ("circle") tournament on n (even) players: pair q of round r
@@ -42,11 +40,13 @@ __device__ inline double quarter_allsum(double v) {
   return v;
 }
 
-// grid.x = number of block pairs in this round
+// grid.x = number of block pairs in this round; SVD_W = columns per block (16, or 8 for l > 600)
+template <int SVD_W>
 __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __restrict__ G, int l, int lp,
                                                                    int nblk, int round, double tol2,
                                                                    int32_t* __restrict__ rotcount,
                                                                    int inner_sweeps) {
+  constexpr int SVD_C = 2 * SVD_W;   // columns resident per workgroup
   extern __shared__ double cols[];  // [SVD_C][lp] followed by one int slot (single LDS object)
   int& s_rot = *reinterpret_cast<int*>(cols + SVD_C * lp);
   const int tid = threadIdx.x;
@@ -68,7 +68,9 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   for (int sw = 0; sw < inner_sweeps; ++sw) {
     for (int r = 0; r < SVD_C - 1; ++r) {
       int p, q;
-      rr_pair(SVD_C, r, 4 * wave + quarter, &p, &q);
+      const int pairidx = 4 * wave + quarter;
+      const bool active = pairidx < SVD_C / 2;
+      rr_pair(SVD_C, r, active ? pairidx : 0, &p, &q);
       double* gp = cols + p * lp;
       double* gq = cols + q * lp;
       double a = 0.0, b = 0.0, c = 0.0;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
         a += x * x; b += y * y; c += x * y;
       }
       a = quarter_allsum(a); b = quarter_allsum(b); c = quarter_allsum(c);
-      if (a > 0.0 && b > 0.0 && c * c > tol2 * (a * b)) {
+      if (active && a > 0.0 && b > 0.0 && c * c > tol2 * (a * b)) {
         // Rutishauser rotation, t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (b-a)/(2c),
         // rewritten as t = sign(d*e) |e| / (|d| + hypot(d, e)).  The angle only has to be approximately
         // optimal -- what must hold to fp64 rounding is cs^2 + sn^2 = 1 -- so t comes from the
@@ -137,8 +139,9 @@ __global__ void jacobi_finish_kernel(const double* __restrict__ G, int l, const 
   if (threadIdx.x == 0) S[rank] = nc;
 }
 
-int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, const SvdWork& w) {
-  const int l = (int)l64;
+template <int SVD_W>
+static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S, const SvdWork& w) {
+  constexpr int SVD_C = 2 * SVD_W;
   int lp = l;   // column stride (doubles): lp % 32 == 16 spreads the quarter waves of a 32-lane group over both bank halves
   while ((lp & 31) != 16) ++lp;
   int nblk = (l + SVD_W - 1) / SVD_W;
@@ -147,8 +150,8 @@ int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, cons
   const size_t shmem = (size_t)SVD_C * lp * sizeof(double) + 16;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)jacobi_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024 - 64);
+    (void)hipFuncSetAttribute((const void*)jacobi_block_kernel<SVD_W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024 - 64);
     attr_set = true;
   }
   const double tol = sqrt((double)l) * DBL_EPSILON;
@@ -158,11 +161,11 @@ int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, cons
   for (; sweeps < max_sweeps; ++sweeps) {
     hipMemsetAsync(w.rotcount, 0, sizeof(int32_t), st);
     if (nblk == 2) {
-      hipLaunchKernelGGL(jacobi_block_kernel, dim3(1), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk, 0, tol2,
+      hipLaunchKernelGGL(jacobi_block_kernel<SVD_W>, dim3(1), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk, 0, tol2,
                          w.rotcount, 2);
     } else {
       for (int r = 0; r < nblk - 1; ++r)
-        hipLaunchKernelGGL(jacobi_block_kernel, dim3(nblk / 2), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk,
+        hipLaunchKernelGGL(jacobi_block_kernel<SVD_W>, dim3(nblk / 2), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk,
                            r, tol2, w.rotcount, 1);
     }
     int32_t rot = 0;
@@ -173,6 +176,13 @@ int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, cons
   hipLaunchKernelGGL(jacobi_norms_kernel, dim3((l + 3) / 4), dim3(256), 0, st, G, l, w.norms);
   hipLaunchKernelGGL(jacobi_finish_kernel, dim3(l), dim3(64), 0, st, G, l, w.norms, U, S);
   return sweeps;
+}
+
+// 32 resident columns per workgroup up to l = 600, 16 beyond (LDS: columns x (l padded) x 8 B <= 160 KB)
+int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, const SvdWork& w) {
+  const int l = (int)l64;
+  if (l <= 600) return svd_small_impl<16>(st, G, l, U, S, w);
+  return svd_small_impl<8>(st, G, l, U, S, w);
 }
 
 }}  // namespace gsi::hipk

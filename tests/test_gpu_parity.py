@@ -402,3 +402,29 @@ def test_qr_rank_deficient_falls_back(gsi, ctx):
     assert after["householder"] - before["householder"] == 1
     assert np.abs(Q.T @ Q - np.eye(40)).max() < 1e-13
     assert np.linalg.norm(Y - Q @ (Q.T @ Y)) < 1e-11 * np.linalg.norm(Y)
+
+
+# ---- wide sketches: column chunking of the contraction kernel (l > 160) and the larger Jacobi problem --------
+@pytest.mark.parametrize("n,K,p,q", [(1500, 200, 120, 1), (1200, 300, 212, 2)])
+def test_randsvd_wide_sketch(gsi, ctx, n, K, p, q):
+    rng = np.random.default_rng(n + K)
+    B = rng.standard_normal((n, n)) / np.sqrt(n)
+    A = B @ np.diag(np.logspace(0, -3, n)) @ B.T          # SPD, slowly decaying spectrum
+    Omega = rng.standard_normal((n, K + p))
+    Z, S = gsi.randsvd(A, K, p, q, Omega=Omega, return_S=True)
+    Zref, Sref, _ = orc.randsvd_full(A, K, p, q, Omega)
+    assert rel_sv_err(S, Sref, K) < 1e-9
+    assert np.linalg.norm(Z @ Z.T - Zref @ Zref.T) < 1e-8 * np.linalg.norm(Zref @ Zref.T)
+
+
+def test_unaligned_sizes(gsi, ctx):
+    """odd n / odd l: every load goes through the element-wise predicated path."""
+    rng = np.random.default_rng(77)
+    n, K, p, q = 1237, 37, 12, 2
+    B = rng.standard_normal((n, 300))
+    A = B @ B.T / 300
+    Omega = rng.standard_normal((n, K + p))
+    Z, S = gsi.randsvd(A, K, p, q, Omega=Omega, return_S=True)
+    Zref, Sref, _ = orc.randsvd_full(A, K, p, q, Omega)
+    assert rel_sv_err(S, Sref, K) < 1e-9
+    assert orc.xis_error_up_to_sign(Z, Zref, K) < 1e-6
