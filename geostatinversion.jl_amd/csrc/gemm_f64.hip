@@ -129,7 +129,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     if (wide && wg_full && k0 + BK <= kend) {
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it)
-        a_reg[set][it] = *reinterpret_cast<const double2*>(Ab + (a_off0 + (uint32_t)it * a_step));
+        {   // A is streamed once: non-temporal, to keep it out of the way of the X tiles in L2
+          typedef double nt_double2 __attribute__((ext_vector_type(2)));
+          const nt_double2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_double2*>(Ab + (a_off0 + (uint32_t)it * a_step)));
+          a_reg[set][it].x = v.x; a_reg[set][it].y = v.y;
+        }
 #pragma unroll
       for (int it = 0; it < B_PAIRS; ++it)
         if (!B_RAGGED || b_c + RSTEP * it < NT * 16)
