@@ -55,6 +55,7 @@ class HipBackend : public Backend {
     hipSetDevice(device_);
     hipStreamSynchronize(st_);
     for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_}) if (b->p) hipFree(b->p);
+    for (auto& b : pool_) hipFree(b.p);
     for (auto& ev : ev_pool_) hipEventDestroy(ev);
     for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     hipFree(flags_);
@@ -66,39 +67,80 @@ class HipBackend : public Backend {
   void bind() { hipSetDevice(device_); }
 
   // ---- memory ----
+  // Panel-sized temporaries come and go inside every entry point; everything is ordered on the one
+  // stream, so a released block can be handed to the next request without synchronising or going back
+  // to hipFree/hipMalloc.  Exact-size free lists (the sizes repeat from call to call), trimmed when the
+  // cache exceeds half of what is in use.
   double* alloc(size_t count) override {
     bind();
-    void* p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc(&p, count * sizeof(double));
+    const size_t bytes = count * sizeof(double);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (size_t i = 0; i < pool_.size(); ++i)
+        if (pool_[i].bytes == bytes) {
+          void* p = pool_[i].p;
+          pool_[i] = pool_.back();
+          pool_.pop_back();
+          pooled_ -= (int64_t)bytes;
+          sizes_.push_back({p, bytes});
+          in_use_ += (int64_t)bytes;
+          return (double*)p;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {   // give the cache back and retry once
+      (void)hipGetLastError();
+      trim_pool(0);
+      e = hipMalloc(&p, bytes);
+    }
     if (e != hipSuccess) {
       (void)hipGetLastError();
-      throw Error(GSI_ERR_OOM, "hipMalloc of " + std::to_string(count * sizeof(double)) + " bytes failed: " +
-                                   hipGetErrorString(e));
+      throw Error(GSI_ERR_OOM, "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
     }
     std::lock_guard<std::mutex> g(mu_);
-    sizes_.push_back({p, count * sizeof(double)});
-    in_use_ += (int64_t)(count * sizeof(double));
+    sizes_.push_back({p, bytes});
+    in_use_ += (int64_t)bytes;
     return (double*)p;
   }
   void release(double* p) override {
     if (!p) return;
     bind();
-    hipStreamSynchronize(st_);
+    size_t bytes = 0;
     {
       std::lock_guard<std::mutex> g(mu_);
       for (size_t i = 0; i < sizes_.size(); ++i)
         if (sizes_[i].p == p) {
-          in_use_ -= (int64_t)sizes_[i].bytes;
+          bytes = sizes_[i].bytes;
+          in_use_ -= (int64_t)bytes;
           sizes_[i] = sizes_.back();
           sizes_.pop_back();
           break;
         }
+      if (bytes != 0 && bytes <= ((size_t)8 << 30)) {   // operators (tens of GB) are not worth caching
+        pool_.push_back({p, bytes});
+        pooled_ += (int64_t)bytes;
+        p = nullptr;
+      }
     }
-    hipFree(p);
+    if (p) {
+      hipStreamSynchronize(st_);
+      hipFree(p);
+    }
+    if (pooled_ > ((int64_t)4 << 30) && pooled_ > in_use_ / 2) trim_pool(in_use_ / 4);
+  }
+  void trim_pool(int64_t keep_bytes) {
+    hipStreamSynchronize(st_);
+    std::lock_guard<std::mutex> g(mu_);
+    while (!pool_.empty() && pooled_ > keep_bytes) {
+      hipFree(pool_.back().p);
+      pooled_ -= (int64_t)pool_.back().bytes;
+      pool_.pop_back();
+    }
   }
   int64_t bytes_in_use() const override {
-    return in_use_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes);
+    return in_use_ + pooled_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes);
   }
   void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) override {
     if (rows <= 0 || cols <= 0) return;
@@ -372,7 +414,8 @@ class HipBackend : public Backend {
   DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_;
   std::mutex mu_;
   std::vector<DevBuf> sizes_;
-  int64_t in_use_ = 0;
+  std::vector<DevBuf> pool_;
+  int64_t in_use_ = 0, pooled_ = 0;
   bool prof_ = false;
   Rec cur_{};
   std::vector<Rec> records_;
