@@ -64,6 +64,21 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
   const int64_t jp = j - 1;
   int64_t r = -1;
   double rpiv = 0.0;
+  // Issue this thread's first row loads before the reduction prologue: they do not depend on the pivot
+  // (the one row that does -- the pivot's old position -- is replaced from s_old below), and the
+  // prologue is a chain of dependent global/LDS latencies that would otherwise sit in front of them.
+  const int64_t base = j + (int64_t)blockIdx.x * 256 * rows_per_thread;
+  double pre_x0 = 0.0;
+  double pre_a[LU_LEAF];
+  {
+    const int64_t i0 = base + tid;
+    if (i0 < m) {
+      const double* row0 = Y + i0;
+      if (do_update) pre_x0 = row0[jp * ld];
+#pragma unroll
+      for (int k = 0; k < LU_LEAF; ++k) pre_a[k] = (k < nlive) ? row0[(j + k) * ld] : 0.0;
+    }
+  }
   if (do_update) {
     // (1) redundant, fixed-order reduction of the previous column's partial arg-maxes
     double best = -1.0;
@@ -119,7 +134,6 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
   double besta[LU_LEAF];
 #pragma unroll
   for (int k = 0; k < LU_LEAF; ++k) besta[k] = 0.0;
-  const int64_t base = j + (int64_t)blockIdx.x * 256 * rows_per_thread;
   for (int rr = 0; rr < rows_per_thread; ++rr) {
     const int64_t i = base + tid + 256 * (int64_t)rr;
     if (i < m) {
@@ -127,13 +141,13 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
       double a[LU_LEAF];
       if (do_update) {
         const bool moved = (i == r);           // this position receives the old row j-1
-        const double x0 = moved ? s_old[0] : row[jp * ld];
+        const double x0 = moved ? s_old[0] : (rr == 0 ? pre_x0 : row[jp * ld]);
         const double lij = (rpiv != 0.0) ? x0 * rpiv : x0;
         row[jp * ld] = lij;
 #pragma unroll
         for (int k = 0; k < LU_LEAF; ++k) {
           if (k < nlive) {
-            const double xk = moved ? s_old[1 + k] : row[(j + k) * ld];
+            const double xk = moved ? s_old[1 + k] : (rr == 0 ? pre_a[k] : row[(j + k) * ld]);
             a[k] = xk - lij * s_u[1 + k];
             row[(j + k) * ld] = a[k];
           }
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
       } else {
 #pragma unroll
         for (int k = 0; k < LU_LEAF; ++k)
-          if (k < nlive) a[k] = row[(j + k) * ld];
+          if (k < nlive) a[k] = (rr == 0) ? pre_a[k] : row[(j + k) * ld];
       }
       if (do_argmax) {
         if (i == j) {
