@@ -15,12 +15,13 @@ from .context import Context, Operator, DeviceMatrix, dense_operator, gridcov_op
 from . import randmatfact as RandMatFact
 from .randmatfact import rangefinder, randsvd, eig_nystrom, colnorms, lu_L, qr_thinQ, svd_tall, gemm
 from .lowrank import LowRankCovMatrix, PCGALowRankMatrix
-from .getxis import getxis, getxis_iwantfields, randsvdwithseed
-from .pcga import pcgadirect, pcgalsqr, rga, pcga
+from .getxis import getxis, getxis_iwantfields, getxis_device, randsvdwithseed
+from .pcga import pcgadirect, pcgalsqr, rga, pcga, DeviceBasis
 
 __all__ = [
     "GsiError", "load", "LIB_PATH", "Context", "Operator", "DeviceMatrix", "dense_operator",
     "gridcov_operator", "default_context", "RandMatFact", "rangefinder", "randsvd", "eig_nystrom",
     "colnorms", "lu_L", "qr_thinQ", "svd_tall", "gemm", "LowRankCovMatrix", "PCGALowRankMatrix",
-    "getxis", "getxis_iwantfields", "randsvdwithseed", "pcgadirect", "pcgalsqr", "rga", "pcga",
+    "getxis", "getxis_iwantfields", "getxis_device", "randsvdwithseed", "pcgadirect", "pcgalsqr", "rga", "pcga",
+    "DeviceBasis",
 ]

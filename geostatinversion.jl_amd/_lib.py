@@ -58,6 +58,9 @@ SIGNATURES = {
     "gsi_gemm": (C.c_int, [c_vp, C.c_int, c_i64, c_i64, c_i64, C.c_double, c_dp, c_i64, c_dp, c_i64, c_dp, c_i64]),
     "gsi_pcga_params": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_dp, c_dp, C.c_double, c_dp]),
     "gsi_pcga_update": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_dp, C.c_double, c_dp, c_i64, c_dp, c_dp]),
+    "gsi_pcga_params_dev": (C.c_int, [c_vp, c_vp, c_i64, c_dp, c_dp, C.c_double, c_dp]),
+    "gsi_pcga_update_dev": (C.c_int, [c_vp, c_vp, c_i64, c_dp, C.c_double, c_dp, c_i64, c_dp, c_dp]),
+    "gsi_mat_download_col": (C.c_int, [c_vp, c_vp, c_i64, c_dp]),
     "gsi_ctx_profile": (C.c_int, [c_vp, C.c_int]),
     "gsi_ctx_phase_reset": (C.c_int, [c_vp]),
     "gsi_ctx_phase_times": (C.c_int, [c_vp, c_dp, C.POINTER(c_i64)]),

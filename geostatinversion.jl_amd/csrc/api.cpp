@@ -439,25 +439,38 @@ int gsi_gemm(gsi_ctx* ctx, int trans, int64_t m, int64_t l, int64_t k, double al
 }
 
 // ---- consumers -----------------------------------------------------------------------
+namespace {
+void pcga_params_impl(Context& c, const double* Zdev, int64_t n, int64_t K, const double* s, const double* X,
+                      double delta, double* out) {
+  Backend* be = c.be.get();
+  Buf O(be, (size_t)n * (K + 3)), sv(be, (size_t)n), Xv(be, (size_t)n);
+  be->upload2d(sv.p, n, s, n, n, 1);
+  be->upload2d(Xv.p, n, X, n, n, 1);
+  be->pcga_params(Zdev, n, K, sv.p, Xv.p, delta, O.p);           // direct.jl:39-45 / lsqr.jl:37-43
+  be->download2d(out, n, O.p, n, n, K + 3);
+}
+void pcga_update_impl(Context& c, const double* Zdev, int64_t n, int64_t K, const double* X, double beta_bar,
+                      const double* etas, int64_t nobs, const double* xi_bar, double* s_out) {
+  Backend* be = c.be.get();
+  Buf E(be, (size_t)nobs * K), xb(be, (size_t)nobs), w(be, (size_t)K), sd(be, (size_t)n), Xd(be, (size_t)n);
+  be->upload2d(E.p, nobs, etas, nobs, nobs, K);
+  be->upload2d(xb.p, nobs, xi_bar, nobs, nobs, 1);
+  be->upload2d(Xd.p, n, X, n, n, 1);
+  be->gemm_tn(K, 1, nobs, 1.0, E.p, nobs, xb.p, nobs, 0.0, w.p, K);     // w_i = dot(eta_i, xi_bar)
+  be->scal_copy(n, beta_bar, Xd.p, sd.p);                               // s = X * beta_bar      direct.jl:61
+  be->gemm_nn(n, 1, K, 1.0, Zdev, n, w.p, K, 1.0, sd.p, n);             // s += sum_i xis[i]*w_i  direct.jl:62-65
+  be->download2d(s_out, n, sd.p, n, n, 1);
+}
+}  // namespace
+
 int gsi_pcga_params(gsi_ctx* ctx, const double* Z, int64_t n, int64_t K, const double* s, const double* X,
                     double delta, double* out) {
   return guarded([&] {
     REQUIRE(ctx && Z && s && X && out, "NULL argument");
     REQUIRE(n >= 1 && K >= 1, "bad shape");
-    Backend* be = ctx->c.be.get();
-    // out[:, i] = s + delta * col_i,  cols = [Z, X, s, 0]   as one rank-1-plus-scale product:
-    // built from the gemm kernel: out = [Z X s 0] * delta + s * ones'
-    Buf M(be, (size_t)n * (K + 3)), O(be, (size_t)n * (K + 3)), sv(be, (size_t)n);
-    be->upload2d(M.p, n, Z, n, n, K);
-    be->upload2d(M.p + (size_t)n * K, n, X, n, n, 1);
-    be->upload2d(M.p + (size_t)n * (K + 1), n, s, n, n, 1);
-    be->fill_zero(M.p + (size_t)n * (K + 2), (size_t)n);
-    be->upload2d(sv.p, n, s, n, n, 1);
-    for (int64_t c = 0; c < K + 3; ++c) {
-      be->scal_copy(n, 1.0, sv.p, O.p + (size_t)n * c);
-      be->axpy(n, delta, M.p + (size_t)n * c, O.p + (size_t)n * c);
-    }
-    be->download2d(out, n, O.p, n, n, K + 3);
+    Buf Zd(ctx->c.be.get(), (size_t)n * K);
+    ctx->c.be->upload2d(Zd.p, n, Z, n, n, K);
+    pcga_params_impl(ctx->c, Zd.p, n, K, s, X, delta, out);
   });
 }
 
@@ -466,17 +479,35 @@ int gsi_pcga_update(gsi_ctx* ctx, const double* Z, int64_t n, int64_t K, const d
   return guarded([&] {
     REQUIRE(ctx && Z && X && etas && xi_bar && s_out, "NULL argument");
     REQUIRE(n >= 1 && K >= 1 && nobs >= 1, "bad shape");
-    Backend* be = ctx->c.be.get();
-    Buf Zd(be, (size_t)n * K), E(be, (size_t)nobs * K), xb(be, (size_t)nobs), w(be, (size_t)K), sd(be, (size_t)n),
-        Xd(be, (size_t)n);
-    be->upload2d(Zd.p, n, Z, n, n, K);
-    be->upload2d(E.p, nobs, etas, nobs, nobs, K);
-    be->upload2d(xb.p, nobs, xi_bar, nobs, nobs, 1);
-    be->upload2d(Xd.p, n, X, n, n, 1);
-    be->gemm_tn(K, 1, nobs, 1.0, E.p, nobs, xb.p, nobs, 0.0, w.p, K);   // w_i = dot(eta_i, xi_bar)
-    be->scal_copy(n, beta_bar, Xd.p, sd.p);                             // s = X * beta_bar
-    be->gemm_nn(n, 1, K, 1.0, Zd.p, n, w.p, K, 1.0, sd.p, n);           // s += sum_i xis[i] * w_i
-    be->download2d(s_out, n, sd.p, n, n, 1);
+    Buf Zd(ctx->c.be.get(), (size_t)n * K);
+    ctx->c.be->upload2d(Zd.p, n, Z, n, n, K);
+    pcga_update_impl(ctx->c, Zd.p, n, K, X, beta_bar, etas, nobs, xi_bar, s_out);
+  });
+}
+
+int gsi_pcga_params_dev(gsi_ctx* ctx, const gsi_mat* basis, int64_t K, const double* s, const double* X,
+                        double delta, double* out) {
+  return guarded([&] {
+    REQUIRE(ctx && basis && s && X && out, "NULL argument");
+    REQUIRE(basis->ctx == ctx && K >= 1 && K <= basis->cols, "bad basis / K");
+    pcga_params_impl(ctx->c, basis->buf.p, basis->rows, K, s, X, delta, out);
+  });
+}
+
+int gsi_pcga_update_dev(gsi_ctx* ctx, const gsi_mat* basis, int64_t K, const double* X, double beta_bar,
+                        const double* etas, int64_t nobs, const double* xi_bar, double* s_out) {
+  return guarded([&] {
+    REQUIRE(ctx && basis && X && etas && xi_bar && s_out, "NULL argument");
+    REQUIRE(basis->ctx == ctx && K >= 1 && K <= basis->cols && nobs >= 1, "bad basis / K / nobs");
+    pcga_update_impl(ctx->c, basis->buf.p, basis->rows, K, X, beta_bar, etas, nobs, xi_bar, s_out);
+  });
+}
+
+int gsi_mat_download_col(gsi_ctx* ctx, const gsi_mat* mat, int64_t col, double* host) {
+  return guarded([&] {
+    REQUIRE(ctx && mat && host && mat->ctx == ctx, "bad argument");
+    REQUIRE(col >= 0 && col < mat->cols, "column out of range");
+    ctx->c.be->download2d(host, mat->rows, mat->buf.p + (size_t)col * mat->rows, mat->rows, mat->rows, 1);
   });
 }
 

@@ -78,6 +78,9 @@ class Backend {
   virtual double dot(int64_t n, const double* x, const double* y) = 0;
   virtual double nrm2(int64_t n, const double* x) = 0;
   virtual void scal_copy(int64_t n, double a, const double* x, double* y) = 0;  // y = a*x
+  // out (n x (K+3)) = [s + delta*Z[:,i] (i<K), s + delta*X, s + delta*s, s]   direct.jl:39-45
+  virtual void pcga_params(const double* Z, int64_t n, int64_t K, const double* s, const double* X, double delta,
+                           double* out) = 0;
 
   // error flags raised asynchronously by kernels (zero pivot, non-posdef); checked and
   // cleared by the pipeline at the end of each entry point. Returns GSI_* code or 0.

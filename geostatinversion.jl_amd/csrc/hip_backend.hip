@@ -319,6 +319,12 @@ class HipBackend : public Backend {
     bind();
     hipk::scal_copy(st_, n, a, x, y);
   }
+  void pcga_params(const double* Z, int64_t n, int64_t K, const double* s, const double* X, double delta,
+                   double* out) override {
+    bind();
+    hipk::pcga_params(st_, Z, n, K, s, X, delta, out);
+    check_launch("pcga_params");
+  }
 
   int take_error(std::string* msg) override {
     bind();

@@ -41,3 +41,35 @@ def getxis(first, *args, **kwargs):
 def _getxis_matrix(Q, numxis, p, q=3, seed=None, *, Omega=None):
     Z = randsvdwithseed(Q, numxis, p, q, seed, Omega=Omega)     # :65
     return [np.ascontiguousarray(Z[:, i]) for i in range(numxis)]   # :66-68
+
+
+def getxis_device(Q, numxis, p, q=3, seed=None, *, Omega=None, ctx=None):
+    """`getxis` whose result stays in HBM: returns a `DeviceBasis` usable wherever the
+    reference takes `xis` (`pcgadirect`, `pcgalsqr`, `rga`).  Q: a matrix, a `LowRankCovMatrix` or a device
+    `Operator`."""
+    import ctypes as C
+    from . import _lib as L
+    from .context import DeviceMatrix, Operator, dense_operator, default_context
+    from .pcga import DeviceBasis
+    if seed is not None:
+        RMF.seed(int(seed))
+    owned = False
+    if isinstance(Q, Operator):
+        op = Q
+    elif hasattr(Q, "_device_operator"):
+        op = Q._device_operator(ctx)
+    else:
+        op, owned = dense_operator(ctx or default_context(), Q), True
+    try:
+        cx = op.ctx
+        m, n = op.shape
+        l = int(numxis) + int(p)
+        Om = RMF.randn(n, l) if Omega is None else Omega
+        Omd = DeviceMatrix.from_host(cx, Om)
+        Z = DeviceMatrix(cx, n, l)
+        L.check(cx.lib.gsi_randsvd_dev(cx.h, op.h, Omd.h, int(numxis), int(p), int(q), Z.h, None), cx.lib)
+        Omd.close()
+        return DeviceBasis(Z, numxis)
+    finally:
+        if owned:
+            op.close()

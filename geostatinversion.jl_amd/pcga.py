@@ -77,8 +77,52 @@ def _lsqr(matvec, b, maxiter=None):
     return x
 
 
+class DeviceBasis:
+    """The xi-basis resident in HBM: the n x (K+p) matrix Z a device-side randsvd left
+    there; `xis[i]` is its column i.  Pass it to `pcgadirect` / `pcgalsqr` / `rga` in place of the
+    reference's `xis::Array{Array{Float64,1},1}`: the basis then crosses PCIe never (only the n x (K+3)
+    perturbation batch and the updated s do, because the forward model is host code)."""
+
+    def __init__(self, Zmat, K):
+        self.Zmat = Zmat
+        self.ctx = Zmat.ctx
+        self.n = Zmat.shape[0]
+        self.K = int(K)
+        if not 1 <= self.K <= Zmat.shape[1]:
+            raise ValueError("K out of range for this basis")
+
+    def __len__(self):
+        return self.K
+
+    def __getitem__(self, i):
+        """xis[i] on the host (one column)."""
+        if not 0 <= i < self.K:
+            raise IndexError(i)
+        out = np.empty(self.n)
+        L.check(self.ctx.lib.gsi_mat_download_col(self.ctx.h, self.Zmat.h, i, out.ctypes.data_as(L.c_dp)), self.ctx.lib)
+        return out
+
+    def params(self, s, X, delta):
+        out = np.empty((self.n, self.K + 3), order="F")
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        L.check(self.ctx.lib.gsi_pcga_params_dev(self.ctx.h, self.Zmat.h, self.K, s.ctypes.data_as(L.c_dp),
+                                                 X.ctypes.data_as(L.c_dp), float(delta), L.dptr(out)), self.ctx.lib)
+        return out
+
+    def update(self, X, beta_bar, etas, xi_bar):
+        E = np.asfortranarray(np.stack(etas, axis=1))
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        xb = np.ascontiguousarray(xi_bar, dtype=np.float64)
+        out = np.empty(self.n)
+        L.check(self.ctx.lib.gsi_pcga_update_dev(self.ctx.h, self.Zmat.h, self.K, X.ctypes.data_as(L.c_dp),
+                                                 float(beta_bar), L.dptr(E), E.shape[0], xb.ctypes.data_as(L.c_dp),
+                                                 out.ctypes.data_as(L.c_dp)), self.ctx.lib)
+        return out
+
+
 class _Basis:
-    """xis as one n x K column-major block for the device kernels."""
+    """xis given on the host (the reference's Vector{Vector{Float64}}) as one n x K column-major block."""
 
     def __init__(self, xis, ctx):
         self.ctx = ctx or default_context()
@@ -106,6 +150,10 @@ class _Basis:
         return out
 
 
+def _as_basis(xis, ctx):
+    return xis if isinstance(xis, DeviceBasis) else _Basis(xis, ctx)
+
+
 def _iteration_head(forwardmodel, basis, s, X, delta):
     """direct.jl:38-46 / lsqr.jl:36-51."""
     K = basis.K
@@ -122,7 +170,7 @@ def pcgadirect(forwardmodel, s0, X, xis, R, y, *, maxiters=5, delta=SQRT_EPS, xt
                callback=lambda s, obs_cal: None, ctx=None):
     """`pcgadirect(forwardmodel, s0, X, xis, R, y; maxiters=5, delta=sqrt(eps), xtol=1e-6, callback)`
     (direct.jl:21-67)."""
-    basis = _Basis(xis, ctx)
+    basis = _as_basis(xis, ctx)
     s = np.asarray(s0, dtype=np.float64)
     X = np.asarray(X, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
@@ -147,7 +195,7 @@ def pcgadirect(forwardmodel, s0, X, xis, R, y, *, maxiters=5, delta=SQRT_EPS, xt
 def pcgalsqr(forwardmodel, s0, X, xis, R, y, *, maxiters=5, delta=SQRT_EPS, xtol=1e-6, ctx=None):
     """`pcgalsqr(forwardmodel, s0, X, xis, R, y; maxiters=5, delta=sqrt(eps), xtol=1e-6)`
     (lsqr.jl:20-63).  No `callback` keyword, as in the reference."""
-    basis = _Basis(xis, ctx)
+    basis = _as_basis(xis, ctx)
     s = np.asarray(s0, dtype=np.float64)
     X = np.asarray(X, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)

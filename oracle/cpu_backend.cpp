@@ -122,6 +122,14 @@ class CpuBackend : public Backend {
   double dot(int64_t n, const double* x, const double* y) override { double s = 0; for (int64_t i = 0; i < n; ++i) s += x[i] * y[i]; return s; }
   double nrm2(int64_t n, const double* x) override { return std::sqrt(dot(n, x, x)); }
   void scal_copy(int64_t n, double a, const double* x, double* y) override { for (int64_t i = 0; i < n; ++i) y[i] = a * x[i]; }
+  void pcga_params(const double* Z, int64_t n, int64_t K, const double* s, const double* X, double delta,
+                   double* out) override {
+    for (int64_t c = 0; c < K + 3; ++c)
+      for (int64_t i = 0; i < n; ++i) {
+        const double d = c < K ? Z[i + c * n] : (c == K ? X[i] : (c == K + 1 ? s[i] : 0.0));
+        out[i + c * n] = s[i] + delta * d;
+      }
+  }
   int take_error(std::string* msg) override {
     if (lu_info_) {
       if (msg) *msg = "SingularException(" + std::to_string(lu_info_) + "): exactly zero pivot in lu()";

@@ -127,3 +127,33 @@ def test_pcga_consumers(gsi, cx):
     assert np.linalg.norm(got - ref) < 1e-6 * np.linalg.norm(ref)
     got = gsi.pcgalsqr(forward, X.copy(), X, xis, R, y, ctx=cx)
     assert np.linalg.norm(got - truep) / np.linalg.norm(truep) < 2e-2
+
+
+def test_device_resident_basis(gsi, cx):
+    """the xi-basis stays on the device between getxis and the PCGA iterations."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(41)
+    M, N, mu = 8, 96, 3.0
+    x = rng.standard_normal(N)
+    Q0 = rng.standard_normal((M, N))
+    Qc = Q0.T @ Q0
+    w, V = np.linalg.eigh(Qc)
+    truep = (V * np.sqrt(np.clip(w, 0, None))) @ V.T @ rng.standard_normal(N) + mu
+    forward = lambda pv: pv * x
+    Om = rng.standard_normal((N, M + 1))
+    basis = gsi.getxis_device(Qc, M, 1, 3, Omega=Om, ctx=cx)
+    xis_host = gsi.getxis(Qc, M, 1, 3, Omega=Om) if False else [basis[i] for i in range(M)]
+    Zref = orc.randsvd(Qc, M, 1, 3, Om)
+    assert orc.xis_error_up_to_sign(np.stack(xis_host, axis=1), Zref, M) < 1e-6
+    X = np.full(N, mu)
+    R = 1e-8 * sp.identity(N, format="csc")
+    y = forward(truep) + 1e-4 * rng.standard_normal(N)
+    got_dev = gsi.pcgadirect(forward, X.copy(), X, basis, R, y)
+    got_host = gsi.pcgadirect(forward, X.copy(), X, xis_host, R, y, ctx=cx)
+    assert np.linalg.norm(got_dev - got_host) < 1e-9 * np.linalg.norm(got_host)
+    assert np.linalg.norm(got_dev - truep) / np.linalg.norm(truep) < 2e-2
+    got_lsqr = gsi.pcgalsqr(forward, X.copy(), X, basis, R, y)
+    assert np.linalg.norm(got_lsqr - truep) / np.linalg.norm(truep) < 2e-2
+    S = rng.standard_normal((48, N)) / np.sqrt(N)
+    got_rga = gsi.rga(forward, X.copy(), X, basis, R, y, S)
+    assert got_rga.shape == (N,)

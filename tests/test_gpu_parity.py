@@ -428,3 +428,29 @@ def test_unaligned_sizes(gsi, ctx):
     Zref, Sref, _ = orc.randsvd_full(A, K, p, q, Omega)
     assert rel_sv_err(S, Sref, K) < 1e-9
     assert orc.xis_error_up_to_sign(Z, Zref, K) < 1e-6
+
+
+def test_device_resident_basis_gpu(gsi, ctx):
+    """SURVEY.md 8f (f1) on the GPU: getxis_device -> DeviceBasis -> pcgadirect / pcgalsqr."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(43)
+    M, N, mu = 16, 512, 10.0
+    x = rng.standard_normal(N)
+    Q0 = rng.standard_normal((M, N))
+    Qc = Q0.T @ Q0
+    w, V = np.linalg.eigh(Qc)
+    truep = (V * np.sqrt(np.clip(w, 0, None))) @ V.T @ rng.standard_normal(N) + mu
+    forward = lambda pv: pv * x
+    Om = rng.standard_normal((N, M + 2))
+    basis = gsi.getxis_device(Qc, M, 2, 3, Omega=Om)
+    xis_ref = orc.getxis_dense(Qc, M, 2, 3, Om)
+    assert orc.xis_error_up_to_sign(np.stack([basis[i] for i in range(M)], axis=1), np.stack(xis_ref, axis=1), M) < 1e-6
+    X = np.full(N, mu)
+    R = 1e-8 * sp.identity(N, format="csc")
+    y = forward(truep) + 1e-4 * rng.standard_normal(N)
+    got = gsi.pcgadirect(forward, X.copy(), X, basis, R, y)
+    ref = orc.pcgadirect(forward, X.copy(), X, xis_ref, R, y)
+    assert np.linalg.norm(got - ref) < 1e-6 * np.linalg.norm(ref)
+    assert np.linalg.norm(got - truep) / np.linalg.norm(truep) < 2e-2
+    got = gsi.pcgalsqr(forward, X.copy(), X, basis, R, y)
+    assert np.linalg.norm(got - truep) / np.linalg.norm(truep) < 2e-2
