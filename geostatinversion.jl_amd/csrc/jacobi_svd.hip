@@ -45,7 +45,7 @@ template <int SVD_W>
 __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __restrict__ G, int l, int lp,
                                                                    int nblk, int round, double tol2,
                                                                    int32_t* __restrict__ rotcount,
-                                                                   int inner_sweeps) {
+                                                                   int inner_sweeps, int cross_only) {
   constexpr int SVD_C = 2 * SVD_W;   // columns resident per workgroup
   extern __shared__ double cols[];  // [SVD_C][lp] followed by one int slot (single LDS object)
   int& s_rot = *reinterpret_cast<int*>(cols + SVD_C * lp);
@@ -66,11 +66,16 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   __syncthreads();
   int rots = 0;
   for (int sw = 0; sw < inner_sweeps; ++sw) {
-    for (int r = 0; r < SVD_C - 1; ++r) {
+    // cross_only: only pairs (column of block a, column of block b) -- SVD_W rounds of a bipartite
+    // tournament; otherwise all pairs of the 2*SVD_W resident columns (2*SVD_W - 1 rounds).  The pairs
+    // inside a block are swept once per sweep (round 0), not once per block pairing.
+    const int nrounds = cross_only ? SVD_W : SVD_C - 1;
+    for (int r = 0; r < nrounds; ++r) {
       int p, q;
       const int pairidx = 4 * wave + quarter;
       const bool active = pairidx < SVD_C / 2;
-      rr_pair(SVD_C, r, active ? pairidx : 0, &p, &q);
+      if (cross_only) { p = active ? pairidx : 0; q = SVD_W + (p + r) % SVD_W; }
+      else rr_pair(SVD_C, r, active ? pairidx : 0, &p, &q);
       double* gp = cols + p * lp;
       double* gq = cols + q * lp;
       double a = 0.0, b = 0.0, c = 0.0;
@@ -162,11 +167,11 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
     hipMemsetAsync(w.rotcount, 0, sizeof(int32_t), st);
     if (nblk == 2) {
       hipLaunchKernelGGL(jacobi_block_kernel<SVD_W>, dim3(1), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk, 0, tol2,
-                         w.rotcount, 2);
+                         w.rotcount, 2, 0);
     } else {
       for (int r = 0; r < nblk - 1; ++r)
         hipLaunchKernelGGL(jacobi_block_kernel<SVD_W>, dim3(nblk / 2), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk,
-                           r, tol2, w.rotcount, 1);
+                           r, tol2, w.rotcount, 1, r == 0 ? 0 : 1);
     }
     int32_t rot = 0;
     hipMemcpyAsync(&rot, w.rotcount, sizeof(int32_t), hipMemcpyDeviceToHost, st);
