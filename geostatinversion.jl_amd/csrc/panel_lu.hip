@@ -89,6 +89,14 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
       const int64_t oi = pidx_in[p];
       if (lu_better(ov, oi, best, besti)) { best = ov; besti = oi; bblk = p; }
     }
+    // speculative: every thread fetches the candidate row of ITS best workgroup and row j-1's saved
+    // values now, so these global-load latencies overlap the reduction instead of following it
+    const int nl1 = nlive + 1;
+    double spec[LU_LEAF + 1];
+#pragma unroll
+    for (int k = 0; k < LU_LEAF + 1; ++k)
+      spec[k] = (bblk >= 0 && k < nl1) ? cand_in[(int64_t)bblk * (LU_LEAF + 1) + k] : 0.0;
+    double oldv = (tid < nl1) ? rowsave_in[tid] : 0.0;
     s_val[tid] = best; s_idx[tid] = besti; s_blk[tid] = bblk;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -101,12 +109,15 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
     const int wblk = s_blk[0];
     const bool valid = (r >= jp && r < m && wblk >= 0);
     if (!valid) r = jp;   // all-NaN column: no interchange
-    const int nl1 = nlive + 1;
-    if (tid < nl1) {
-      s_old[tid] = rowsave_in[tid];
-      s_u[tid] = valid ? cand_in[(int64_t)wblk * (LU_LEAF + 1) + tid] : rowsave_in[tid];
+    if (tid < nl1) s_old[tid] = oldv;
+    if (valid && bblk == wblk) {          // the (unique) thread whose local best is the global winner
+#pragma unroll
+      for (int k = 0; k < LU_LEAF + 1; ++k)
+        if (k < nl1) s_u[k] = spec[k];
     }
     const double bestv = s_val[0];
+    __syncthreads();
+    if (!valid && tid < nl1) s_u[tid] = s_old[tid];
     __syncthreads();
     const double piv = s_u[0];
     rpiv = (piv != 0.0) ? 1.0 / piv : 0.0;
