@@ -161,6 +161,15 @@ def gridcov_operator(ctx, nx, ny, ell, kind=0):
     return Operator(ctx, h)
 
 
+def gridcov_implicit_operator(ctx, nx, ny, ell):
+    """The Gaussian grid covariance of `gridcov_operator(kind=0)` as an implicit operator: entries are
+    regenerated inside the product kernel, nothing of size n^2 is stored."""
+    row0, mloc = ctx.shard(nx * ny)
+    h = C.c_void_p()
+    L.check(ctx.lib.gsi_op_gridcov_implicit(ctx.h, C.byref(h), nx, ny, float(ell), row0, mloc), ctx.lib)
+    return Operator(ctx, h)
+
+
 class DeviceMatrix(_Handle):
     """Column-major Float64 matrix resident in HBM (`gsi_mat`)."""
     _destroy = "gsi_mat_destroy"

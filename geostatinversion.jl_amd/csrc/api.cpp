@@ -1,5 +1,6 @@
 // api.cpp -- the C ABI of include/gsi_hip.h: argument checking, host<->device staging and
 // error translation around pipeline.cpp.  No C++ exception crosses the boundary.
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -175,6 +176,28 @@ int gsi_op_dense_gridcov(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, doub
     A.ld = m_local > 0 ? ((m_local + 15) / 16) * 16 : 16;
     A.data = Buf(ctx->c.be.get(), (size_t)A.ld * n);
     ctx->c.be->fill_gridcov(A.data.p, A.ld, nx, ny, ell, kind, row0, m_local);
+    *op = o.release();
+  });
+}
+
+int gsi_op_gridcov_implicit(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, double ell, int64_t row0,
+                            int64_t m_local) {
+  return guarded([&] {
+    REQUIRE(ctx && op, "NULL argument");
+    *op = nullptr;
+    REQUIRE(nx >= 1 && ny >= 1 && ell > 0, "bad grid covariance parameters");
+    REQUIRE(nx * ny < ((int64_t)1 << 31), "implicit grid covariance: more than 2^31 points");
+    const int64_t n = nx * ny;
+    check_shard(ctx->c, n, row0, m_local);
+    std::unique_ptr<gsi_op> o(new gsi_op());
+    Operator& A = o->op;
+    A.ctx = &ctx->c; A.kind = OP_GRIDCOV_IMPLICIT; A.m = n; A.n = n; A.row0 = row0; A.mloc = m_local;
+    A.gx = nx; A.gy = ny; A.ld = 0;
+    std::vector<double> tab((size_t)(nx + ny));
+    for (int64_t d = 0; d < nx; ++d) tab[(size_t)d] = std::exp(-(double)(d * d) / (2.0 * ell * ell));
+    for (int64_t d = 0; d < ny; ++d) tab[(size_t)(nx + d)] = std::exp(-(double)(d * d) / (2.0 * ell * ell));
+    A.data = Buf(ctx->c.be.get(), tab.size());
+    ctx->c.be->upload2d(A.data.p, (int64_t)tab.size(), tab.data(), (int64_t)tab.size(), (int64_t)tab.size(), 1);
     *op = o.release();
   });
 }

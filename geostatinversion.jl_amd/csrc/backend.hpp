@@ -47,6 +47,13 @@ class Backend {
   virtual void gemm_tn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc) = 0;
 
+  // C(m x l) = G * B(k x l) for the separable grid covariance G(i, j) = ex[|x_i - x_j|] * ey[|y_i - y_j|],
+  // grid point i = (i / ny, i % ny), rows roff.., reduction indices koff..; tab = [ex (nx) | ey (ny)].
+  // G is generated, never stored (the "implicit" operator).
+  virtual void gemm_nn_gridcov(int64_t m, int64_t l, int64_t k, const double* tab, int64_t nx, int64_t ny,
+                               int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
+                               int64_t ldc) = 0;
+
   // ---- panel factorizations, in place ----
   // Y (m x l, ld) <- L of lu(Y) in pivoted row order; ipiv (device int32[l]) may be null.
   // Sets *singular_flag (backend int, see flags()) to j+1 on an exactly zero pivot.

@@ -60,11 +60,25 @@ constexpr int KSTEP_NN = 2 * NTHREADS / BMT;          // NN A tile: k advance pe
 constexpr int RSTEP = 2 * NTHREADS / BK;              // TN A tile / B tile: row (column) advance per pair slot
 static_assert(A_PAIRS * 2 * NTHREADS == BMT * BK, "tile does not divide over the threads");
 
-template <int NT, bool TRANS_A>
+// GEN: the big operand is never stored.  A(i, j) = ex[|x_i - x_j|] * ey[|y_i - y_j|] for grid points
+// i = (i / ny, i % ny) (a separable stationary covariance, SURVEY.md 8d "implicit" configuration); the
+// staging registers are filled from the two L1-resident tables instead of from HBM, everything after
+// that (LDS images, fragments, MFMAs) is the stored-operand kernel unchanged.
+struct GenA {
+  const double* ex;   // nx entries
+  const double* ey;   // ny entries
+  int32_t ny;
+  int32_t pad_;
+  int64_t roff;       // global index of row 0 of the product
+  int64_t koff;       // global index of reduction index 0
+};
+
+template <int NT, bool TRANS_A, bool GEN>
 __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     int64_t M, int64_t L, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* __restrict__ C, int64_t ldc, double alpha,
-    double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, int wide) {
+    double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, int wide, GenA gen) {
+  static_assert(!(GEN && TRANS_A), "the generated operand is symmetric: only the NN form exists");
   constexpr int A_ELEMS = TRANS_A ? BMT * BKP : BK * BMP;
   constexpr int B_ELEMS = NT * 16 * BKP;
   constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
@@ -118,8 +132,46 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   // load path on full-depth tiles; the branch is workgroup-uniform
   const bool wg_full = (r0 + BMT <= M) && (c0 + NT * 16 <= L);
 
+  // GEN: grid coordinates of this thread's two rows (fixed for the whole kernel), and of the reduction
+  // index the NEXT prefetched pair slot covers.  The latter is wave-uniform (a_k = wave index), lives in
+  // SGPRs and is advanced incrementally -- prefetch() is called on consecutive tiles, in order.
+  int g_x0 = 0, g_y0 = 0, g_x1 = 0, g_y1 = 0, g_kx = 0, g_ky = 0;
+  if constexpr (GEN) {
+    const int64_t gr = gen.roff + r0 + a_r;
+    g_x0 = (int)(gr / gen.ny); g_y0 = (int)(gr % gen.ny);
+    g_x1 = g_x0; g_y1 = g_y0 + 1;
+    if (g_y1 == gen.ny) { g_y1 = 0; g_x1 = g_x0 + 1; }
+    const int64_t gk = gen.koff + kbeg + __builtin_amdgcn_readfirstlane(a_k);
+    g_kx = __builtin_amdgcn_readfirstlane((int)(gk / gen.ny));
+    g_ky = __builtin_amdgcn_readfirstlane((int)(gk % gen.ny));
+  }
+
   auto prefetch = [&](int64_t k0, auto SET) {
     constexpr int set = decltype(SET)::value;
+    if constexpr (GEN) {
+      const int64_t kfirst = k0 + __builtin_amdgcn_readfirstlane(a_k);
+      auto advance = [&]() {
+        g_ky += KSTEP_NN;
+        while (g_ky >= gen.ny) { g_ky -= gen.ny; ++g_kx; }
+      };
+      if (r0 + BMT <= M && k0 + BK <= kend) {      // interior: no predicates (workgroup-uniform branch)
+#pragma unroll
+        for (int it = 0; it < A_PAIRS; ++it) {
+          a_reg[set][it].x = gen.ex[abs(g_x0 - g_kx)] * gen.ey[abs(g_y0 - g_ky)];
+          a_reg[set][it].y = gen.ex[abs(g_x1 - g_kx)] * gen.ey[abs(g_y1 - g_ky)];
+          advance();
+        }
+      } else {
+        const bool ok_r0 = r0 + a_r < M, ok_r1 = r0 + a_r + 1 < M;
+#pragma unroll
+        for (int it = 0; it < A_PAIRS; ++it) {
+          const bool okk = kfirst + KSTEP_NN * it < kend;   // uniform
+          a_reg[set][it].x = (okk && ok_r0) ? gen.ex[abs(g_x0 - g_kx)] * gen.ey[abs(g_y0 - g_ky)] : 0.0;
+          a_reg[set][it].y = (okk && ok_r1) ? gen.ex[abs(g_x1 - g_kx)] * gen.ey[abs(g_y1 - g_ky)] : 0.0;
+          advance();
+        }
+      }
+    }
     const char* Ab = Abase + 8 * (TRANS_A ? k0 : k0 * lda);   // uniform
     const char* Bb = Bbase + 8 * k0;                          // uniform
     // launder the strides so the per-load offsets are recomputed per tile (one VALU add each)
@@ -127,6 +179,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     uint32_t a_step = a_step_c, b_step = b_step_c;
     asm volatile("" : "+s"(a_step), "+s"(b_step));
     if (wide && wg_full && k0 + BK <= kend) {
+      if constexpr (!GEN) {
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it)
         {   // A is streamed once: non-temporal, to keep it out of the way of the X tiles in L2
@@ -134,6 +187,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
           const nt_double2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_double2*>(Ab + (a_off0 + (uint32_t)it * a_step)));
           a_reg[set][it].x = v.x; a_reg[set][it].y = v.y;
         }
+      }
 #pragma unroll
       for (int it = 0; it < B_PAIRS; ++it)
         if (!B_RAGGED || b_c + RSTEP * it < NT * 16)
@@ -141,6 +195,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
       return;
     }
     // general path: element-wise, predicated (edges, odd leading dimensions, unaligned views)
+    if constexpr (!GEN) {
 #pragma unroll
     for (int it = 0; it < A_PAIRS; ++it) {
       const char* p = Ab + (a_off0 + (uint32_t)it * a_step);
@@ -150,6 +205,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
       const bool ok1 = TRANS_A ? (r < M && k + 1 < kend) : (r + 1 < M && k < kend);
       a_reg[set][it].x = ok0 ? *reinterpret_cast<const double*>(p) : 0.0;
       a_reg[set][it].y = ok1 ? *reinterpret_cast<const double*>(p + 8) : 0.0;
+    }
     }
 #pragma unroll
     for (int it = 0; it < B_PAIRS; ++it) {
@@ -304,28 +360,29 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t L, int nsplit, const dou
   }
 }
 
-template <int NT, bool TRANS_A>
+template <int NT, bool TRANS_A, bool GEN>
 static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A,
                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha,
-                      double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide) {
+                      double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide, const GenA& gen) {
   constexpr size_t shmem = 2 * ((TRANS_A ? BMT * BKP : BK * BMP) + NT * 16 * BKP) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<NT, TRANS_A>,
+    (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<NT, TRANS_A, GEN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<NT, TRANS_A>), grid, dim3(NTHREADS), shmem, st, M, L, K, A, lda, B, ldb, C,
-                     ldc, alpha, beta, slabs, kchunk, nchunks_x, wide);
+  hipLaunchKernelGGL((gemm_f64_kernel<NT, TRANS_A, GEN>), grid, dim3(NTHREADS), shmem, st, M, L, K, A, lda, B, ldb, C,
+                     ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen);
 }
 
-template <bool TRANS_A>
+template <bool TRANS_A, bool GEN>
 static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K,
                             const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
-                            int64_t ldc, double alpha, double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide) {
+                            int64_t ldc, double alpha, double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide,
+                            const GenA& gen) {
 #define GSI_CASE(N)                                                                             \
   case N:                                                                                       \
-    launch_nt<N, TRANS_A>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide); \
+    launch_nt<N, TRANS_A, GEN>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
     break;
   switch (nt) {
     GSI_CASE(1) GSI_CASE(2) GSI_CASE(3) GSI_CASE(4) GSI_CASE(5)
@@ -353,9 +410,9 @@ size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K) {
   return ns > 1 ? (size_t)ns * (size_t)M * (size_t)L : 0;
 }
 
-// Host launcher. `ws` must hold gemm_workspace_doubles(M, L, K) doubles (or be null if 0).
-void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, double alpha, const double* A,
-              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws) {
+static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M, int64_t L, int64_t K, double alpha,
+                        const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+                        int64_t ldc, double* ws) {
   if (M <= 0 || L <= 0) return;
   // columns are processed in chunks of nt*16 <= 160; balance the chunks
   const int64_t tiles = (L + 15) / 16;
@@ -371,10 +428,13 @@ void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, doub
   double* slabs = (ns_eff > 1) ? ws : nullptr;
   // 16-byte loads need 16-B aligned bases and even leading dimensions (sub-panel views often are not)
   const int wide = (((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && (lda & 1) == 0 && (ldb & 1) == 0) ? 1 : 0;
-  if (transA)
-    launch_dispatch<true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide);
+  const GenA none = {nullptr, nullptr, 1, 0, 0, 0};
+  if (gen != nullptr)
+    launch_dispatch<false, true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, *gen);
+  else if (transA)
+    launch_dispatch<true, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, none);
   else
-    launch_dispatch<false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide);
+    launch_dispatch<false, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, none);
   if (ns_eff > 1) {
     const int64_t total = M * L;
     int blocks = (int)((total + 255) / 256);
@@ -382,6 +442,21 @@ void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, doub
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, M, L, ns_eff, slabs, C, ldc,
                        alpha, beta);
   }
+}
+
+// Host launchers. `ws` must hold gemm_workspace_doubles(M, L, K) doubles (or be null if 0).
+void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, double alpha, const double* A,
+              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws) {
+  gemm_launch(st, transA, nullptr, M, L, K, alpha, A, lda, B, ldb, beta, C, ldc, ws);
+}
+
+// C (M x L) = G * B with G(i, k) = ex[|x_i - x_k|] ey[|y_i - y_k|], i = roff + row, k = koff + reduction index;
+// tab = [ex (nx) | ey (ny)] in device memory.  The operand G is generated in registers, never stored.
+void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* tab, int64_t nx, int64_t ny,
+                      int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws) {
+  GenA g = {tab, tab + nx, (int32_t)ny, 0, roff, koff};
+  // A / lda only feed the 16-byte-load test for the stored operand: pass aligned dummies
+  gemm_launch(st, false, &g, M, L, K, 1.0, nullptr, 2, B, ldb, 0.0, C, ldc, ws);
 }
 
 }}  // namespace gsi::hipk

@@ -186,6 +186,13 @@ class HipBackend : public Backend {
     hipk::gemm_f64(st_, true, m, l, k, alpha, A, lda, B, ldb, beta, C, ldc, ws);
     check_launch("gemm_tn");
   }
+  void gemm_nn_gridcov(int64_t m, int64_t l, int64_t k, const double* tab, int64_t nx, int64_t ny, int64_t roff,
+                       int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc) override {
+    bind();
+    double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, k));
+    hipk::gemm_f64_gridcov(st_, m, l, k, tab, nx, ny, roff, koff, B, ldb, C, ldc, ws);
+    check_launch("gemm_nn_gridcov");
+  }
 
   // ---- panels ----
   void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv_host) override {

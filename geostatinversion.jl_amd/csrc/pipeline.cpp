@@ -40,6 +40,11 @@ void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* 
     be->gemm_nn(A.mloc, l, A.n, 1.0, A.data.p, A.ld, X, ldx, 0.0, Yloc, ldy);   // RandMatFact.jl:55,70
     return;
   }
+  if (A.kind == OP_GRIDCOV_IMPLICIT) {
+    ScopedPhase ph(be, PH_GEMM_N);
+    be->gemm_nn_gridcov(A.mloc, l, A.n, A.data.p, A.gx, A.gy, A.row0, 0, X, ldx, Yloc, ldy);
+    return;
+  }
   // LowRankCovMatrix: A*X = S (S'X) / (N-1)   (lowrank.jl:115-121 as two tall-skinny products)
   Buf T(be, (size_t)A.N * l);
   {
@@ -86,6 +91,23 @@ void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, dou
       ScopedPhase ph(be, PH_GEMM_T);
       if (A.mloc > 0)
         be->gemm_tn(A.n, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, Z, ldz);   // RandMatFact.jl:67,85
+      else
+        for (int64_t cidx = 0; cidx < l; ++cidx) be->fill_zero(Z + cidx * ldz, (size_t)A.n);
+    }
+    if (c.comm) {
+      ScopedPhase ph(be, PH_COMM);
+      if (ldz == A.n) c.comm->allreduce_sum(Z, (size_t)A.n * l);
+      else throw Error(GSI_ERR_INTERNAL, "op_mul_t: strided output with a communicator");
+    }
+    return;
+  }
+  if (A.kind == OP_GRIDCOV_IMPLICIT) {
+    // A symmetric: (A_loc)' X_loc = G[:, row0 .. row0+mloc) * X_loc -- the same generated NN product with
+    // the roles of the row and reduction offsets exchanged; partial sums over the ranks' row blocks
+    {
+      ScopedPhase ph(be, PH_GEMM_T);
+      if (A.mloc > 0)
+        be->gemm_nn_gridcov(A.n, l, A.mloc, A.data.p, A.gx, A.gy, 0, A.row0, Xloc, ldx, Z, ldz);
       else
         for (int64_t cidx = 0; cidx < l; ++cidx) be->fill_zero(Z + cidx * ldz, (size_t)A.n);
     }

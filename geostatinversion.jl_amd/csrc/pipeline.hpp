@@ -33,7 +33,7 @@ struct Context {
   int nranks() const { return comm ? comm->nranks : 1; }
 };
 
-enum OpKind { OP_DENSE = 0, OP_LOWRANK = 1 };
+enum OpKind { OP_DENSE = 0, OP_LOWRANK = 1, OP_GRIDCOV_IMPLICIT = 2 };
 
 // A linear operator m x n; this rank holds rows [row0, row0 + mloc).
 struct Operator {
@@ -43,6 +43,7 @@ struct Operator {
   Buf data;        // dense: mloc x n (ld mloc).  lowrank: samples shard mloc x N (ld mloc)
   int64_t ld = 0;
   int64_t N = 0;   // lowrank: number of samples
+  int64_t gx = 0, gy = 0;   // implicit grid covariance: data = [ex (gx) | ey (gy)], the operator is never stored
 };
 
 // block-row layout used whenever a caller does not supply one

@@ -70,6 +70,20 @@ class CpuBackend : public Backend {
                int64_t ldb, double beta, double* C, int64_t ldc) override {
     gsio_gemm_tn(m, l, k, alpha, A, lda, B, ldb, beta, C, ldc);
   }
+  void gemm_nn_gridcov(int64_t m, int64_t l, int64_t k, const double* tab, int64_t nx, int64_t ny, int64_t roff,
+                       int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc) override {
+    const double* ex = tab; const double* ey = tab + nx;
+    for (int64_t c = 0; c < l; ++c)
+      for (int64_t r = 0; r < m; ++r) {
+        const int64_t gi = roff + r;
+        double s = 0.0;
+        for (int64_t kk = 0; kk < k; ++kk) {
+          const int64_t gj = koff + kk;
+          s += ex[std::llabs(gi / ny - gj / ny)] * ey[std::llabs(gi % ny - gj % ny)] * B[kk + c * ldb];
+        }
+        C[r + c * ldc] = s;
+      }
+  }
   void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv) override {
     const int info = gsio_lu_L(Y, m, l, ld, ipiv);
     if (info && !lu_info_) lu_info_ = info;

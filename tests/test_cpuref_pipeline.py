@@ -157,3 +157,23 @@ def test_device_resident_basis(gsi, cx):
     S = rng.standard_normal((48, N)) / np.sqrt(N)
     got_rga = gsi.rga(forward, X.copy(), X, basis, R, y, S)
     assert got_rga.shape == (N,)
+
+
+def test_implicit_gridcov_operator(gsi, cx):
+    """gsi_op_gridcov_implicit: generated products equal the stored Gaussian covariance (implicit)."""
+    nx, ny, ell = 11, 6, 2.0
+    G = gaussian_cov(nx, ny, ell)
+    op = gsi.gridcov_implicit_operator(cx, nx, ny, ell)
+    assert op.shape == (nx * ny, nx * ny)
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((nx * ny, 7))
+    assert np.abs(op.matmul(X) - G @ X).max() < 1e-12
+    assert np.abs(op.rmatmul_t(X) - G.T @ X).max() < 1e-12
+    Om = rng.standard_normal((nx * ny, 12))
+    Z, S = gsi.randsvd(op, 8, 4, 2, Omega=Om, return_S=True)
+    Zr, Sr, _ = orc.randsvd_full(G, 8, 4, 2, Om)
+    assert rel_sv_err(S, Sr, 8) < 1e-9
+    assert orc.xis_error_up_to_sign(Z, Zr, 8) < 1e-6
+    op.close()
+    with pytest.raises(gsi.GsiError):
+        gsi.gridcov_implicit_operator(cx, 4, 4, -1.0)

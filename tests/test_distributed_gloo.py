@@ -102,6 +102,18 @@ def _worker(rank, world, port, q):
         Y = rng.standard_normal((90, 3))
         results["mul_t"] = float(np.abs(op.rmatmul_t(Y) - B.T @ Y).max())
         op.close()
+        # implicit grid covariance (never stored): sharded generated products against the dense matrix
+        G = gaussian_cov(9, 7, 2.5)                                  # n = 63
+        gop = gsi.gridcov_implicit_operator(ctx, 9, 7, 2.5)
+        X = rng.standard_normal((63, 5))
+        results["implicit_mul"] = float(np.abs(gop.matmul(X) - G @ X).max())
+        results["implicit_mul_t"] = float(np.abs(gop.rmatmul_t(X) - G.T @ X).max())
+        Om = rng.standard_normal((63, 12))
+        Z, S = gsi.randsvd(gop, 8, 4, 2, Omega=Om, return_S=True)
+        Zr, Sr, _ = orc.randsvd_full(G, 8, 4, 2, Om)
+        results["implicit_sv"] = rel_sv_err(S, Sr, 8)
+        results["implicit_xis"] = orc.xis_error_up_to_sign(Z, Zr, 8)
+        gop.close()
         ctx.close()
         dist.barrier()
         dist.destroy_process_group()
@@ -135,7 +147,7 @@ def test_sharded_pipeline_gloo(world):
     for rank, _, res in out:
         for k, v in res.items():
             tol = 1e-6 if k.endswith("xis") else 1e-9
-            if k.endswith("orth") or k in ("mul", "mul_t", "lowrank_mul"):
+            if k.endswith("orth") or k in ("mul", "mul_t", "lowrank_mul", "implicit_mul", "implicit_mul_t"):
                 tol = 1e-11
             assert v < tol, (rank, k, v)
     # every rank computed the same replicated result

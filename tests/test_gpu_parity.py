@@ -456,3 +456,38 @@ def test_device_resident_basis_gpu(gsi, ctx):
     assert np.linalg.norm(got - truep) / np.linalg.norm(truep) < 2e-2
     got = gsi.pcgalsqr(forward, X.copy(), X, basis, R, y)
     assert np.linalg.norm(got - truep) / np.linalg.norm(truep) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,l", [(40, 33, 5), (40, 33, 160), (64, 50, 200), (130, 7, 48)])
+def test_implicit_gridcov_products(gsi, ctx, nx, ny, l):
+    """gsi_op_gridcov_implicit (entries generated inside the MFMA kernel, nothing stored) against the stored
+    operator of gsi_op_dense_gridcov on the same grid: A*X and A'*X, ragged row / reduction edges included."""
+    ell = 3.5
+    n = nx * ny
+    rng = np.random.default_rng(nx * ny + l)
+    X = rng.standard_normal((n, l))
+    dense = gsi.gridcov_operator(ctx, nx, ny, ell, 0)
+    impl = gsi.gridcov_implicit_operator(ctx, nx, ny, ell)
+    Yd, Yi = dense.matmul(X), impl.matmul(X)
+    scale = np.abs(Yd).max()
+    assert np.abs(Yi - Yd).max() < 1e-13 * scale
+    assert np.abs(impl.rmatmul_t(X) - dense.rmatmul_t(X)).max() < 1e-13 * scale
+    dense.close()
+    impl.close()
+
+
+@pytest.mark.gpu
+def test_implicit_gridcov_randsvd(gsi, ctx):
+    """randsvd through the implicit operator = randsvd of the stored matrix (same Omega), and = the oracle."""
+    nx, ny, ell, K, p, q = 48, 40, 4.0, 20, 12, 2
+    n = nx * ny
+    Om = np.random.default_rng(3).standard_normal((n, K + p))
+    impl = gsi.gridcov_implicit_operator(ctx, nx, ny, ell)
+    Z, S = gsi.randsvd(impl, K, p, q, Omega=Om, return_S=True)
+    A = gaussian_cov(nx, ny, ell)
+    Zr, Sr, _ = orc.randsvd_full(A, K, p, q, Om)
+    assert rel_sv_err(S, Sr, K) < 1e-9
+    assert orc.xis_error_up_to_sign(Z, Zr, K) < 1e-6
+    assert np.all(Z[:, K:] == 0)
+    impl.close()
