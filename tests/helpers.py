@@ -57,3 +57,25 @@ def rel_sv_err(S, Sref, K, floor=1e-10):
     Sref = np.asarray(Sref)[:K]
     mask = Sref > floor * Sref[0]
     return float(np.max(np.abs(S[mask] - Sref[mask]) / Sref[mask]))
+
+
+def random_shape_cases(seed, count, nmax):
+    """(m, n, K, p, q, spectrum_decay) tuples for the shape sweeps: tiny, ragged, rectangular, l == min(m, n) ..."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(count):
+        n = int(rng.integers(1, nmax + 1))
+        m = n if rng.random() < 0.5 else int(rng.integers(max(1, n // 2), 2 * n + 1))
+        l = int(rng.integers(1, min(m, n) + 1))
+        p = int(rng.integers(0, l))          # K = l - p >= 1
+        q = int(rng.integers(0, 4))
+        cases.append((m, n, l - p, p, q, float(rng.uniform(0.3, 2.0))))
+    return cases
+
+
+def decaying_matrix(rng, m, n, decay):
+    """m x n matrix with singular values (i+1)^-decay and Haar-ish factors: distinct, well separated spectrum."""
+    r = min(m, n)
+    U, _ = np.linalg.qr(rng.standard_normal((m, r)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, r)))
+    return (U * (np.arange(1, r + 1.0) ** -decay)[None, :]) @ V.T

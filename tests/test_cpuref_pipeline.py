@@ -177,3 +177,17 @@ def test_implicit_gridcov_operator(gsi, cx):
     op.close()
     with pytest.raises(gsi.GsiError):
         gsi.gridcov_implicit_operator(cx, 4, 4, -1.0)
+
+
+def test_randsvd_shape_sweep_cpuref(gsi, cx):
+    """The same seeded shape sweep as the GPU suite, through pipeline.cpp on the CPU reference backend."""
+    from helpers import random_shape_cases, decaying_matrix
+    rng = np.random.default_rng(2024)
+    for (m, n, K, p, q, decay) in random_shape_cases(11, 60, 60):
+        A = decaying_matrix(rng, m, n, decay)
+        Om = rng.standard_normal((n, K + p))
+        Z, S = gsi.randsvd(A, K, p, q, Omega=Om, return_S=True, ctx=cx)
+        Zr, Sr, _ = orc.randsvd_full(A, K, p, q, Om)
+        assert np.all(Z[:, K:] == 0)
+        assert np.abs(S - Sr).max() / Sr[0] < 1e-10, (m, n, K, p, q)
+        assert np.abs(Z @ Z.T - Zr @ Zr.T).max() / Sr[0] < 1e-8, (m, n, K, p, q)

@@ -57,6 +57,31 @@ def test_lu_L_matches_lapack(gsi, ctx, m, l):
     assert np.abs(L - Lref).max() < 1e-11
 
 
+@pytest.mark.parametrize("m", [40, 300, 1000, 4100, 70001])
+def test_lu_pivot_ties_exact(gsi, ctx, m):
+    """Dyadic entries (+-1, +-1/2), two columns: both elimination steps are exact in any operation order and both
+    columns are full of equal-magnitude candidates spread over all workgroups; the pivot must be the FIRST
+    maximal row, as idamax/dgetrf picks it.  Bit-exact pivots and bit-exact L."""
+    rng = np.random.default_rng(m)
+    Y = rng.choice([-1.0, 1.0], (m, 2)) * 2.0 ** -rng.integers(0, 2, (m, 2))
+    Y[: m // 3, 0] *= 0.5                      # the first maximal row of column 0 is not row 0
+    L, got = gsi.lu_L(Y, return_pivots=True)
+    assert np.array_equal(got, orc.lu_pivots(Y))
+    assert np.array_equal(L, orc.lu_L(Y))
+
+
+@pytest.mark.parametrize("h,l", [(20, 7), (333, 40), (2500, 160), (1111, 33)])
+def test_lu_pivot_ties_duplicate_rows(gsi, ctx, h, l):
+    """Y = [R; R]: at every step the maximum is attained by two bitwise-identical rows (whatever the rounding of
+    the previous updates), so every pivot decision is a tie between a row and its copy: lowest index wins."""
+    rng = np.random.default_rng(h + l)
+    R = rng.standard_normal((h, l))
+    Y = np.vstack([R, R])
+    L, got = gsi.lu_L(Y, return_pivots=True)
+    assert np.array_equal(got, orc.lu_pivots(Y))
+    assert np.abs(L - orc.lu_L(Y)).max() < 1e-11
+
+
 def test_lu_singular_raises(gsi, ctx):
     Y = np.zeros((20, 3))
     Y[:, 0] = 1.0
@@ -491,3 +516,22 @@ def test_implicit_gridcov_randsvd(gsi, ctx):
     assert orc.xis_error_up_to_sign(Z, Zr, K) < 1e-6
     assert np.all(Z[:, K:] == 0)
     impl.close()
+
+
+@pytest.mark.gpu
+def test_randsvd_shape_sweep(gsi, ctx):
+    """60 seeded random (m, n, K, p, q) configurations -- 1 x 1, ragged, rectangular, l = min(m, n), p = 0 --
+    against the oracle: svd(Q'A).S and the basis-independent product Z Z' (= V_K S_K V_K')."""
+    from helpers import random_shape_cases, decaying_matrix
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for (m, n, K, p, q, decay) in random_shape_cases(11, 60, 150):
+        A = decaying_matrix(rng, m, n, decay)
+        Om = rng.standard_normal((n, K + p))
+        Z, S = gsi.randsvd(A, K, p, q, Omega=Om, return_S=True, ctx=ctx)
+        Zr, Sr, _ = orc.randsvd_full(A, K, p, q, Om)
+        assert Z.shape == (n, K + p) and np.all(Z[:, K:] == 0)
+        e_s = np.abs(S - Sr).max() / Sr[0]
+        e_z = np.abs(Z @ Z.T - Zr @ Zr.T).max() / Sr[0]
+        worst = max(worst, e_s, e_z)
+        assert e_s < 1e-10 and e_z < 1e-8, (m, n, K, p, q, e_s, e_z)

@@ -127,3 +127,21 @@ def test_scipy_oracle_vs_golden():
     g3 = np.load(os.path.join(GOLD, "lowrank_n100_N24.npz"))
     xis, _ = orc.getxis_fields(list(g3["fields"]), int(g3["K"]), int(g3["p"]), int(g3["q"]), g3["Omega"])
     assert orc.xis_error_up_to_sign(np.array(xis).T, g3["xis"].T, int(g3["K"])) < 1e-7
+
+
+@pytest.mark.parametrize("h,l", [(20, 7), (150, 24)])
+def test_c_oracle_lu_ties_duplicate_rows(h, l):
+    """Tie-breaking of the pivot search (lowest index, idamax) in the C restatement: Y = [R; R]."""
+    import cpuref
+    import ctypes as C
+    lib = cpuref.load_oracle_c()
+    rng = np.random.default_rng(h * l)
+    R = rng.standard_normal((h, l))
+    Y = np.asfortranarray(np.vstack([R, R]))
+    piv = np.zeros(l, dtype=np.int32)
+    Yc = Y.copy(order="F")
+    lib.gsio_lu_L.restype = C.c_int
+    info = lib.gsio_lu_L(Yc.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(2 * h), C.c_int64(l), C.c_int64(2 * h),
+                         piv.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert info == 0
+    assert np.array_equal(piv, orc.lu_pivots(Y))
