@@ -267,7 +267,7 @@ class HipBackend : public Backend {
   }
   void svd_small(double* G, int64_t l, double* U, double* S) override {
     bind();
-    if (l > 1200) throw Error(GSI_ERR_ARG, "sketch width l = K+p > 1200 is not supported by the LDS-resident block Jacobi SVD");
+    if (l > 5000) throw Error(GSI_ERR_ARG, "sketch width l = K+p > 5000 is not supported by the LDS-resident block Jacobi SVD");
     grow(ws_svd_, sizeof(double) * (l + 8) + 64);
     hipk::SvdWork w;
     w.norms = (double*)ws_svd_.p;

@@ -183,11 +183,14 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
   return sweeps;
 }
 
-// 32 resident columns per workgroup up to l = 600, 16 beyond (LDS: columns x (l padded) x 8 B <= 160 KB)
+// 32 resident columns per workgroup up to l = 600, then 16 / 8 / 4 as the columns get longer
+// (LDS: columns x (l padded) x 8 B <= 160 KB); l <= SVD_MAX_L = 5000.
 int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, const SvdWork& w) {
   const int l = (int)l64;
   if (l <= 600) return svd_small_impl<16>(st, G, l, U, S, w);
-  return svd_small_impl<8>(st, G, l, U, S, w);
+  if (l <= 1200) return svd_small_impl<8>(st, G, l, U, S, w);
+  if (l <= 2500) return svd_small_impl<4>(st, G, l, U, S, w);
+  return svd_small_impl<2>(st, G, l, U, S, w);
 }
 
 }}  // namespace gsi::hipk

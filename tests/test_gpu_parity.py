@@ -129,6 +129,18 @@ def test_svd_tall(gsi, ctx, n, l):
         assert min(np.linalg.norm(V[:, i] - Uref[:, i]), np.linalg.norm(V[:, i] + Uref[:, i])) < 1e-6
 
 
+@pytest.mark.parametrize("n,l", [(1400, 1300), (2800, 2600)])
+def test_svd_tall_very_wide(gsi, ctx, n, l):
+    """Sketch widths beyond the 16- and 8-column LDS blockings of the Jacobi kernel (4 / 2 columns per block)."""
+    rng = np.random.default_rng(l)
+    W = rng.standard_normal((n, l)) * np.logspace(0, -3, l)[None, :]
+    S, V = gsi.svd_tall(W)
+    Sref = np.linalg.svd(W, compute_uv=False)
+    assert np.all(np.diff(S) <= 0)
+    assert np.abs(S - Sref).max() <= 1e-12 * Sref[0]
+    assert np.abs(V.T @ V - np.eye(l)).max() < 1e-11
+
+
 # ---- rangefinder: the reference's own property tests (test/testrmf.jl:11-19) + oracle parity ----
 @pytest.mark.parametrize("n,m", [(10, 2), (10, 5), (100, 5), (100, 10), (100, 25)])
 def test_rangefinder_exact_rank(gsi, ctx, n, m):
