@@ -40,6 +40,7 @@
 //    grid would not fill the chip (row shards on 8 GPUs, small M): deterministic, no atomics.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 #include "hip_common.hpp"
 
@@ -392,15 +393,29 @@ static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_
 #undef GSI_CASE
 }
 
-// Number of K splits for a grid of `nwg` workgroups (one workgroup per CU, 256 CUs).
+// Number of K splits for a grid of `nwg` workgroups.  One workgroup per CU, 256 CUs: a grid of g equal
+// workgroups takes ceil(g / 256) rounds, so 181 row blocks (or 392: 2 rounds for 1.53 rounds of work) leave a
+// large part of the chip idle.  Splitting K by s makes the rounds s times shorter: pick the s that minimises
+// ceil(nwg * s / 256) / s, charged 0.4 % per split for the slab write + reduce, and only when it buys > 3 %.
 int gemm_choose_split(int64_t nwg, int64_t K) {
-  if (nwg >= 192 || K < 8 * BK) return 1;
-  int64_t want = (256 + nwg - 1) / nwg;
+  constexpr int64_t CUS = 256;
+  static const bool legacy = getenv("GSI_GEMM_SPLIT_LEGACY") != nullptr;   // A/B knob: fill-the-chip rule only
+  if (legacy) {
+    if (nwg >= 192 || K < 8 * BK) return 1;
+    int64_t want = (CUS + nwg - 1) / nwg, cap = K / (4 * BK);
+    if (want > cap) want = cap;
+    return (int)(want < 1 ? 1 : (want > 64 ? 64 : want));
+  }
+  if (K < 8 * BK || nwg >= 16 * CUS) return 1;
   int64_t maxs = K / (4 * BK);
-  if (want > maxs) want = maxs;
-  if (want < 1) want = 1;
-  if (want > 64) want = 64;
-  return (int)want;
+  if (maxs > 64) maxs = 64;
+  int best = 1;
+  double best_cost = (double)((nwg + CUS - 1) / CUS);
+  for (int64_t s = 2; s <= maxs; ++s) {
+    const double cost = (double)((nwg * s + CUS - 1) / CUS) / (double)s * (1.0 + 0.004 * (double)s);
+    if (cost < 0.97 * best_cost) { best = (int)s; best_cost = cost; }
+  }
+  return best;
 }
 
 size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K) {

@@ -17,7 +17,7 @@ lib = ctx.lib
 for G in ([a.G] if a.G > 0 else [2, 4, 8]):
     mloc = a.n // G
     rng = np.random.default_rng(0)
-    A = np.asfortranarray(rng.standard_normal((mloc, 1024)).repeat(a.n // 1024, axis=1))
+    A = np.asfortranarray(rng.standard_normal((mloc, 1024))[:, np.arange(a.n) % 1024])
     op = gsi.dense_operator(ctx, A)
     del A
     X = gsi.DeviceMatrix(ctx, a.n, a.l).randn(1)
