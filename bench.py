@@ -4,8 +4,10 @@
 One "step" = one `randsvd(A, K, p, q)` (RandMatFact.jl:83-90) with the operator A and the Gaussian
 test matrix Omega already resident in HBM.  Workload at N = 1: BASELINE.json configs[1] -- dense
 fp64 65536 x 65536 Gaussian covariance (256 x 256 unit grid, ell = 16), K = 128, p = 32 (l = 160),
-q = 2.  For N > 1 the same matrix is row-sharded over the ranks ("strong" scaling), RCCL
-all-reduce / all-gather between the passes.
+q = 2.  For N > 1 the matrix is row-sharded over the ranks, RCCL all-reduce / all-gather between the
+passes.  Default `--scaling weak`: every GPU keeps the SAME 34 GB row shard as at
+N = 1 (n grows as sqrt(N): 256 x round(256 sqrt(N)) grid, per-GPU contraction work fixed) -- multi-GPU exists
+here to factor covariances that do not fit one GPU.  `--scaling strong` shards the N = 1 matrix instead.
 
 metric value   = algorithmic GB/s of the whole job: (2q+2) * (8 n^2 + 16 n l) bytes / step time
 roofline       = the dominant kernel (the fp64 MFMA contraction A*X / A'*X): 2 n^2 l flop per
@@ -78,6 +80,7 @@ def main():
     ap.add_argument("--K", type=int, default=128)
     ap.add_argument("--p", type=int, default=32)
     ap.add_argument("--q", type=int, default=2)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -104,10 +107,12 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(world, rank, ids[0])                  # RCCL communicator over xGMI
 
-    n = args.grid * args.grid
+    nx = args.grid
+    ny = args.grid if args.scaling == "strong" else int(round(args.grid * world ** 0.5))   # n^2 / N fixed
+    n = nx * ny
     K, p, q = args.K, args.p, args.q
     l = K + p
-    op = gsi.gridcov_operator(ctx, args.grid, args.grid, args.ell, 0)      # A resident in HBM
+    op = gsi.gridcov_operator(ctx, nx, ny, args.ell, 0)                     # A resident in HBM
     Omega = gsi.DeviceMatrix(ctx, n, l).randn(1234)                          # Omega resident in HBM
     Z = gsi.DeviceMatrix(ctx, n, l)
     S = gsi.DeviceMatrix(ctx, l, 1)
@@ -151,14 +156,14 @@ def main():
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1 and n == 65536 and l == 160:   # counters were collected on this shape
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                "kernel": "gemm_f64_kernel<NT,TRANS_A> (v_mfma_f64_16x16x4_f64)",
+                "kernel": "gemm_f64_kernel<NT,TRANS_A,GEN> (v_mfma_f64_16x16x4_f64)",
                 "avg_launch_ms": avg_ms, "launches": int(g_cnt),
                 "hbm_frac_of_A_stream": (8.0 * mloc * n / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if avg_ms > 0 else 0.0}
 
@@ -166,11 +171,15 @@ def main():
         out = {
             "metric": "randSVD GB/s + top-k singular-value rel-err", "value": value, "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"dense fp64 {n}x{n} Gaussian covariance ({args.grid}x{args.grid} grid, "
-                                   f"ell={args.ell}), K={K}, p={p}, q={q} (BASELINE.json configs[1])",
-                       "n": n, "K": K, "p": p, "q": q, "parallelism": f"row-shard x{world}"},
+            "config": {"workload": f"dense fp64 {n}x{n} Gaussian covariance ({nx}x{ny} grid, "
+                                   f"ell={args.ell}), K={K}, p={p}, q={q} (BASELINE.json configs[1]"
+                                   + ("" if world == 1 else
+                                      (", n scaled by sqrt(N): same 34 GB row shard per GPU" if args.scaling == "weak"
+                                       else ", same matrix row-sharded")) + ")",
+                       "n": n, "K": K, "p": p, "q": q, "parallelism": f"row-shard x{world}",
+                       "operator_bytes_per_gpu": 8.0 * mloc * n},
             "roofline": roofline,
             "phases_ms_per_step": {k: v[0] / args.steps for k, v in phases.items()},
             "phase_launch_groups_per_step": {k: v[1] / args.steps for k, v in phases.items()},
