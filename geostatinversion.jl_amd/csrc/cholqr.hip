@@ -3,17 +3,17 @@
 //
 // Why: Householder on an m x l panel costs ~l/NB sweeps of the panel plus 2 launches per column; at
 // the metric's nominal size (m = 10^6, l = 320) that is ~100 GB of HBM traffic per factorization.
-// CholeskyQR2 is two rounds of { G = Y'Y (one read of Y, MFMA), R = chol(G) (l x l), Y <- Y R^-1
-// (blocked triangular solve = MFMA GEMMs) }: ~6 panel passes, all through the contraction kernel of
-// gemm_f64.hip.  The computed Q has the same range as Y (all the reference keeps of its pivoted QR),
+// CholeskyQR2 is two rounds of { G = Y'Y (MFMA), R = chol(G) (l x l), X = R^-1 (l x l, explicit),
+// Y_next = Y X (ONE out-of-place MFMA product) }: ~8 panel passes, all through the contraction kernel of
+// gemm_f64.hip, and the input panel stays intact until the method is known to have worked (no save copy).  The computed Q has the same range as Y (all the reference keeps of its pivoted QR),
 // is orthonormal to machine precision after the second round, and W = Q (R2 R1) holds to O(eps)|W|,
 // so singular values keep the absolute O(eps sigma_1) accuracy of a Householder QR.
 //
 // Safety: the method needs cond(Y) < ~1e7.  The first Cholesky can break down (or silently lose
 // everything) beyond that, and the reference's own tests produce exactly rank-deficient sketches
 // (SURVEY.md H7).  Both rounds therefore raise a device flag on a non-positive / negligible pivot and
-// the second round checks |Q1'Q1 - I|_max; on any doubt the caller restores the panel and runs the
-// Householder path (panel_qr.hip).  Decision = one 4-byte read per factorization.
+// the second round checks |Q1'Q1 - I|_max; on any doubt the caller runs the Householder path (panel_qr.hip)
+// on the untouched panel.  Decision = one 4-byte read per factorization, taken before the last product.
 #include "hip_common.hpp"
 #include <cfloat>
 
@@ -164,52 +164,80 @@ static inline int grid_for(int64_t total, int cap = 2048) {
   return (int)g;
 }
 
-size_t cholqr_small_doubles(int64_t l) {
-  const int64_t nblk = (l + CQ_TB - 1) / CQ_TB;
-  return (size_t)(3 * l * l + nblk * CQ_TB * CQ_TB + 64);
+// X (l x l) <- identity
+__global__ void cq_identity_kernel(double* __restrict__ X, int l) {
+  const int64_t total = (int64_t)l * l;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    X[e] = (e % l == e / l) ? 1.0 : 0.0;
 }
 
-// One CholeskyQR2 attempt on Y (m x l, ld), in place.  `small` holds cholqr_small_doubles(l) doubles;
-// flag is a zeroed device int.  On return (stream-ordered) flag == 0 means success; R (may be null)
-// receives R2*R1.  The caller must have saved Y if it wants to fall back.
-void cholqr2(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld, double* R, double* small,
-             int32_t* flag, double* gemm_ws) {
-  const int l = (int)l64;
+size_t cholqr_small_doubles(int64_t l) {
+  const int64_t nblk = (l + CQ_TB - 1) / CQ_TB;
+  return (size_t)(5 * l * l + nblk * CQ_TB * CQ_TB + 64);
+}
+
+namespace {
+struct CqBufs { double *R1, *R2, *Gt, *X1, *X2, *Rinv; };
+inline CqBufs cq_bufs(double* small, int l) {
+  const size_t ll = (size_t)l * l;
+  return {small, small + ll, small + 2 * ll, small + 3 * ll, small + 4 * ll, small + 5 * ll};
+}
+
+// One round: Rp <- chol(src' src) (upper), X <- Rp^-1 (explicit, l x l), dst <- src X.
+// The inverse costs 2 * l/32 launches on l x l data (the blocked solve applied to the identity); what it buys
+// is ONE pass over the panel for Y R^-1 (read src, write dst) instead of a blocked in-place solve that re-reads
+// the already solved block columns for every later one (l/64 panel reads), and an untouched src.
+void cq_round(hipStream_t st, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t m, int l, double* Rp,
+              double* X, const CqBufs& b, bool check, int32_t* flag, double* gemm_ws, bool apply) {
   const int nblk = (l + CQ_TB - 1) / CQ_TB;
-  double* R1 = small;
-  double* R2 = small + (size_t)l * l;
-  double* Gt = small + 2 * (size_t)l * l;
-  double* Rinv = small + 3 * (size_t)l * l;
-  for (int pass = 0; pass < 2; ++pass) {
-    double* Rp = pass == 0 ? R1 : R2;
-    gemm_f64(st, true, l, l, m, 1.0, Y, ld, Y, ld, 0.0, Rp, l, gemm_ws);          // G = Y'Y
-    if (pass == 1)
-      hipLaunchKernelGGL(cq_orth_check_kernel, dim3(grid_for((int64_t)l * l, 64)), dim3(256), 0, st, Rp, l, 0.1,
-                         flag);
-    // R = chol(G), blocked: per 32-column block one small kernel (diagonal block + its inverse + block
-    // row) and one MFMA GEMM for the trailing update; the block inverses are what the solve below needs
-    hipLaunchKernelGGL(cq_diagmax_kernel, dim3(1), dim3(256), 0, st, Rp, l, Gt);
-    for (int jb = 0; jb < nblk; ++jb) {
-      const int j0 = jb * CQ_TB;
-      const int b = (l - j0 < CQ_TB) ? (l - j0) : CQ_TB;
-      hipLaunchKernelGGL(cq_chol_block_kernel, dim3(1), dim3(256), 0, st, Rp, l, j0, b, Gt,
-                         Rinv + (size_t)jb * CQ_TB * CQ_TB, flag);
-      const int t = l - j0 - b;
-      if (t > 0)
-        gemm_f64(st, true, t, t, b, -1.0, Rp + j0 + (int64_t)(j0 + b) * l, l, Rp + j0 + (int64_t)(j0 + b) * l, l, 1.0,
-                 Rp + (j0 + b) + (int64_t)(j0 + b) * l, l, gemm_ws);
-    }
-    for (int jb = 0; jb < nblk; ++jb) {                                             // Y <- Y R^-1, blocked
-      const int64_t j0 = (int64_t)jb * CQ_TB;
-      const int b = (int)((l - j0 < CQ_TB) ? (l - j0) : CQ_TB);
-      if (j0 > 0)
-        gemm_f64(st, false, m, b, j0, -1.0, Y, ld, Rp + j0 * (int64_t)l, l, 1.0, Y + j0 * ld, ld, gemm_ws);
-      hipLaunchKernelGGL(cq_right_mult_kernel, dim3(grid_for(m, 1024)), dim3(256), 0, st, Y, m, ld, j0, b,
-                         Rinv + (size_t)jb * CQ_TB * CQ_TB);
-    }
+  gemm_f64(st, true, l, l, m, 1.0, src, lds, src, lds, 0.0, Rp, l, gemm_ws);          // G = Y'Y
+  if (check)
+    hipLaunchKernelGGL(cq_orth_check_kernel, dim3(grid_for((int64_t)l * l, 64)), dim3(256), 0, st, Rp, l, 0.1, flag);
+  // R = chol(G), blocked: per 32-column block one small kernel (diagonal block + its inverse + block
+  // row) and one MFMA GEMM for the trailing update; the block inverses are what the solve below needs
+  hipLaunchKernelGGL(cq_diagmax_kernel, dim3(1), dim3(256), 0, st, Rp, l, b.Gt);
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int j0 = jb * CQ_TB;
+    const int bb = (l - j0 < CQ_TB) ? (l - j0) : CQ_TB;
+    hipLaunchKernelGGL(cq_chol_block_kernel, dim3(1), dim3(256), 0, st, Rp, l, j0, bb, b.Gt,
+                       b.Rinv + (size_t)jb * CQ_TB * CQ_TB, flag);
+    const int t = l - j0 - bb;
+    if (t > 0)
+      gemm_f64(st, true, t, t, bb, -1.0, Rp + j0 + (int64_t)(j0 + bb) * l, l, Rp + j0 + (int64_t)(j0 + bb) * l, l, 1.0,
+               Rp + (j0 + bb) + (int64_t)(j0 + bb) * l, l, gemm_ws);
   }
+  hipLaunchKernelGGL(cq_identity_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, X, l);
+  for (int jb = 0; jb < nblk; ++jb) {                                                 // X <- I R^-1, blocked
+    const int64_t j0 = (int64_t)jb * CQ_TB;
+    const int bb = (int)((l - j0 < CQ_TB) ? (l - j0) : CQ_TB);
+    if (j0 > 0)
+      gemm_f64(st, false, j0 + bb, bb, j0, -1.0, X, l, Rp + j0 * (int64_t)l, l, 1.0, X + j0 * l, l, gemm_ws);
+    hipLaunchKernelGGL(cq_right_mult_kernel, dim3(grid_for(j0 + bb, 1024)), dim3(256), 0, st, X, j0 + bb, (int64_t)l,
+                       j0, bb, b.Rinv + (size_t)jb * CQ_TB * CQ_TB);
+  }
+  if (apply) gemm_f64(st, false, m, l, l, 1.0, src, lds, X, l, 0.0, dst, ldd, gemm_ws);   // dst = src R^-1
+}
+}  // namespace
+
+// CholeskyQR2 on Y (m x l, ld) in two host-visible steps.
+// cholqr2_factor: T (m x l, ld ldt) <- Y R1^-1, then R2 = chol(T'T) and R2^-1; Y is NOT modified.  flag (zeroed
+// device int) != 0 afterwards means "do not trust it" -- the caller runs Householder on the untouched Y.
+// cholqr2_apply (after the host has read flag == 0): Y <- T R2^-1, R (may be null) <- R2 R1.
+void cholqr2_factor(hipStream_t st, const double* Y, int64_t m, int64_t l64, int64_t ld, double* T, int64_t ldt,
+                    double* small, int32_t* flag, double* gemm_ws) {
+  const int l = (int)l64;
+  const CqBufs b = cq_bufs(small, l);
+  cq_round(st, Y, ld, T, ldt, m, l, b.R1, b.X1, b, false, flag, gemm_ws, true);
+  cq_round(st, T, ldt, nullptr, 0, m, l, b.R2, b.X2, b, true, flag, gemm_ws, false);
+}
+
+void cholqr2_apply(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld, const double* T, int64_t ldt,
+                   double* R, double* small, double* gemm_ws) {
+  const int l = (int)l64;
+  const CqBufs b = cq_bufs(small, l);
+  gemm_f64(st, false, m, l, l, 1.0, T, ldt, b.X2, l, 0.0, Y, ld, gemm_ws);
   if (R != nullptr)
-    hipLaunchKernelGGL(cq_triprod_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, R2, R1, l, R);
+    hipLaunchKernelGGL(cq_triprod_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, b.R2, b.R1, l, R);
 }
 
 }}  // namespace gsi::hipk

@@ -232,7 +232,7 @@ class HipBackend : public Backend {
     const size_t o_coef = take(2 + NB + 2), o_part = take((size_t)nb * NB), o_tau = take(l),
                  o_T = take((size_t)npan * NB * NB), o_G = take(NB * NB), o_V = take((size_t)m * NB),
                  o_Wt = take((size_t)l * NB), o_W2 = take((size_t)l * NB), o_small = take(hipk::cholqr_small_doubles(l)),
-                 o_Q = take((size_t)m * l);
+                 o_Q = take((size_t)(m + 1) * l);
     grow(ws_qr_, cnt * sizeof(double));
     double* base = (double*)ws_qr_.p;
     hipk::QrWork w;
@@ -242,6 +242,8 @@ class HipBackend : public Backend {
     size_t gmax = hipk::gemm_workspace_doubles(l, NB, m);
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(NB, NB, m));
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, l, m));
+    gmax = std::max(gmax, hipk::gemm_workspace_doubles(m, l, l));       // CholeskyQR2: Y R^-1 as one product
+    gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, 32, l));      //             : the l x l inverse
     for (int64_t t = NB; t <= l; t += NB) gmax = std::max(gmax, hipk::gemm_workspace_doubles(t, NB, m));
     double* ws = gemm_ws(gmax + 64);
     // First choice: CholeskyQR2 (a handful of MFMA GEMM passes).  It needs a numerically full-rank,
@@ -249,17 +251,20 @@ class HipBackend : public Backend {
     // Householder reflectors from the saved copy.
     static const bool no_cholqr = (getenv("GSI_NO_CHOLQR") != nullptr);
     if (!no_cholqr && l <= 1024 && m >= 2 * l) {
-      HIP_CHECK(hipMemcpy2DAsync(w.Qo, m * sizeof(double), Y, ld * sizeof(double), m * sizeof(double), l,
-                                 hipMemcpyDeviceToDevice, st_));
+      // both rounds run out of place (Y -> Qo -> Y); Y is only overwritten once the flag is known to be clear
       HIP_CHECK(hipMemsetAsync(flags_ + 9, 0, sizeof(int32_t), st_));
-      hipk::cholqr2(st_, Y, m, l, ld, R, base + o_small, flags_ + 9, ws);
-      check_launch("cholqr2");
+      const int64_t ldt = (m + 1) & ~(int64_t)1;   // even: 16-byte loads in the contraction kernel
+      hipk::cholqr2_factor(st_, Y, m, l, ld, w.Qo, ldt, base + o_small, flags_ + 9, ws);
+      check_launch("cholqr2_factor");
       int32_t f = 0;
       HIP_CHECK(hipMemcpyAsync(&f, flags_ + 9, sizeof(int32_t), hipMemcpyDeviceToHost, st_));
       HIP_CHECK(hipStreamSynchronize(st_));
-      if (f == 0) { ++n_cholqr_; return; }
-      HIP_CHECK(hipMemcpy2DAsync(Y, ld * sizeof(double), w.Qo, m * sizeof(double), m * sizeof(double), l,
-                                 hipMemcpyDeviceToDevice, st_));
+      if (f == 0) {
+        hipk::cholqr2_apply(st_, Y, m, l, ld, w.Qo, ldt, R, base + o_small, ws);
+        check_launch("cholqr2_apply");
+        ++n_cholqr_;
+        return;
+      }
     }
     ++n_householder_;
     hipk::qr_thinQ(st_, Y, m, l, ld, R, w, ws);

@@ -50,8 +50,10 @@ void qr_thinQ(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, doubl
 
 // ---- cholqr.hip ----
 size_t cholqr_small_doubles(int64_t l);
-void cholqr2(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, double* R, double* small_ws,
-             int32_t* flag, double* gemm_ws);
+void cholqr2_factor(hipStream_t st, const double* Y, int64_t m, int64_t l, int64_t ld, double* T, int64_t ldt,
+                    double* small_ws, int32_t* flag, double* gemm_ws);
+void cholqr2_apply(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const double* T, int64_t ldt,
+                   double* R, double* small_ws, double* gemm_ws);
 
 // ---- jacobi_svd.hip ----
 struct SvdWork {

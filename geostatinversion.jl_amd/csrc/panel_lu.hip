@@ -22,8 +22,6 @@
 
 namespace gsi { namespace hipk {
 
-constexpr int LU_ROWS_PER_BLOCK_MIN = 256;
-
 int64_t lu_max_blocks(int64_t m) {
   int64_t rpt = (m + 256 * 1024 - 1) / (256 * 1024);
   if (rpt < 1) rpt = 1;
