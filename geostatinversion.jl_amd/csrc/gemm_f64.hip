@@ -400,6 +400,8 @@ static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_
 int gemm_choose_split(int64_t nwg, int64_t K) {
   constexpr int64_t CUS = 256;
   static const bool legacy = getenv("GSI_GEMM_SPLIT_LEGACY") != nullptr;   // A/B knob: fill-the-chip rule only
+  static const int forced = getenv("GSI_GEMM_FORCE_SPLIT") ? atoi(getenv("GSI_GEMM_FORCE_SPLIT")) : 0;   // experiments
+  if (forced > 0 && nwg >= 256 && K >= 64 * BK) return forced;
   if (legacy) {
     if (nwg >= 192 || K < 8 * BK) return 1;
     int64_t want = (CUS + nwg - 1) / nwg, cap = K / (4 * BK);
