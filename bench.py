@@ -71,6 +71,11 @@ def cpu_baseline_and_parity(gsi, ctx, K, p, q, grid=224, ell=14.0):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON result of rank 0): libraries that chat on fd 1 (gloo's
+    # "[Gloo] Rank 0 is connected ...", RCCL's version banner) are sent to stderr for the whole run.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -192,7 +197,7 @@ def main():
             out["xis_err_up_to_sign"] = xerr
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -111,6 +111,9 @@ class Comm {
   virtual void allreduce_sum(double* buf, size_t count) = 0;
   // every rank contributes `count` doubles; recv holds nranks*count, rank-major
   virtual void allgather(const double* send, double* recv, size_t count) = 0;
+  // send holds nranks blocks of `count` doubles (block g is destined for rank g); recv (count) = sum over ranks
+  // of their block `rank`
+  virtual void reduce_scatter_sum(const double* send, double* recv, size_t count) = 0;
 };
 
 // Provided by whichever backend is linked into the library.

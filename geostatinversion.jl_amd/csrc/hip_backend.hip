@@ -452,6 +452,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi& rccl() {
@@ -466,9 +467,10 @@ RcclApi& rccl() {
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
     api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
     api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
+    api.ReduceScatter = (decltype(api.ReduceScatter))dlsym(api.h, "ncclReduceScatter");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
   });
-  if (!api.h || !api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.AllGather)
+  if (!api.h || !api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.AllGather || !api.ReduceScatter)
     throw Error(GSI_ERR_RCCL, "librccl.so could not be loaded: multi-GPU needs RCCL");
   return api;
 }
@@ -505,6 +507,10 @@ class RcclComm : public Comm {
   void allgather(const double* send, double* recv, size_t count) override {
     be_->bind();
     RCCL_CHECK(rccl().AllGather(send, recv, count, ncclDouble, comm_, be_->stream()));
+  }
+  void reduce_scatter_sum(const double* send, double* recv, size_t count) override {
+    be_->bind();
+    RCCL_CHECK(rccl().ReduceScatter(send, recv, count, ncclDouble, ncclSum, comm_, be_->stream()));
   }
 
  private:

@@ -142,40 +142,99 @@ void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, dou
   gather_rows(c, A, Yloc.p, A.mloc, l, Z);
 }
 
+// Rows [r0n, r0n + nloc) (block layout of default_shard(A.n)) of W = A' * X, X given by this rank's rows Xloc.
+// Multi-rank only.  Dense / implicit: local partial over the rank's rows of A, packed by destination rank,
+// reduce-scattered (half the traffic of the all-reduce of op_mul_t, and nothing n x l is replicated).
+// LowRankCovMatrix: adjoint(A) === A and its rows are sharded like A's, so the local rows come out directly.
+static Buf op_mul_t_sharded(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, int64_t nloc) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  const int G = c.nranks();
+  const int64_t n = A.n, pad = (n + G - 1) / G;
+  if (A.kind == OP_LOWRANK) {
+    Buf T(be, (size_t)A.N * l);
+    {
+      ScopedPhase ph(be, PH_GEMM_T);
+      be->gemm_tn(A.N, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, T.p, A.N);
+    }
+    {
+      ScopedPhase ph(be, PH_COMM);
+      c.comm->allreduce_sum(T.p, (size_t)A.N * l);
+    }
+    Buf Wloc(be, (size_t)std::max<int64_t>(A.mloc, 1) * l);
+    ScopedPhase ph(be, PH_GEMM_N);
+    be->gemm_nn(A.mloc, l, A.N, 1.0 / (double)(A.N - 1), A.data.p, A.ld, T.p, A.N, 0.0, Wloc.p, A.mloc);
+    return Wloc;
+  }
+  Buf P(be, (size_t)n * l);
+  {
+    ScopedPhase ph(be, PH_GEMM_T);
+    if (A.mloc == 0)
+      be->fill_zero(P.p, (size_t)n * l);
+    else if (A.kind == OP_DENSE)
+      be->gemm_tn(n, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, P.p, n);       // RandMatFact.jl:85
+    else
+      be->gemm_nn_gridcov(n, l, A.mloc, A.data.p, A.gx, A.gy, 0, A.row0, Xloc, ldx, P.p, n);
+  }
+  Buf send(be, (size_t)pad * l * G), recv(be, (size_t)pad * l);
+  if (pad * G != n) be->fill_zero(send.p, (size_t)pad * l * G);
+  for (int g = 0; g < G; ++g) {
+    int64_t r0, ml;
+    default_shard(n, G, g, &r0, &ml);
+    if (ml > 0) be->copy2d(send.p + (size_t)g * pad * l, pad, P.p + r0, n, ml, l);
+  }
+  P.reset();
+  {
+    ScopedPhase ph(be, PH_COMM);
+    c.comm->reduce_scatter_sum(send.p, recv.p, (size_t)pad * l);
+  }
+  if (nloc == pad) return recv;
+  Buf Wloc(be, (size_t)std::max<int64_t>(nloc, 1) * l);
+  be->copy2d(Wloc.p, nloc, recv.p, pad, nloc, l);
+  return Wloc;
+}
+
 static void lu_panel(Context& c, double* Y, int64_t rows, int64_t l) {
   ScopedPhase ph(c.be.get(), PH_LU);
   c.be->lu_L(Y, rows, l, rows, nullptr);   // F = lu(Y); Q = F.L   RandMatFact.jl:60-61,68-69,72-73
 }
 
-// thin orthonormal basis of the row-sharded panel Yloc (mloc x l, ld mloc), in place / swapped
-static void tsqr(Context& c, const Operator& A, Buf& Yloc, int64_t l) {
+static bool all_shards_tall(int64_t m, int G, int64_t l) {
+  for (int g = 0; g < G; ++g) {
+    int64_t r0, ml;
+    default_shard(m, G, g, &r0, &ml);
+    if (ml < l) return false;
+  }
+  return true;
+}
+
+// thin orthonormal basis of a row-sharded panel: this rank holds rows [row0, row0 + mloc) of the m x l panel in
+// Yloc (ld mloc), block layout of default_shard(m).  In place / swapped.  Rout (may be null): the l x l
+// triangular factor of the WHOLE panel, replicated.
+static void tsqr(Context& c, int64_t m, int64_t row0, int64_t mloc, Buf& Yloc, int64_t l, double* Rout) {
   Backend* be = c.be.get();
   const int G = c.nranks();
   if (G == 1) {
     ScopedPhase ph(be, PH_QR);
-    be->qr_thinQ(Yloc.p, A.mloc, l, A.mloc, nullptr);   // qr(Y, Val(true)) -> Matrix(F.Q)  :57-58,75-76
+    be->qr_thinQ(Yloc.p, mloc, l, mloc, Rout);   // qr(Y, Val(true)) -> Matrix(F.Q)  :57-58,75-76
     return;
   }
-  bool all_tall = true;
-  for (int g = 0; g < G; ++g) {
-    int64_t r0, ml;
-    default_shard(A.m, G, g, &r0, &ml);
-    if (ml < l) all_tall = false;
-  }
-  if (!all_tall) {  // a shard shorter than the sketch width: factor the gathered panel everywhere
-    Buf Yfull(be, (size_t)A.m * l);
-    gather_rows(c, A, Yloc.p, A.mloc, l, Yfull.p);
+  if (!all_shards_tall(m, G, l)) {  // a shard shorter than the sketch width: factor the gathered panel everywhere
+    Operator shape;
+    shape.m = m; shape.row0 = row0; shape.mloc = mloc;
+    Buf Yfull(be, (size_t)m * l);
+    gather_rows(c, shape, Yloc.p, mloc, l, Yfull.p);
     {
       ScopedPhase ph(be, PH_QR);
-      be->qr_thinQ(Yfull.p, A.m, l, A.m, nullptr);
+      be->qr_thinQ(Yfull.p, m, l, m, Rout);
     }
-    be->copy2d(Yloc.p, A.mloc, Yfull.p + A.row0, A.m, A.mloc, l);
+    be->copy2d(Yloc.p, mloc, Yfull.p + row0, m, mloc, l);
     return;
   }
   Buf R(be, (size_t)l * l), Rall(be, (size_t)l * l * G), stack(be, (size_t)l * l * G);
   {
     ScopedPhase ph(be, PH_QR);
-    be->qr_thinQ(Yloc.p, A.mloc, l, A.mloc, R.p);
+    be->qr_thinQ(Yloc.p, mloc, l, mloc, R.p);
   }
   {
     ScopedPhase ph(be, PH_COMM);
@@ -185,15 +244,16 @@ static void tsqr(Context& c, const Operator& A, Buf& Yloc, int64_t l) {
   for (int g = 0; g < G; ++g) be->copy2d(stack.p + (int64_t)g * l, sl, Rall.p + (size_t)g * l * l, l, l, l);
   {
     ScopedPhase ph(be, PH_QR);
-    be->qr_thinQ(stack.p, sl, l, sl, nullptr);
+    be->qr_thinQ(stack.p, sl, l, sl, Rout);
   }
-  Buf Qn(be, (size_t)A.mloc * l);
+  Buf Qn(be, (size_t)mloc * l);
   {
     ScopedPhase ph(be, PH_SMALL_GEMM);
-    be->gemm_nn(A.mloc, l, l, 1.0, Yloc.p, A.mloc, stack.p + (int64_t)c.rank() * l, sl, 0.0, Qn.p, A.mloc);
+    be->gemm_nn(mloc, l, l, 1.0, Yloc.p, mloc, stack.p + (int64_t)c.rank() * l, sl, 0.0, Qn.p, mloc);
   }
   Yloc = std::move(Qn);
 }
+static void tsqr(Context& c, const Operator& A, Buf& Yloc, int64_t l) { tsqr(c, A.m, A.row0, A.mloc, Yloc, l, nullptr); }
 
 Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
   Context& c = *A.ctx;
@@ -260,6 +320,31 @@ void randsvd(const Operator& A, const double* Omega, int64_t K, int64_t p, int64
   if (K < 0 || p < 0 || K + p < 1) throw Error(GSI_ERR_ARG, "randsvd: need K >= 0, p >= 0, K + p >= 1");
   const int64_t l = K + p;
   Buf Q = rangefinder(A, Omega, l, q);                      // Q = rangefinder(A, K+p, q)     :84
+  const int G = c.nranks();
+  if (c.comm && all_shards_tall(A.n, G, l) && (A.kind != OP_LOWRANK || A.m == A.n)) {   // any communicator, also 1 rank
+    // svd(B) row-sharded: W = B' = A'Q never exists whole.  TSQR of its row blocks gives the l x l factor
+    // everywhere; the small SVD is replicated; each rank forms its rows of Z and the blocks are gathered.
+    int64_t r0n, nloc;
+    default_shard(A.n, G, c.rank(), &r0n, &nloc);
+    Buf Wloc = op_mul_t_sharded(A, Q.p, A.mloc, l, nloc);    // B = Q'*A (rows of B')                :85
+    Q.reset();
+    Buf R(be, (size_t)l * l), U(be, (size_t)l * l);
+    tsqr(c, A.n, r0n, nloc, Wloc, l, R.p);
+    {
+      ScopedPhase ph(be, PH_SVD);
+      be->svd_small(R.p, l, U.p, S);                         // (), S, V = svd(B)                    :86
+      be->scale_cols_sqrt(U.p, l, S, K);                     // Sh = sqrt([S[1:K]; zeros(p)])        :87
+    }
+    Buf Zloc(be, (size_t)nloc * l);
+    {
+      ScopedPhase ph(be, PH_SMALL_GEMM);
+      be->gemm_nn(nloc, l, l, 1.0, Wloc.p, nloc, U.p, l, 0.0, Zloc.p, nloc);   // Z = V*Sh            :88
+    }
+    Operator shape;
+    shape.m = A.n; shape.row0 = r0n; shape.mloc = nloc;
+    gather_rows(c, shape, Zloc.p, nloc, l, Z);
+    return;
+  }
   Buf W(be, (size_t)A.n * l);
   op_mul_t(A, Q.p, A.mloc, l, W.p, A.n);                    // B = Q'*A  (held as B' = A'Q)   :85
   Q.reset();

@@ -181,6 +181,12 @@ class CallbackComm : public Comm {
     if (!g_allgather) throw Error(GSI_ERR_RCCL, "cpuref: collectives not registered");
     g_allgather(send, recv, (int64_t)count);
   }
+  void reduce_scatter_sum(const double* send, double* recv, size_t count) override {   // all-reduce, keep own block
+    if (!g_allreduce) throw Error(GSI_ERR_RCCL, "cpuref: collectives not registered");
+    std::vector<double> tmp(send, send + count * (size_t)nranks);
+    g_allreduce(tmp.data(), (int64_t)tmp.size());
+    std::memcpy(recv, tmp.data() + count * (size_t)rank, count * sizeof(double));
+  }
 };
 }  // namespace
 

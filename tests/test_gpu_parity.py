@@ -393,6 +393,7 @@ A = gaussian_cov(20, 15, 3.0); rng = np.random.default_rng(1); Om = rng.standard
 Z1, S1 = gsi.randsvd(A, 14, 6, 2, Omega=Om, return_S=True, ctx=ctx)
 fields = powerlaw_fields(rng, (12, 12), 30); Om2 = rng.standard_normal((144, 12))
 lr = gsi.LowRankCovMatrix(fields, ctx=ctx); Z3 = gsi.randsvd(lr, 8, 4, 3, Omega=Om2)
+gi = gsi.gridcov_implicit_operator(ctx, 20, 15, 3.0); Z5 = gsi.randsvd(gi, 14, 6, 2, Omega=Om)
 del os.environ["GSI_FORCE_COMM"]
 ctx2 = gsi.Context(0)
 Z2, S2 = gsi.randsvd(A, 14, 6, 2, Omega=Om, return_S=True, ctx=ctx2)
@@ -400,6 +401,7 @@ lr2 = gsi.LowRankCovMatrix(fields, ctx=ctx2); Z4 = gsi.randsvd(lr2, 8, 4, 3, Ome
 assert np.abs(S1 - S2).max() < 1e-12 * S2[0], np.abs(S1 - S2).max()
 assert np.abs(Z1 - Z2).max() < 1e-9
 assert np.abs(Z3 - Z4).max() < 1e-9
+assert np.abs(Z5 @ Z5.T - Z2 @ Z2.T).max() < 1e-9
 print("rccl-1rank-ok")
 '''
     env = dict(os.environ)
