@@ -74,10 +74,11 @@ struct GenA {
   int64_t koff;       // global index of reduction index 0
 };
 
-// RAGGED: the sketch width is not a multiple of 16 (K + p is the caller's choice), so the last columns of the
-// X tile do not exist.  A separate instantiation keeps the 16-byte stream of the operator and predicates the X
-// pairs per column (measured at l = 150: 28.0 -> 21.8 ms); folding that into the full-width kernel as a
-// second fast path cost the full-width case 2.7 %, hence the template parameter.
+// RAGGED: the "irregular X" instantiation.  Either the sketch width is not a multiple of 16 (K + p is the
+// caller's choice), so the last columns of the X tile do not exist, or X is only 8-byte aligned (n odd as its
+// leading dimension).  It keeps the 16-byte stream of the operator and loads the X pairs per column, predicated,
+// with 8-byte alignment (measured at l = 150: 28.0 -> 21.3 ms); folding that into the regular kernel as a
+// second fast path cost the regular case 2.7 %, hence the template parameter.
 template <int NT, bool TRANS_A, bool GEN, bool RAGGED>
 __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     int64_t M, int64_t L, int64_t K, const double* __restrict__ A, int64_t lda,
@@ -197,10 +198,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 #pragma unroll
         for (int it = 0; it < B_PAIRS; ++it) {
           const int cl = b_c + RSTEP * it;
-          if (cl < NT * 16 && c0 + cl < L)
-            b_reg[set][it] = *reinterpret_cast<const double2*>(Bb + (b_off0 + (uint32_t)it * b_step));
-          else
+          if (cl < NT * 16 && c0 + cl < L) {   // X may be only 8-byte aligned here (odd n as leading dimension)
+            typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+            const double2_u v = *reinterpret_cast<const double2_u*>(Bb + (b_off0 + (uint32_t)it * b_step));
+            b_reg[set][it] = make_double2(v.x, v.y);
+          } else {
             b_reg[set][it] = make_double2(0.0, 0.0);
+          }
         }
         return;
       }
@@ -395,10 +399,10 @@ template <bool TRANS_A, bool GEN>
 static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K,
                             const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
                             int64_t ldc, double alpha, double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide,
-                            const GenA& gen) {
+                            bool irregular_x, const GenA& gen) {
 #define GSI_CASE(N)                                                                             \
   case N:                                                                                       \
-    if (L % (N * 16) != 0)                                                                        \
+    if (irregular_x)                                                                              \
       launch_nt<N, TRANS_A, GEN, true>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
     else                                                                                          \
       launch_nt<N, TRANS_A, GEN, false>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
@@ -462,14 +466,19 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   dim3 grid((unsigned)(rowblocks * nchunks), (unsigned)ns_eff, 1);
   double* slabs = (ns_eff > 1) ? ws : nullptr;
   // 16-byte loads need 16-B aligned bases and even leading dimensions (sub-panel views often are not)
-  const int wide = (((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && (lda & 1) == 0 && (ldb & 1) == 0) ? 1 : 0;
+  const bool a_ok = ((uintptr_t)A & 15) == 0 && (lda & 1) == 0;
+  const bool b_ok = ((uintptr_t)B & 15) == 0 && (ldb & 1) == 0;
+  // regular kernel: everything 16-byte loadable and full 16-column tiles; irregular-X kernel: the operator is,
+  // X is ragged or only 8-byte aligned; otherwise (operator itself unaligned) the element-wise path of the regular one
+  const bool irregular_x = a_ok && (!b_ok || L % ((int64_t)nt * 16) != 0);
+  const int wide = a_ok && (b_ok || irregular_x) ? 1 : 0;
   const GenA none = {nullptr, nullptr, 1, 0, 0, 0};
   if (gen != nullptr)
-    launch_dispatch<false, true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, *gen);
+    launch_dispatch<false, true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, irregular_x, *gen);
   else if (transA)
-    launch_dispatch<true, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, none);
+    launch_dispatch<true, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, irregular_x, none);
   else
-    launch_dispatch<false, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, none);
+    launch_dispatch<false, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, irregular_x, none);
   if (ns_eff > 1) {
     const int64_t total = M * L;
     int blocks = (int)((total + 255) / 256);

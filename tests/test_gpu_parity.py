@@ -24,7 +24,8 @@ def ctx(gsi):
 
 # ---- MFMA products ----------------------------------------------------------------------
 @pytest.mark.parametrize("m,k,l", [(64, 32, 16), (100, 77, 5), (257, 130, 48), (1000, 999, 160),
-                                   (2000, 2000, 161), (33, 4000, 320), (5000, 64, 33)])
+                                   (2000, 2000, 161), (33, 4000, 320), (5000, 64, 33),
+                                   (1025, 777, 150), (513, 2049, 100), (4099, 1283, 37)])
 def test_gemm_nn_tn(gsi, ctx, m, k, l):
     rng = np.random.default_rng(m * 7 + k)
     A = rng.standard_normal((m, k))
@@ -530,6 +531,20 @@ def test_implicit_gridcov_randsvd(gsi, ctx):
     assert orc.xis_error_up_to_sign(Z, Zr, K) < 1e-6
     assert np.all(Z[:, K:] == 0)
     impl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,K,p", [(33, 35, 40, 10), (47, 21, 100, 20), (64, 33, 23, 0)])
+def test_randsvd_odd_n_ragged_l(gsi, ctx, nx, ny, K, p):
+    """n odd (X panels only 8-byte aligned) and K + p not a multiple of 16: the irregular-X instantiation of the
+    contraction kernel carries every operator product; result against the oracle."""
+    n = nx * ny
+    A = gaussian_cov(nx, ny, 2.5) + 0.05 * exponential_cov(nx, ny, 6.0)
+    Om = np.random.default_rng(n).standard_normal((n, K + p))
+    Z, S = gsi.randsvd(A, K, p, 2, Omega=Om, return_S=True, ctx=ctx)
+    Zr, Sr, _ = orc.randsvd_full(A, K, p, 2, Om)
+    assert np.abs(S[:K] - Sr[:K]).max() < 1e-10 * Sr[0]
+    assert np.abs(Z @ Z.T - Zr @ Zr.T).max() < 1e-8 * Sr[0]
 
 
 @pytest.mark.gpu
