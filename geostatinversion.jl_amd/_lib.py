@@ -87,7 +87,7 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("GSI_HIP_LIB") or LIB_PATH     # GSI_HIP_LIB: another build of the same library (A/B runs)
     if not os.path.exists(p):
         raise ImportError(
             f"{p} not found: build it with `python {os.path.join(_HERE, 'build.py')}` (needs hipcc). "

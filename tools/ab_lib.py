@@ -6,14 +6,16 @@ import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gsi_amd as gsi
 ap = argparse.ArgumentParser()
-ap.add_argument("other")
+ap.add_argument("others", nargs="+")
 ap.add_argument("--grid", type=int, default=256)
 ap.add_argument("--l", type=int, default=160)
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
 n = a.grid * a.grid
-libs = {"new": gsi._lib.load(), "old": gsi._lib.load(os.path.abspath(a.other))}
+libs = {"shipped": gsi._lib.load()}
+for o in a.others:
+    libs[os.path.basename(o)] = gsi._lib.load(os.path.abspath(o))
 st = {}
 for name, lib in libs.items():
     ctx = gsi.Context(0, lib=lib)
@@ -21,7 +23,8 @@ for name, lib in libs.items():
                 gsi.DeviceMatrix(ctx, n, a.l))
 tot = {k: [0.0, 0.0] for k in libs}
 for r in range(a.rounds):
-    for name in ("new", "old") if r % 2 == 0 else ("old", "new"):
+    order = list(libs)
+    for name in (order if r % 2 == 0 else order[::-1]):
         ctx, op, X, Y = st[name]
         lib = ctx.lib
         for trans in (0, 1):
@@ -33,4 +36,4 @@ for r in range(a.rounds):
             key = "gemm_t" if trans else "gemm_n"
             tot[name][trans] += ph[key][0] / ph[key][1]
 for name in libs:
-    print(name, f"l={a.l}: NN {tot[name][0]/a.rounds:.3f} ms  TN {tot[name][1]/a.rounds:.3f} ms", flush=True)
+    print(f"{name:18s}", f"l={a.l}: NN {tot[name][0]/a.rounds:.3f} ms  TN {tot[name][1]/a.rounds:.3f} ms", flush=True)
