@@ -25,7 +25,7 @@ struct LuWork {
   int32_t* info;       // [1] first exactly-zero pivot (1-based), 0 if none
   int64_t maxblocks;
 };
-constexpr int LU_NB = 32;     // outer block (trailing update through the MFMA GEMM)
+constexpr int LU_NB = 64;     // widest outer block (trailing update through the MFMA GEMM): very tall panels; 32 otherwise
 constexpr int LU_LEAF = 8;    // columns factored by per-column sweeps; blocks in between are split recursively
 int64_t lu_max_blocks(int64_t m);
 void lu_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const LuWork& w, double* gemm_ws);
