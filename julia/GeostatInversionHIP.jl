@@ -104,6 +104,18 @@ function LowRankCovMatrix(samples::Array{Array{Float64, 1}, 1}; c::Context=ctx()
 	return op
 end
 
+"Gaussian covariance exp(-d^2/(2 ell^2)) of an nx x ny unit grid as a matrix-free operator: entries are regenerated
+inside the product kernel, nothing of size n^2 is stored (`gsi_op_gridcov_implicit`).  Usable wherever a Matrix is."
+function GridCovImplicit(nx::Int, ny::Int, ell::Float64; c::Context=ctx())
+	r = Ref{Ptr{Cvoid}}(C_NULL)
+	check(ccall((:gsi_op_gridcov_implicit, libgsi), Cint,
+		(Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Int64, Int64, Cdouble, Int64, Int64),
+		c.h, r, nx, ny, ell, 0, nx * ny))
+	op = DeviceOperator(r[], c, nx * ny, nx * ny)
+	finalizer(finalize_op!, op)
+	return op
+end
+
 Base.size(A::DeviceOperator) = (A.m, A.n)
 function Base.size(A::DeviceOperator, i::Int)
 	(i == 1 || i == 2) || error("there is no $i-th dimension in a DeviceOperator")   # lowrank.jl:58
