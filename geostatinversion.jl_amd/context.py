@@ -72,7 +72,7 @@ class Context:
     def counters(self):
         out = (C.c_int64 * 4)()
         L.check(self.lib.gsi_ctx_counters(self.h, out), self.lib)
-        return {"cholqr2": out[0], "householder": out[1], "jacobi_sweeps": out[2]}
+        return {"cholqr2": out[0], "householder": out[1], "jacobi_sweeps": out[2], "scholqr3": out[3]}
 
     def device_bytes(self):
         b = C.c_int64()

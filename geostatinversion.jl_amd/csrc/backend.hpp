@@ -100,7 +100,7 @@ class Backend {
   virtual void phase_reset() = 0;
   virtual void phase_times(double* ms, int64_t* counts) = 0;
   // [0] CholeskyQR2 factorizations, [1] Householder factorizations (incl. fallbacks), [2] Jacobi sweeps of
-  // the last small SVD, [3] reserved
+  // the last small SVD, [3] shifted CholeskyQR3 factorizations
   virtual void counters(int64_t* out4) { out4[0] = out4[1] = out4[2] = out4[3] = 0; }
 };
 

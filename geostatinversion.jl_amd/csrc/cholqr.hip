@@ -171,16 +171,37 @@ __global__ void cq_identity_kernel(double* __restrict__ X, int l) {
     X[e] = (e % l == e / l) ? 1.0 : 0.0;
 }
 
+// G_ii += s: the shift of shifted CholeskyQR3 (Fukaya, Kannan, Nakatsukasa, Yamamoto, Yanagisawa 2020).  With
+// chol(G + sI) the first round cannot break down and Y R^-1 has a condition number of order sqrt(s)/sigma_min,
+// which two further plain rounds finish.  The paper's s = 11 (m l + l (l + 1)) u |Y|^2 is a worst-case bound on
+// the rounding error of the Gram matrix; here s = 4 l sqrt(m) u trace(G) (the probabilistic size of that error,
+// u = 2^-53, trace(G) = |Y|_F^2), which extends the reach from cond ~1e11 to ~1e13: if it is ever too small the
+// Cholesky pivots flag it and the caller falls back -- a wrong guess costs time, never accuracy.
+__global__ __launch_bounds__(256) void cq_shift_kernel(double* __restrict__ G, int l, double m) {
+  __shared__ double s[256];
+  double tr = 0.0;
+  for (int i = threadIdx.x; i < l; i += 256) tr += G[i + (int64_t)i * l];
+  s[threadIdx.x] = tr;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  const double shift = 4.0 * (double)l * sqrt(m) * (0.5 * DBL_EPSILON) * s[0];
+  for (int i = threadIdx.x; i < l; i += 256) G[i + (int64_t)i * l] += shift;
+}
+
 size_t cholqr_small_doubles(int64_t l) {
   const int64_t nblk = (l + CQ_TB - 1) / CQ_TB;
-  return (size_t)(5 * l * l + nblk * CQ_TB * CQ_TB + 64);
+  return (size_t)(7 * l * l + nblk * CQ_TB * CQ_TB + 64);
 }
 
 namespace {
-struct CqBufs { double *R1, *R2, *Gt, *X1, *X2, *Rinv; };
+struct CqBufs { double *R1, *R2, *R3, *Gt, *X1, *X2, *X3, *Rinv; };
 inline CqBufs cq_bufs(double* small, int l) {
   const size_t ll = (size_t)l * l;
-  return {small, small + ll, small + 2 * ll, small + 3 * ll, small + 4 * ll, small + 5 * ll};
+  return {small, small + ll, small + 2 * ll, small + 3 * ll, small + 4 * ll, small + 5 * ll, small + 6 * ll,
+          small + 7 * ll};
 }
 
 // One round: Rp <- chol(src' src) (upper), X <- Rp^-1 (explicit, l x l), dst <- src X.
@@ -188,11 +209,12 @@ inline CqBufs cq_bufs(double* small, int l) {
 // is ONE pass over the panel for Y R^-1 (read src, write dst) instead of a blocked in-place solve that re-reads
 // the already solved block columns for every later one (l/64 panel reads), and an untouched src.
 void cq_round(hipStream_t st, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t m, int l, double* Rp,
-              double* X, const CqBufs& b, bool check, int32_t* flag, double* gemm_ws, bool apply) {
+              double* X, const CqBufs& b, bool check, int32_t* flag, double* gemm_ws, bool apply, bool shift = false) {
   const int nblk = (l + CQ_TB - 1) / CQ_TB;
   gemm_f64(st, true, l, l, m, 1.0, src, lds, src, lds, 0.0, Rp, l, gemm_ws);          // G = Y'Y
   if (check)
     hipLaunchKernelGGL(cq_orth_check_kernel, dim3(grid_for((int64_t)l * l, 64)), dim3(256), 0, st, Rp, l, 0.1, flag);
+  if (shift) hipLaunchKernelGGL(cq_shift_kernel, dim3(1), dim3(256), 0, st, Rp, l, (double)m);
   // R = chol(G), blocked: per 32-column block one small kernel (diagonal block + its inverse + block
   // row) and one MFMA GEMM for the trailing update; the block inverses are what the solve below needs
   hipLaunchKernelGGL(cq_diagmax_kernel, dim3(1), dim3(256), 0, st, Rp, l, b.Gt);
@@ -238,6 +260,31 @@ void cholqr2_apply(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld
   gemm_f64(st, false, m, l, l, 1.0, T, ldt, b.X2, l, 0.0, Y, ld, gemm_ws);
   if (R != nullptr)
     hipLaunchKernelGGL(cq_triprod_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, b.R2, b.R1, l, R);
+}
+
+// Shifted CholeskyQR3, the tier between CholeskyQR2 and Householder: panels with cond up to ~1e15 (sketches of
+// fast-decaying covariance spectra after the power iterations).  Y -> T (shifted round) -> S (plain round); third
+// Gram matrix, its orthogonality check, R3 and R3^-1.  Y is NOT modified.  Afterwards flag != 0 means "not trusted".
+void scholqr3_factor(hipStream_t st, const double* Y, int64_t m, int64_t l64, int64_t ld, double* T, int64_t ldt,
+                     double* S, int64_t lds_, double* small, int32_t* flag, double* gemm_ws) {
+  const int l = (int)l64;
+  const CqBufs b = cq_bufs(small, l);
+  cq_round(st, Y, ld, T, ldt, m, l, b.R1, b.X1, b, false, flag, gemm_ws, true, true);
+  cq_round(st, T, ldt, S, lds_, m, l, b.R2, b.X2, b, false, flag, gemm_ws, true);
+  cq_round(st, S, lds_, nullptr, 0, m, l, b.R3, b.X3, b, true, flag, gemm_ws, false);
+}
+
+// after the host has read flag == 0: Y <- S R3^-1, R (may be null) <- R3 R2 R1
+void scholqr3_apply(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld, const double* S, int64_t lds_,
+                    double* R, double* small, double* gemm_ws) {
+  const int l = (int)l64;
+  const CqBufs b = cq_bufs(small, l);
+  gemm_f64(st, false, m, l, l, 1.0, S, lds_, b.X3, l, 0.0, Y, ld, gemm_ws);
+  if (R != nullptr) {
+    const int g = grid_for((int64_t)l * l, 256);
+    hipLaunchKernelGGL(cq_triprod_kernel, dim3(g), dim3(256), 0, st, b.R2, b.R1, l, b.X1);   // X1 is free: R2 R1
+    hipLaunchKernelGGL(cq_triprod_kernel, dim3(g), dim3(256), 0, st, b.R3, b.X1, l, R);
+  }
 }
 
 }}  // namespace gsi::hipk

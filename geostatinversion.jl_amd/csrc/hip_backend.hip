@@ -246,25 +246,52 @@ class HipBackend : public Backend {
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, 32, l));      //             : the l x l inverse
     for (int64_t t = NB; t <= l; t += NB) gmax = std::max(gmax, hipk::gemm_workspace_doubles(t, NB, m));
     double* ws = gemm_ws(gmax + 64);
-    // First choice: CholeskyQR2 (a handful of MFMA GEMM passes).  It needs a numerically full-rank,
-    // moderately conditioned panel; the kernels raise a flag otherwise and we redo the panel with
-    // Householder reflectors from the saved copy.
+    // Three tiers, each leaving Y untouched until it is known to have worked (one 4-byte flag read):
+    //   CholeskyQR2 (a handful of MFMA passes; needs cond(Y) < ~1e7), shifted CholeskyQR3 (cond up to ~1e13: sketches
+    //   of fast-decaying covariance spectra), Householder reflectors (anything, including exact rank deficiency).
+    // A panel that needed the second tier makes the next few factorizations start there: consecutive panels of one
+    // operator are alike, and a failed first attempt costs ~1.2 ms at C2.
     static const bool no_cholqr = (getenv("GSI_NO_CHOLQR") != nullptr);
     if (!no_cholqr && l <= 1024 && m >= 2 * l) {
-      // both rounds run out of place (Y -> Qo -> Y); Y is only overwritten once the flag is known to be clear
-      HIP_CHECK(hipMemsetAsync(flags_ + 9, 0, sizeof(int32_t), st_));
       const int64_t ldt = (m + 1) & ~(int64_t)1;   // even: 16-byte loads in the contraction kernel
-      hipk::cholqr2_factor(st_, Y, m, l, ld, w.Qo, ldt, base + o_small, flags_ + 9, ws);
-      check_launch("cholqr2_factor");
       int32_t f = 0;
-      HIP_CHECK(hipMemcpyAsync(&f, flags_ + 9, sizeof(int32_t), hipMemcpyDeviceToHost, st_));
-      HIP_CHECK(hipStreamSynchronize(st_));
-      if (f == 0) {
-        hipk::cholqr2_apply(st_, Y, m, l, ld, w.Qo, ldt, R, base + o_small, ws);
-        check_launch("cholqr2_apply");
-        ++n_cholqr_;
-        return;
+      if (skip_tier1_ > 0) {
+        --skip_tier1_;
+      } else {
+        // both rounds run out of place (Y -> Qo -> Y); Y is only overwritten once the flag is known to be clear
+        HIP_CHECK(hipMemsetAsync(flags_ + 9, 0, sizeof(int32_t), st_));
+        hipk::cholqr2_factor(st_, Y, m, l, ld, w.Qo, ldt, base + o_small, flags_ + 9, ws);
+        check_launch("cholqr2_factor");
+        HIP_CHECK(hipMemcpyAsync(&f, flags_ + 9, sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        if (f == 0) {
+          hipk::cholqr2_apply(st_, Y, m, l, ld, w.Qo, ldt, R, base + o_small, ws);
+          check_launch("cholqr2_apply");
+          ++n_cholqr_;
+          return;
+        }
+        skip_tier1_ = 8;
       }
+      // second tier: shifted CholeskyQR3 with one more transient panel; Y still untouched
+      static const bool no_scholqr3 = (getenv("GSI_NO_SCHOLQR3") != nullptr);
+      double* S2 = nullptr;
+      if (!no_scholqr3) {
+        try { S2 = alloc((size_t)ldt * l); } catch (const Error&) { S2 = nullptr; }
+      }
+      if (S2 != nullptr) {
+        HIP_CHECK(hipMemsetAsync(flags_ + 9, 0, sizeof(int32_t), st_));
+        hipk::scholqr3_factor(st_, Y, m, l, ld, w.Qo, ldt, S2, ldt, base + o_small, flags_ + 9, ws);
+        check_launch("scholqr3_factor");
+        HIP_CHECK(hipMemcpyAsync(&f, flags_ + 9, sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        if (f == 0) {
+          hipk::scholqr3_apply(st_, Y, m, l, ld, S2, ldt, R, base + o_small, ws);
+          check_launch("scholqr3_apply");
+        }
+        release(S2);     // stream-ordered pool: reuse only by later work on this stream
+        if (f == 0) { ++n_scholqr3_; return; }
+      }
+      skip_tier1_ = 0;   // neither Cholesky tier applies to this kind of panel: probe from the top next time
     }
     ++n_householder_;
     hipk::qr_thinQ(st_, Y, m, l, ld, R, w, ws);
@@ -392,7 +419,7 @@ class HipBackend : public Backend {
   }
 
   void counters(int64_t* out4) override {
-    out4[0] = n_cholqr_; out4[1] = n_householder_; out4[2] = last_svd_sweeps_; out4[3] = 0;
+    out4[0] = n_cholqr_; out4[1] = n_householder_; out4[2] = last_svd_sweeps_; out4[3] = n_scholqr3_;
   }
   int device() const { return device_; }
 
@@ -441,7 +468,8 @@ class HipBackend : public Backend {
   double acc_ms_[PH_COUNT] = {0};
   int64_t acc_n_[PH_COUNT] = {0};
   int last_svd_sweeps_ = 0;
-  int64_t n_cholqr_ = 0, n_householder_ = 0;
+  int64_t n_cholqr_ = 0, n_householder_ = 0, n_scholqr3_ = 0;
+  int skip_tier1_ = 0;
 };
 
 // ---- RCCL, bound lazily so a single-GPU user never needs librccl to resolve -----------------

@@ -54,6 +54,10 @@ void cholqr2_factor(hipStream_t st, const double* Y, int64_t m, int64_t l, int64
                     double* small_ws, int32_t* flag, double* gemm_ws);
 void cholqr2_apply(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const double* T, int64_t ldt,
                    double* R, double* small_ws, double* gemm_ws);
+void scholqr3_factor(hipStream_t st, const double* Y, int64_t m, int64_t l, int64_t ld, double* T, int64_t ldt,
+                     double* S, int64_t lds, double* small_ws, int32_t* flag, double* gemm_ws);
+void scholqr3_apply(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const double* S, int64_t lds,
+                    double* R, double* small_ws, double* gemm_ws);
 
 // ---- jacobi_svd.hip ----
 struct SvdWork {

@@ -413,24 +413,31 @@ print("rccl-1rank-ok")
 
 
 # ---- CholeskyQR2 fast path and its Householder fall-back -------------------------------------------------
-@pytest.mark.parametrize("cond,expect_fast", [(1e0, True), (1e4, True), (1e10, False)])
-def test_qr_paths(gsi, ctx, cond, expect_fast):
-    rng = np.random.default_rng(int(np.log10(cond)) + 3)
+def test_qr_paths(gsi):
+    """CholeskyQR2 for well conditioned panels, shifted CholeskyQR3 beyond (fast-decaying spectra), Householder as
+    the last resort; all three give an orthonormal Q and Y = Q R to rounding.  A panel that needed the second tier
+    makes the following factorizations start there (own context: the hint is per-context state)."""
+    c = gsi.Context(0)
     m, l = 4096, 96
-    U, _ = np.linalg.qr(rng.standard_normal((m, l)))
-    V, _ = np.linalg.qr(rng.standard_normal((l, l)))
-    Y = (U * np.logspace(0, -np.log10(cond), l)) @ V.T
-    before = ctx.counters()
-    Q, R = gsi.qr_thinQ(Y, return_R=True)
-    after = ctx.counters()
-    assert (after["cholqr2"] - before["cholqr2"] == 1) == expect_fast
-    assert (after["householder"] - before["householder"] == 1) == (not expect_fast)
-    assert np.abs(Q.T @ Q - np.eye(l)).max() < 1e-13
-    assert np.abs(Q @ R - Y).max() < 1e-13 * l
-    assert np.abs(np.tril(R, -1)).max() == 0.0
-    s = np.linalg.svd(R, compute_uv=False)
-    sref = np.linalg.svd(Y, compute_uv=False)
-    assert np.abs(s - sref).max() < 1e-13 * sref[0]       # absolute O(eps*sigma_1), like Householder / dgesdd
+    seq = [(1e0, "cholqr2"), (1e4, "cholqr2"), (1e10, "scholqr3"), (1e12, "scholqr3"), (1e15, "householder"),
+           (1e0, "cholqr2")]
+    for cond, path in seq:
+        rng = np.random.default_rng(int(np.log10(cond)) + 3)
+        U, _ = np.linalg.qr(rng.standard_normal((m, l)))
+        V, _ = np.linalg.qr(rng.standard_normal((l, l)))
+        Y = (U * np.logspace(0, -np.log10(cond), l)) @ V.T
+        before = c.counters()
+        Q, R = gsi.qr_thinQ(Y, return_R=True, ctx=c)
+        after = c.counters()
+        for k in ("cholqr2", "scholqr3", "householder"):
+            assert after[k] - before[k] == (1 if k == path else 0), (cond, k, before, after)
+        assert np.abs(Q.T @ Q - np.eye(l)).max() < 1e-13
+        assert np.abs(Q @ R - Y).max() < 1e-13 * l
+        assert np.abs(np.tril(R, -1)).max() == 0.0
+        s = np.linalg.svd(R, compute_uv=False)
+        sref = np.linalg.svd(Y, compute_uv=False)
+        assert np.abs(s - sref).max() < 1e-13 * sref[0]       # absolute O(eps*sigma_1), like Householder / dgesdd
+    c.close()
 
 
 def test_qr_rank_deficient_falls_back(gsi, ctx):
