@@ -283,6 +283,7 @@ class HipBackend : public Backend {
         try { S2 = alloc((size_t)ldt * l); } catch (const Error&) { S2 = nullptr; }
       }
       if (S2 != nullptr) {
+        struct Guard { HipBackend* be; double* p; ~Guard() { be->release(p); } } guard{this, S2};   // stream-ordered pool
         HIP_CHECK(hipMemsetAsync(flags_ + 9, 0, sizeof(int32_t), st_));
         hipk::scholqr3_factor(st_, Y, m, l, ld, w.Qo, ldt, S2, ldt, base + o_small, flags_ + 9, ws);
         check_launch("scholqr3_factor");
@@ -292,7 +293,6 @@ class HipBackend : public Backend {
           hipk::scholqr3_apply(st_, Y, m, l, ld, S2, ldt, R, base + o_small, ws);
           check_launch("scholqr3_apply");
         }
-        release(S2);     // stream-ordered pool: reuse only by later work on this stream
         if (f == 0) { ++n_scholqr3_; return; }
       }
       skip_tier1_ = 0;   // neither Cholesky tier applies to this kind of panel: probe from the top next time
