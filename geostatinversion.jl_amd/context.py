@@ -170,6 +170,17 @@ def gridcov_implicit_operator(ctx, nx, ny, ell):
     return Operator(ctx, h)
 
 
+def fft_powerlaw_operator(ctx, Ns, beta):
+    """Matrix-free covariance of FFTRF-style power-law fields on a structured grid (circulant embedding, spectrum
+    |k|^beta, unit diagonal): `gsi_op_fft_powerlaw`.  `Ns` = grid points per axis (1 to 3 axes); the operator acts on
+    vec(field) in Julia's (column-major) order."""
+    Ns = [int(v) for v in Ns]
+    arr = (C.c_int64 * len(Ns))(*Ns)
+    h = C.c_void_p()
+    L.check(ctx.lib.gsi_op_fft_powerlaw(ctx.h, C.byref(h), len(Ns), arr, float(beta)), ctx.lib)
+    return Operator(ctx, h)
+
+
 class DeviceMatrix(_Handle):
     """Column-major Float64 matrix resident in HBM (`gsi_mat`)."""
     _destroy = "gsi_mat_destroy"

@@ -54,6 +54,13 @@ class Backend {
                                int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
                                int64_t ldc) = 0;
 
+  // Matrix-free stationary covariance on an N[0] x N[1] x N[2] grid (column-major point index) by circulant
+  // embedding: A = R F^-1 diag(lambda) F R', lambda(k) = |k|^beta, unit diagonal (fft_cov.hip).  Opaque plan.
+  virtual void* fftcov_create(const int64_t N[3], double beta) = 0;
+  virtual void fftcov_destroy(void* plan) = 0;
+  // Y (n x l, ld ldy) = A X (n x l, ld ldx)
+  virtual void fftcov_apply(void* plan, int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy) = 0;
+
   // ---- panel factorizations, in place ----
   // Y (m x l, ld) <- L of lu(Y) in pivoted row order; ipiv (device int32[l]) may be null.
   // Sets *singular_flag (backend int, see flags()) to j+1 on an exactly zero pivot.

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <map>
+#include <memory>
 #include <vector>
 #include "../../include/gsi_hip.h"
 #include "backend.hpp"
@@ -193,6 +194,40 @@ class HipBackend : public Backend {
     double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, k));
     hipk::gemm_f64_gridcov(st_, m, l, k, tab, nx, ny, roff, koff, B, ldb, C, ldc, ws);
     check_launch("gemm_nn_gridcov");
+  }
+
+  // ---- matrix-free FFT covariance ----
+  struct FftCov { int64_t N[3], M[3]; double* lam; double* W; int nb_max; };
+  void* fftcov_create(const int64_t N[3], double beta) override {
+    bind();
+    std::unique_ptr<FftCov> p(new FftCov());
+    int64_t Mtot = 1;
+    for (int a = 0; a < 3; ++a) {
+      if (N[a] < 1) throw Error(GSI_ERR_ARG, "fft covariance: grid dimensions must be >= 1");
+      p->N[a] = N[a]; p->M[a] = hipk::fft_embed_size(N[a]);
+      if (p->M[a] > 4096) throw Error(GSI_ERR_ARG, "fft covariance: at most 2048 grid points per axis (a line must fit LDS)");
+      Mtot *= p->M[a];
+    }
+    // work array: as many column pairs at once as fit ~2 GB, at most 64
+    int64_t nb = ((int64_t)2 << 30) / (16 * Mtot);
+    p->nb_max = (int)std::max<int64_t>(1, std::min<int64_t>(nb, 64));
+    p->lam = alloc((size_t)Mtot + 64);
+    try { p->W = alloc((size_t)2 * Mtot * p->nb_max); } catch (...) { release(p->lam); throw; }
+    hipk::fft_spectrum(st_, p->lam, p->lam + Mtot, p->M, beta);
+    check_launch("fft_spectrum");
+    return p.release();
+  }
+  void fftcov_destroy(void* plan) override {
+    FftCov* p = static_cast<FftCov*>(plan);
+    if (!p) return;
+    release(p->W); release(p->lam);
+    delete p;
+  }
+  void fftcov_apply(void* plan, int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy) override {
+    bind();
+    FftCov* p = static_cast<FftCov*>(plan);
+    hipk::fft_cov_apply(st_, p->N, p->M, p->lam, reinterpret_cast<double2*>(p->W), p->nb_max, l, X, ldx, Y, ldy);
+    check_launch("fft_cov_apply");
   }
 
   // ---- panels ----

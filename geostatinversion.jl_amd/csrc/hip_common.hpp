@@ -14,6 +14,13 @@ void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, doub
 void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* tab, int64_t nx, int64_t ny,
                       int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws);
 
+// ---- fft_cov.hip ----
+int64_t fft_embed_size(int64_t N);   // next power of two >= 2 N (1 for a singleton axis)
+// lam (M0*M1*M2 doubles) <- |k|^beta / sum, part64: 64 doubles of scratch
+void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3], double beta);
+void fft_cov_apply(hipStream_t st, const int64_t N[3], const int64_t M[3], const double* lam, double2* W, int nb_max,
+                   int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy);
+
 // ---- panel_lu.hip ----
 struct LuWork {
   // ping-pong sets (column parity): what the sweep of column j leaves for the sweep of column j+1

@@ -31,10 +31,19 @@ void check_async_errors(Context& c) {
   if (code != 0) throw Error(code, msg);
 }
 
+Operator::~Operator() {
+  if (plan && ctx && ctx->be) ctx->be->fftcov_destroy(plan);
+}
+
 void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* Yloc, int64_t ldy) {
   Context& c = *A.ctx;
   Backend* be = c.be.get();
   if (A.mloc == 0) return;
+  if (A.kind == OP_FFT_COV) {     // matrix-free: pad, FFT passes, spectrum, inverse passes, restrict (single rank)
+    ScopedPhase ph(be, PH_GEMM_N);
+    be->fftcov_apply(A.plan, l, X, ldx, Yloc, ldy);
+    return;
+  }
   if (A.kind == OP_DENSE) {
     ScopedPhase ph(be, PH_GEMM_N);
     be->gemm_nn(A.mloc, l, A.n, 1.0, A.data.p, A.ld, X, ldx, 0.0, Yloc, ldy);   // RandMatFact.jl:55,70
@@ -86,6 +95,11 @@ void gather_rows(Context& c, const Operator& A, const double* Yloc, int64_t ldy,
 void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, double* Z, int64_t ldz) {
   Context& c = *A.ctx;
   Backend* be = c.be.get();
+  if (A.kind == OP_FFT_COV) {     // symmetric: A' X = A X
+    ScopedPhase ph(be, PH_GEMM_T);
+    be->fftcov_apply(A.plan, l, Xloc, ldx, Z, ldz);
+    return;
+  }
   if (A.kind == OP_DENSE) {
     {
       ScopedPhase ph(be, PH_GEMM_T);
@@ -173,6 +187,8 @@ static Buf op_mul_t_sharded(const Operator& A, const double* Xloc, int64_t ldx, 
       be->fill_zero(P.p, (size_t)n * l);
     else if (A.kind == OP_DENSE)
       be->gemm_tn(n, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, P.p, n);       // RandMatFact.jl:85
+    else if (A.kind == OP_FFT_COV)
+      be->fftcov_apply(A.plan, l, Xloc, ldx, P.p, n);                                // one rank holds everything
     else
       be->gemm_nn_gridcov(n, l, A.mloc, A.data.p, A.gx, A.gy, 0, A.row0, Xloc, ldx, P.p, n);
   }

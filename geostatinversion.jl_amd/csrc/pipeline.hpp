@@ -33,7 +33,7 @@ struct Context {
   int nranks() const { return comm ? comm->nranks : 1; }
 };
 
-enum OpKind { OP_DENSE = 0, OP_LOWRANK = 1, OP_GRIDCOV_IMPLICIT = 2 };
+enum OpKind { OP_DENSE = 0, OP_LOWRANK = 1, OP_GRIDCOV_IMPLICIT = 2, OP_FFT_COV = 3 };
 
 // A linear operator m x n; this rank holds rows [row0, row0 + mloc).
 struct Operator {
@@ -44,6 +44,11 @@ struct Operator {
   int64_t ld = 0;
   int64_t N = 0;   // lowrank: number of samples
   int64_t gx = 0, gy = 0;   // implicit grid covariance: data = [ex (gx) | ey (gy)], the operator is never stored
+  void* plan = nullptr;     // OP_FFT_COV: the backend's circulant-embedding plan (owned; single rank)
+  Operator() = default;
+  Operator(const Operator&) = delete;
+  Operator& operator=(const Operator&) = delete;
+  ~Operator();
 };
 
 // block-row layout used whenever a caller does not supply one

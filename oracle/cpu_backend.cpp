@@ -4,7 +4,9 @@
 // collective sequence are then testable under `pytest -m "not gpu"` (world_size-2 gloo).
 // Built by oracle/Makefile into oracle/_build/libgsi_cpuref.so.  The product package never
 // loads this library (geostatinversion.jl_amd/_lib.py opens libgsi_hip.so only).
+#include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdlib>
 #include <cstring>
 #include <random>
@@ -83,6 +85,74 @@ class CpuBackend : public Backend {
         }
         C[r + c * ldc] = s;
       }
+  }
+  // circulant-embedding covariance with a naive O(M * sum M_a) separable DFT (test sizes only)
+  struct FftCov { int64_t N[3], M[3]; std::vector<double> lam; };
+  static void dft_axis(std::vector<std::complex<double>>& w, const int64_t M[3], int axis, double sign) {
+    const int64_t Ma = M[axis];
+    if (Ma == 1) return;
+    int64_t es = 1;
+    for (int a = 0; a < axis; ++a) es *= M[a];
+    const int64_t os = es * Ma, total = M[0] * M[1] * M[2];
+    std::vector<std::complex<double>> line((size_t)Ma), out((size_t)Ma);
+    for (int64_t o = 0; o < total / os; ++o)
+      for (int64_t i = 0; i < es; ++i) {
+        for (int64_t k = 0; k < Ma; ++k) line[(size_t)k] = w[(size_t)(i + es * k + os * o)];
+        for (int64_t k = 0; k < Ma; ++k) {
+          std::complex<double> s = 0.0;
+          for (int64_t j = 0; j < Ma; ++j)
+            s += line[(size_t)j] * std::polar(1.0, sign * 2.0 * M_PI * (double)((j * k) % Ma) / (double)Ma);
+          out[(size_t)k] = s;
+        }
+        for (int64_t k = 0; k < Ma; ++k) w[(size_t)(i + es * k + os * o)] = out[(size_t)k];
+      }
+  }
+  void* fftcov_create(const int64_t N[3], double beta) override {
+    FftCov* p = new FftCov();
+    int64_t Mtot = 1;
+    for (int a = 0; a < 3; ++a) {
+      p->N[a] = N[a];
+      int64_t m = 1;
+      while (m < 2 * N[a]) m <<= 1;
+      p->M[a] = (N[a] == 1) ? 1 : m;
+      Mtot *= p->M[a];
+    }
+    p->lam.resize((size_t)Mtot);
+    double tot = 0.0;
+    for (int64_t e = 0; e < Mtot; ++e) {
+      const int64_t k0 = e % p->M[0], r = e / p->M[0], k1 = r % p->M[1], k2 = r / p->M[1];
+      const int64_t kk[3] = {k0, k1, k2};
+      double s = 0.0;
+      for (int a = 0; a < 3; ++a) {
+        const double f = (double)std::min(kk[a], p->M[a] - kk[a]) / (double)p->M[a];
+        s += f * f;
+      }
+      p->lam[(size_t)e] = s > 0.0 ? std::pow(s, 0.5 * beta) : 0.0;
+      tot += p->lam[(size_t)e];
+    }
+    for (double& v : p->lam) v /= tot;
+    return p;
+  }
+  void fftcov_destroy(void* plan) override { delete static_cast<FftCov*>(plan); }
+  void fftcov_apply(void* plan, int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy) override {
+    FftCov* p = static_cast<FftCov*>(plan);
+    const int64_t* N = p->N; const int64_t* M = p->M;
+    const int64_t Mtot = M[0] * M[1] * M[2], n = N[0] * N[1] * N[2];
+    std::vector<std::complex<double>> w((size_t)Mtot);
+    for (int64_t c = 0; c < l; ++c) {
+      std::fill(w.begin(), w.end(), std::complex<double>(0.0, 0.0));
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t i0 = i % N[0], r = i / N[0], i1 = r % N[1], i2 = r / N[1];
+        w[(size_t)(i0 + M[0] * (i1 + M[1] * i2))] = X[i + c * ldx];
+      }
+      for (int a = 0; a < 3; ++a) dft_axis(w, M, a, -1.0);
+      for (int64_t e = 0; e < Mtot; ++e) w[(size_t)e] *= p->lam[(size_t)e];
+      for (int a = 2; a >= 0; --a) dft_axis(w, M, a, +1.0);
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t i0 = i % N[0], r = i / N[0], i1 = r % N[1], i2 = r / N[1];
+        Y[i + c * ldy] = w[(size_t)(i0 + M[0] * (i1 + M[1] * i2))].real();
+      }
+    }
   }
   void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv) override {
     const int info = gsio_lu_L(Y, m, l, ld, ipiv);

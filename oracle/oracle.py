@@ -478,3 +478,40 @@ def xis_error_up_to_sign(Z1: np.ndarray, Z2: np.ndarray, K: int) -> float:
         a, b = Z1[:, i], Z2[:, i]
         err = max(err, min(np.linalg.norm(a - b), np.linalg.norm(a + b)))
     return float(err)
+
+
+# ---- f2: matrix-free circulant-embedding covariance (not in the reference as an operator) --------------------
+def fft_powerlaw_spectrum(Ns, beta):
+    """lambda on the power-of-two embedding grid (shape M_1 x ... x M_d, Fortran order of the flattened operator):
+    (sum_a (f_a / M_a)^2)^(beta/2), f_a = min(k_a, M_a - k_a), lambda(0) = 0; normalised to mean 1 so that
+    the circulant F^-1 diag(lambda) F has a unit diagonal.  Same power law as FFTRF.jl:58-66 (`S_f ^ (.25*beta)` is
+    the square root of it)."""
+    Ms = [1 if N == 1 else 1 << int(np.ceil(np.log2(2 * N))) for N in Ns]
+    k2 = np.zeros(Ms)
+    for a, M in enumerate(Ms):
+        k = np.arange(M)
+        f = np.minimum(k, M - k) / M
+        shape = [1] * len(Ms)
+        shape[a] = M
+        k2 = k2 + (f ** 2).reshape(shape)
+    lam = np.zeros(Ms)
+    nz = k2 > 0
+    lam[nz] = k2[nz] ** (0.5 * beta)
+    return lam / lam.mean(), Ms
+
+
+def fft_powerlaw_apply(X, Ns, beta):
+    """A X for A = R F^-1 diag(lambda) F R' (zero padding R' of the N-grid into the embedding grid), columns of X =
+    vec(field) in column-major (Julia) order."""
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X[:, None]
+    lam, Ms = fft_powerlaw_spectrum(Ns, beta)
+    out = np.empty_like(X)
+    box = tuple(slice(0, N) for N in Ns)
+    for c in range(X.shape[1]):
+        w = np.zeros(Ms)
+        w[box] = X[:, c].reshape(Ns, order="F")
+        y = np.fft.ifftn(lam * np.fft.fftn(w)).real
+        out[:, c] = y[box].reshape(-1, order="F")
+    return out

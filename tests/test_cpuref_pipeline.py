@@ -191,3 +191,25 @@ def test_randsvd_shape_sweep_cpuref(gsi, cx):
         assert np.all(Z[:, K:] == 0)
         assert np.abs(S - Sr).max() / Sr[0] < 1e-10, (m, n, K, p, q)
         assert np.abs(Z @ Z.T - Zr @ Zr.T).max() / Sr[0] < 1e-8, (m, n, K, p, q)
+
+
+@pytest.mark.parametrize("Ns,beta", [((12,), -2.0), ((6, 5), -3.5), ((4, 3, 5), -3.0)])
+def test_fft_powerlaw_operator_cpuref(gsi, cx, Ns, beta):
+    """gsi_op_fft_powerlaw through the shipped pipeline (naive DFT backend) against the numpy-FFT oracle: products,
+    symmetry, unit diagonal, and a randsvd through the matrix-free operator."""
+    n = int(np.prod(Ns))
+    op = gsi.fft_powerlaw_operator(cx, Ns, beta)
+    assert op.shape == (n, n)
+    A = op.matmul(np.eye(n))
+    Aref = orc.fft_powerlaw_apply(np.eye(n), list(Ns), beta)
+    assert np.abs(A - Aref).max() < 1e-12
+    assert np.abs(A - A.T).max() < 1e-12 and np.abs(np.diag(A) - 1.0).max() < 1e-12
+    assert np.linalg.eigvalsh(0.5 * (A + A.T)).min() > -1e-12
+    rng = np.random.default_rng(n)
+    K, p = min(6, n - 3), 2
+    Om = rng.standard_normal((n, K + p))
+    Z, S = gsi.randsvd(op, K, p, 2, Omega=Om, return_S=True)
+    Zr, Sr, _ = orc.randsvd_full(Aref, K, p, 2, Om)
+    assert rel_sv_err(S, Sr, K) < 1e-9
+    assert np.abs(Z @ Z.T - Zr @ Zr.T).max() < 1e-8 * Sr[0]
+    op.close()

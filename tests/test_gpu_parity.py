@@ -571,3 +571,38 @@ def test_randsvd_shape_sweep(gsi, ctx):
         e_z = np.abs(Z @ Z.T - Zr @ Zr.T).max() / Sr[0]
         worst = max(worst, e_s, e_z)
         assert e_s < 1e-10 and e_z < 1e-8, (m, n, K, p, q, e_s, e_z)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ns,beta,l", [((50,), -2.0, 7), ((24, 17), -3.5, 10), ((40, 64), -2.5, 33), ((9, 6, 11), -3.0, 4),
+                                        ((300, 200), -3.5, 5)])
+def test_fft_powerlaw_operator(gsi, ctx, Ns, beta, l):
+    """The hand-written LDS FFT passes of the matrix-free covariance (gsi_op_fft_powerlaw) against numpy's FFT:
+    odd/even column counts (two real columns per complex transform), 1/2/3 axes, non-power-of-two grids."""
+    n = int(np.prod(Ns))
+    rng = np.random.default_rng(n + l)
+    X = rng.standard_normal((n, l))
+    op = gsi.fft_powerlaw_operator(ctx, Ns, beta)
+    Y = op.matmul(X)
+    Yref = orc.fft_powerlaw_apply(X, list(Ns), beta)
+    assert np.abs(Y - Yref).max() < 1e-12 * np.abs(Yref).max()
+    assert np.abs(op.rmatmul_t(X) - Yref).max() < 1e-12 * np.abs(Yref).max()
+    e = np.zeros((n, 2)); e[0, 0] = 1.0; e[n // 2, 1] = 1.0
+    d = op.matmul(e)
+    assert abs(d[0, 0] - 1.0) < 1e-12 and abs(d[n // 2, 1] - 1.0) < 1e-12          # unit diagonal
+    op.close()
+
+
+@pytest.mark.gpu
+def test_fft_powerlaw_randsvd(gsi, ctx):
+    """randsvd through the matrix-free FFT operator = randsvd of the same covariance stored densely (oracle)."""
+    Ns, beta, K, p, q = (20, 16), -3.5, 12, 6, 2
+    n = int(np.prod(Ns))
+    A = orc.fft_powerlaw_apply(np.eye(n), list(Ns), beta)
+    Om = np.random.default_rng(8).standard_normal((n, K + p))
+    op = gsi.fft_powerlaw_operator(ctx, Ns, beta)
+    Z, S = gsi.randsvd(op, K, p, q, Omega=Om, return_S=True)
+    Zr, Sr, _ = orc.randsvd_full(A, K, p, q, Om)
+    assert rel_sv_err(S, Sr, K) < 1e-9
+    assert np.abs(Z @ Z.T - Zr @ Zr.T).max() < 1e-8 * Sr[0]
+    op.close()
