@@ -10,130 +10,144 @@
 //
 // gfx950 mapping.  lambda is real and even, so F^-1 diag(lambda) F is a REAL operator: two real columns ride in
 // one complex transform (x_a + i x_b -> A x_a + i A x_b) with no untangling pass.  The embedding is the next
-// power of two >= 2 N per axis.  A d-dimensional transform is d passes of batched 1-D radix-2 transforms done
-// entirely in LDS (a line of <= 4096 complex doubles is 64 KB): axis 0 lines are contiguous; for the other axes
-// a workgroup takes a tile of T neighbouring lines so that every global access is T*16 contiguous bytes.  Each
-// pass reads and writes the work array once: HBM-bound (2 d + 1 passes forward/scale/back per column pair,
-// 16 B per embedded point per pass).  Twiddles sit in LDS; the spectrum is a precomputed real table with the
-// 1/M of the inverse transform and the unit-diagonal normalisation folded in.
+// power of two >= 2 N per axis.  A d-dimensional transform is d passes of batched 1-D transforms done entirely in
+// LDS (a line of <= 4096 complex doubles is 64 KB): axis 0 lines are contiguous; for the other axes a workgroup
+// takes a tile of T neighbouring lines so that every global access is T*16 contiguous bytes.
+// HBM-bound, so the passes move as little as possible: the zero padding is never stored or read (forward passes
+// read only the N_a valid entries of a line and skip lines that lie in the padding of a later axis; inverse passes
+// write only the N_a entries that survive the restriction), the first pass reads X and the last writes Y directly,
+// and the spectrum (with the 1/M of the inverse transform and the unit-diagonal normalisation folded in) is
+// applied as the last forward pass stores.  2-D, M = 2N: 20 n complex moved per column pair instead of 48 n.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
-#include <vector>
 #include "hip_common.hpp"
 
 namespace gsi { namespace hipk {
 
-constexpr int FFT_THREADS = 256;
-
-
 __device__ inline double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ inline double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ inline double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 
-// W[b][embedded(i)] = X[i, 2b] + i X[i, 2b+1] inside the N-box, 0 outside.  One thread per embedded point.
-__global__ __launch_bounds__(256) void fft_pack_kernel(double2* __restrict__ W, int64_t Mtot, int nd, int64_t N0, int64_t N1,
-                                                       int64_t N2, int64_t M0, int64_t M1, const double* __restrict__ X,
-                                                       int64_t ldx, int64_t col0, int64_t l) {
-  const int64_t b = blockIdx.y;
-  const int64_t ca = col0 + 2 * b, cb = ca + 1;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < Mtot; e += (int64_t)gridDim.x * 256) {
-    const int64_t i0 = e % M0, r = e / M0, i1 = r % M1, i2 = r / M1;
-    double2 v = make_double2(0.0, 0.0);
-    if (i0 < N0 && i1 < N1 && i2 < N2) {
-      const int64_t i = i0 + N0 * (i1 + N1 * i2);
-      v.x = X[i + ca * ldx];
-      if (cb < l) v.y = X[i + cb * ldx];
-    }
-    W[b * Mtot + e] = v;
-  }
-  (void)nd;
-}
+// One pass: batched in-place 1-D transforms of length Ma (power of two) along one axis of the embedded grid.
+//   element k of line (inner, o):  W[inner + estride * k + off(o)],  inner < estride (all earlier axes, full length),
+//   o < R1 * R2 enumerates the LATER axes restricted to the original grid (i_b < N_b): off(o) = (o % R1) S1 + (o / R1) S2.
+// MODE bits: AXIS0 lines are contiguous (else a workgroup takes T neighbouring `inner`); LOADX the first forward
+// pass reads the two real columns of X; SCALE the last forward pass multiplies by the spectrum as it stores; STOREY
+// the last inverse pass writes the two real columns of Y.  sign = -1 forward, +1 inverse (unnormalised).
+enum { FFT_AXIS0 = 1, FFT_LOADX = 2, FFT_SCALE = 4, FFT_STOREY = 8 };
+struct FftPass {
+  int Ma, log2Ma, nin, nout, T;
+  int64_t estride, R1, S1, R2, S2;
+  double sign;
+};
 
-__global__ __launch_bounds__(256) void fft_unpack_kernel(const double2* __restrict__ W, int64_t Mtot, int64_t N0, int64_t N1,
-                                                         int64_t N2, int64_t M0, int64_t M1, double* __restrict__ Y,
-                                                         int64_t ldy, int64_t col0, int64_t l) {
-  const int64_t b = blockIdx.y;
-  const int64_t ca = col0 + 2 * b, cb = ca + 1;
-  const int64_t n = N0 * N1 * N2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int64_t i0 = i % N0, r = i / N0, i1 = r % N1, i2 = r / N1;
-    const double2 v = W[b * Mtot + i0 + M0 * (i1 + M1 * i2)];
-    Y[i + ca * ldy] = v.x;
-    if (cb < l) Y[i + cb * ldy] = v.y;
-  }
-}
-
-// W[b][e] *= lam[e]   (lam real: spectrum / (M * mean(spectrum)))
-__global__ __launch_bounds__(256) void fft_scale_kernel(double2* __restrict__ W, int64_t Mtot, const double* __restrict__ lam) {
-  double2* Wb = W + (int64_t)blockIdx.y * Mtot;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < Mtot; e += (int64_t)gridDim.x * 256) {
-    const double s = lam[e];
-    double2 v = Wb[e];
-    v.x *= s; v.y *= s;
-    Wb[e] = v;
-  }
-}
-
-// Batched in-place 1-D transforms of length Ma (power of two) along one axis.
-//   element k of line (inner, outer): W[inner + estride * k + ostride * outer],  inner < estride, outer < nouter
-// A workgroup owns T lines: AXIS0 (estride == 1): T consecutive `outer`; otherwise T consecutive `inner`.
-// LDS: T lines of Ma complex + Ma/2 twiddles.  sign = -1 forward, +1 inverse (unnormalised).
-template <bool AXIS0>
-__global__ __launch_bounds__(FFT_THREADS) void fft_axis_kernel(double2* __restrict__ W, int64_t Mtot, int Ma, int log2Ma,
-                                                               int64_t estride, int64_t ostride, int64_t nouter, int T,
-                                                               double sign) {
+template <int MODE>
+__global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, int64_t Mtot, FftPass ps,
+                                                       const double* __restrict__ lam, const double* __restrict__ X,
+                                                       int64_t ldx, double* __restrict__ Y, int64_t ldy, int64_t N0,
+                                                       int64_t col0, int64_t l) {
+  constexpr bool AXIS0 = (MODE & FFT_AXIS0) != 0;
   extern __shared__ double2 fsm[];
+  const int Ma = ps.Ma, log2Ma = ps.log2Ma, T = ps.T;
   double2* tw = fsm;                 // [Ma/2]
-  double2* buf = fsm + Ma / 2;       // [T][Ma + 1]   (+1: lines start in different banks)
-  const int tid = threadIdx.x;
+  double2* buf = fsm + Ma / 2;       // [T][Ma + 1]   (+1: neighbouring lines start in different banks)
+  const int tid = threadIdx.x, nth = blockDim.x;
   const int lstride = Ma + 1;
   double2* Wb = W + (int64_t)blockIdx.y * Mtot;
-  for (int k = tid; k < Ma / 2; k += FFT_THREADS) {
+  const int64_t ca = col0 + 2 * (int64_t)blockIdx.y, cb = ca + 1;
+  for (int k = tid; k < Ma / 2; k += nth) {
     double s, c;
     sincospi(2.0 * (double)k / (double)Ma, &s, &c);
-    tw[k] = make_double2(c, sign * s);
+    tw[k] = make_double2(c, ps.sign * s);
   }
-  // tile -> (inner0, outer0)
-  int64_t inner0, outer0;
+  // tile -> first line; line j of the tile: AXIS0: outer o0 + j, else inner i0 + j of outer o0
+  const int64_t nouter = ps.R1 * ps.R2;
+  int64_t o0, i0 = 0;
   int nlines;
   if (AXIS0) {
-    outer0 = (int64_t)blockIdx.x * T; inner0 = 0;
-    nlines = (int)((nouter - outer0 < T) ? (nouter - outer0) : T);
+    o0 = (int64_t)blockIdx.x * T;
+    nlines = (int)((nouter - o0 < T) ? (nouter - o0) : T);
   } else {
-    const int64_t tiles_per_outer = (estride + T - 1) / T;
-    outer0 = blockIdx.x / tiles_per_outer;
-    inner0 = (blockIdx.x % tiles_per_outer) * T;
-    nlines = (int)((estride - inner0 < T) ? (estride - inner0) : T);
+    const int64_t tiles_per_outer = (ps.estride + T - 1) / T;
+    o0 = blockIdx.x / tiles_per_outer;
+    i0 = (blockIdx.x % tiles_per_outer) * T;
+    nlines = (int)((ps.estride - i0 < T) ? (ps.estride - i0) : T);
   }
+  auto off = [&](int64_t o) -> int64_t { return (o % ps.R1) * ps.S1 + (o / ps.R1) * ps.S2; };
+  const int64_t off0 = AXIS0 ? 0 : off(o0);
   const unsigned shift = 32u - (unsigned)log2Ma;
-  // load with bit reversal of k
-  for (int e = tid; e < nlines * Ma; e += FFT_THREADS) {
+  if (ps.nin < Ma) {      // the padded part of the lines
+    for (int e = tid; e < nlines * lstride; e += nth) buf[e] = make_double2(0.0, 0.0);
+    __syncthreads();
+  }
+  // load k < nin, bit-reversed
+  for (int e = tid; e < nlines * ps.nin; e += nth) {
     int j, k;
-    if (AXIS0) { k = e % Ma; j = e / Ma; } else { j = e % nlines; k = e / nlines; }
-    const int64_t g = AXIS0 ? ((int64_t)k + ostride * (outer0 + j)) : (inner0 + j + estride * (int64_t)k + ostride * outer0);
-    const unsigned kr = (log2Ma == 0) ? 0u : (__brev((unsigned)k) >> shift);
-    buf[j * lstride + kr] = Wb[g];
+    if (AXIS0) { k = e % ps.nin; j = e / ps.nin; } else { j = e % nlines; k = e / nlines; }
+    double2 v;
+    if (MODE & FFT_LOADX) {
+      const int64_t o = o0 + j;                          // (i1, i2) of the original grid
+      const int64_t i = k + N0 * ((o % ps.R1) + ps.R1 * (o / ps.R1));
+      v.x = X[i + ca * ldx];
+      v.y = (cb < l) ? X[i + cb * ldx] : 0.0;
+    } else {
+      const int64_t g = AXIS0 ? ((int64_t)k + off(o0 + j)) : (i0 + j + ps.estride * (int64_t)k + off0);
+      v = Wb[g];
+    }
+    buf[j * lstride + (int)(__brev((unsigned)k) >> shift)] = v;
   }
   __syncthreads();
-  const int nbf = nlines * (Ma / 2);
-  for (int st = 0; st < log2Ma; ++st) {
-    const int half = 1 << st;
-    const int tws = Ma >> (st + 1);
-    for (int e = tid; e < nbf; e += FFT_THREADS) {
+  // decimation in time on the bit-reversed lines.  Two radix-2 stages at a time (radix 4 in registers: 4 reads,
+  // 3 twiddles, 4 writes per 4 points instead of 8 + 4 + 8) -- the pass is as much LDS- as HBM-bound; one radix-2
+  // stage first when log2(Ma) is odd.
+  int st = 0;
+  if (log2Ma & 1) {
+    const int nbf = nlines * (Ma / 2);
+    for (int e = tid; e < nbf; e += nth) {
       const int j = e / (Ma / 2), p = e % (Ma / 2);
-      const int q = p & (half - 1);
-      const int i0 = ((p >> st) << (st + 1)) + q;
-      double2* x = buf + j * lstride;
-      const double2 a = x[i0], b = cmul(tw[q * tws], x[i0 + half]);
-      x[i0] = make_double2(a.x + b.x, a.y + b.y);
-      x[i0 + half] = make_double2(a.x - b.x, a.y - b.y);
+      double2* x = buf + j * lstride + 2 * p;
+      const double2 a = x[0], b = x[1];
+      x[0] = cadd(a, b);
+      x[1] = csub(a, b);
+    }
+    __syncthreads();
+    st = 1;
+  }
+  const int nq = nlines * (Ma / 4);
+  for (; st < log2Ma; st += 2) {
+    const int h = 1 << st;
+    const int tw1 = Ma >> (st + 1);      // twiddle stride of stage st   (block 2h)
+    const int tw2 = Ma >> (st + 2);      //                    stage st+1 (block 4h)
+    for (int e = tid; e < nq; e += nth) {
+      const int j = e / (Ma / 4), p = e % (Ma / 4);
+      const int q = p & (h - 1);
+      double2* x = buf + j * lstride + ((p >> st) << (st + 2)) + q;
+      const double2 w1 = tw[q * tw1], w2 = tw[q * tw2], w3 = tw[(q + h) * tw2];
+      const double2 a0 = x[0], a1 = cmul(w1, x[h]), a2 = x[2 * h], a3 = cmul(w1, x[3 * h]);
+      const double2 b0 = cadd(a0, a1), b1 = csub(a0, a1);
+      const double2 b2 = cmul(w2, cadd(a2, a3)), b3 = cmul(w3, csub(a2, a3));
+      x[0] = cadd(b0, b2);
+      x[2 * h] = csub(b0, b2);
+      x[h] = cadd(b1, b3);
+      x[3 * h] = csub(b1, b3);
     }
     __syncthreads();
   }
-  for (int e = tid; e < nlines * Ma; e += FFT_THREADS) {
+  for (int e = tid; e < nlines * ps.nout; e += nth) {
     int j, k;
-    if (AXIS0) { k = e % Ma; j = e / Ma; } else { j = e % nlines; k = e / nlines; }
-    const int64_t g = AXIS0 ? ((int64_t)k + ostride * (outer0 + j)) : (inner0 + j + estride * (int64_t)k + ostride * outer0);
-    Wb[g] = buf[j * lstride + k];
+    if (AXIS0) { k = e % ps.nout; j = e / ps.nout; } else { j = e % nlines; k = e / nlines; }
+    double2 v = buf[j * lstride + k];
+    if (MODE & FFT_STOREY) {
+      const int64_t o = o0 + j;
+      const int64_t i = k + N0 * ((o % ps.R1) + ps.R1 * (o / ps.R1));
+      Y[i + ca * ldy] = v.x;
+      if (cb < l) Y[i + cb * ldy] = v.y;
+    } else {
+      const int64_t g = AXIS0 ? ((int64_t)k + off(o0 + j)) : (i0 + j + ps.estride * (int64_t)k + off0);
+      if (MODE & FFT_SCALE) { const double sc = lam[g]; v.x *= sc; v.y *= sc; }
+      Wb[g] = v;
+    }
   }
 }
 
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(256) void fft_spectrum_kernel(double* __restrict__ 
   }
 }
 
-// partial sums of lam -> part[blockIdx.x]; then lam *= 1 / sum (one more tiny kernel on the host side order)
+// partial sums of lam -> part[blockIdx.x]; then lam *= 1 / sum
 __global__ __launch_bounds__(256) void fft_sum_kernel(const double* __restrict__ lam, int64_t Mtot, double* __restrict__ part) {
   __shared__ double s[256];
   double acc = 0.0;
@@ -189,50 +203,82 @@ void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3
   hipLaunchKernelGGL(fft_normalise_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, part64, 64);
 }
 
-static void fft_axis(hipStream_t st, double2* W, int64_t Mtot, int nb, const int64_t M[3], int axis, double sign) {
-  const int Ma = (int)M[axis];
-  if (Ma == 1) return;
-  const int lg = ilog2(Ma);
-  int64_t estride = 1;
-  for (int a = 0; a < axis; ++a) estride *= M[a];
-  const int64_t ostride = estride * Ma;
-  const int64_t nouter = Mtot / ostride;
-  // lines per workgroup: as many as fit ~96 KB of LDS, at most 16 (256-byte segments for the strided axes)
-  int T = (int)((96 * 1024) / ((size_t)(Ma + 1) * sizeof(double2)));
+template <int MODE>
+static void launch_pass(hipStream_t st, dim3 grid, int threads, size_t shmem, double2* W, int64_t Mtot, const FftPass& ps,
+                        const double* lam, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t N0, int64_t col0,
+                        int64_t l) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)fft_pass_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    attr = true;
+  }
+  hipLaunchKernelGGL((fft_pass_kernel<MODE>), grid, dim3(threads), shmem, st, W, Mtot, ps, lam, X, ldx, Y, ldy, N0, col0, l);
+}
+
+// one pass along `axis` (N, M: squeezed grid, axis 0 is never a singleton)
+static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], const int64_t M[3], int axis, bool inverse,
+                     bool first_fwd, bool last_fwd, bool last_inv, const double* lam, const double* X, int64_t ldx,
+                     double* Y, int64_t ldy, int64_t col0, int64_t l) {
+  const int64_t Mtot = M[0] * M[1] * M[2];
+  FftPass ps;
+  ps.Ma = (int)M[axis];
+  ps.log2Ma = ilog2(ps.Ma);
+  ps.nin = inverse ? ps.Ma : (int)N[axis];
+  ps.nout = inverse ? (int)N[axis] : ps.Ma;
+  ps.sign = inverse ? 1.0 : -1.0;
+  const int64_t stride[3] = {1, M[0], M[0] * M[1]};
+  ps.estride = stride[axis];
+  ps.R1 = 1; ps.S1 = 0; ps.R2 = 1; ps.S2 = 0;
+  if (axis == 0) { ps.R1 = N[1]; ps.S1 = stride[1]; ps.R2 = N[2]; ps.S2 = stride[2]; }
+  else if (axis == 1) { ps.R1 = N[2]; ps.S1 = stride[2]; }
+  // lines per workgroup: contiguous lines need no neighbours (keep LDS <= ~64 KB so that two workgroups per CU
+  // overlap their load / butterfly / store phases); strided lines want long segments (T up to 16 = 256 bytes; a
+  // 2048-point line is 32 KB, so T = 4 there: 64-byte segments are what LDS capacity allows)
+  const size_t line_bytes = (size_t)(ps.Ma + 1) * sizeof(double2);
+  const size_t budget = (size_t)(axis == 0 ? 64 : 152) * 1024;
+  const size_t twb = (size_t)ps.Ma / 2 * sizeof(double2);
+  int T = (budget > twb + line_bytes) ? (int)((budget - twb) / line_bytes) : 1;
   if (T > 16) T = 16;
   if (T < 1) T = 1;
-  const size_t shmem = ((size_t)Ma / 2 + (size_t)T * (Ma + 1)) * sizeof(double2);
+  ps.T = T;
+  const size_t shmem = twb + (size_t)T * line_bytes;
+  const int threads = ((int64_t)T * ps.Ma >= 4096) ? 512 : 256;
+  const int64_t nouter = ps.R1 * ps.R2;
+  const int64_t tiles = (axis == 0) ? (nouter + T - 1) / T : ((ps.estride + T - 1) / T) * nouter;
+  dim3 grid((unsigned)tiles, (unsigned)nb);
+  const int64_t N0 = N[0];
+#define GSI_FFT_LAUNCH(MODE) launch_pass<MODE>(st, grid, threads, shmem, W, Mtot, ps, lam, X, ldx, Y, ldy, N0, col0, l)
   if (axis == 0) {
-    static bool attr0 = false;
-    if (!attr0) { (void)hipFuncSetAttribute((const void*)fft_axis_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr0 = true; }
-    const int64_t ntiles = (nouter + T - 1) / T;
-    hipLaunchKernelGGL(fft_axis_kernel<true>, dim3((unsigned)ntiles, (unsigned)nb), dim3(FFT_THREADS), shmem, st, W, Mtot, Ma, lg,
-                       estride, ostride, nouter, T, sign);
+    if (!inverse) {
+      if (first_fwd && last_fwd) GSI_FFT_LAUNCH(FFT_AXIS0 | FFT_LOADX | FFT_SCALE);
+      else if (first_fwd) GSI_FFT_LAUNCH(FFT_AXIS0 | FFT_LOADX);
+      else GSI_FFT_LAUNCH(FFT_AXIS0);
+    } else {
+      if (last_inv) GSI_FFT_LAUNCH(FFT_AXIS0 | FFT_STOREY);
+      else GSI_FFT_LAUNCH(FFT_AXIS0);
+    }
   } else {
-    static bool attr1 = false;
-    if (!attr1) { (void)hipFuncSetAttribute((const void*)fft_axis_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr1 = true; }
-    const int64_t tiles_per_outer = (estride + T - 1) / T;
-    hipLaunchKernelGGL(fft_axis_kernel<false>, dim3((unsigned)(tiles_per_outer * nouter), (unsigned)nb), dim3(FFT_THREADS), shmem,
-                       st, W, Mtot, Ma, lg, estride, ostride, nouter, T, sign);
+    if (!inverse && last_fwd) GSI_FFT_LAUNCH(FFT_SCALE);
+    else GSI_FFT_LAUNCH(0);
   }
+#undef GSI_FFT_LAUNCH
 }
 
 // Y (n x l, ld ldy) = A X for the embedded-circulant covariance; W holds nb_max * Mtot complex doubles.
+// N, M are the SQUEEZED dimensions (singleton axes removed, trailing ones = 1): axis 0 is a real axis.
 void fft_cov_apply(hipStream_t st, const int64_t N[3], const int64_t M[3], const double* lam, double2* W, int nb_max,
                    int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy) {
-  const int64_t Mtot = M[0] * M[1] * M[2];
-  const int64_t n = N[0] * N[1] * N[2];
+  int d = 1;
+  if (M[1] > 1) d = 2;
+  if (M[2] > 1) d = 3;
   const int64_t npairs = (l + 1) / 2;
   for (int64_t p0 = 0; p0 < npairs; p0 += nb_max) {
     const int nb = (int)((npairs - p0 < nb_max) ? (npairs - p0) : nb_max);
     const int64_t col0 = 2 * p0;
-    hipLaunchKernelGGL(fft_pack_kernel, dim3(grid_for(Mtot, 2048), nb), dim3(256), 0, st, W, Mtot, 3, N[0], N[1], N[2], M[0],
-                       M[1], X, ldx, col0, l);
-    for (int a = 0; a < 3; ++a) fft_axis(st, W, Mtot, nb, M, a, -1.0);
-    hipLaunchKernelGGL(fft_scale_kernel, dim3(grid_for(Mtot, 2048), nb), dim3(256), 0, st, W, Mtot, lam);
-    for (int a = 2; a >= 0; --a) fft_axis(st, W, Mtot, nb, M, a, +1.0);
-    hipLaunchKernelGGL(fft_unpack_kernel, dim3(grid_for(n, 2048), nb), dim3(256), 0, st, W, Mtot, N[0], N[1], N[2], M[0], M[1], Y,
-                       ldy, col0, l);
+    for (int a = 0; a < d; ++a)
+      fft_pass(st, W, nb, N, M, a, false, a == 0, a == d - 1, false, lam, X, ldx, Y, ldy, col0, l);
+    for (int a = d - 1; a >= 0; --a)
+      fft_pass(st, W, nb, N, M, a, true, false, false, a == 0, lam, X, ldx, Y, ldy, col0, l);
   }
 }
 

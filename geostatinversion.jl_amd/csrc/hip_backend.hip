@@ -202,11 +202,15 @@ class HipBackend : public Backend {
     bind();
     std::unique_ptr<FftCov> p(new FftCov());
     int64_t Mtot = 1;
-    for (int a = 0; a < 3; ++a) {
+    int d = 0;
+    for (int a = 0; a < 3; ++a) { p->N[a] = 1; p->M[a] = 1; }
+    for (int a = 0; a < 3; ++a) {        // squeeze singleton axes: vec() of a 1 x 50 field is a 50-point line
       if (N[a] < 1) throw Error(GSI_ERR_ARG, "fft covariance: grid dimensions must be >= 1");
-      p->N[a] = N[a]; p->M[a] = hipk::fft_embed_size(N[a]);
-      if (p->M[a] > 4096) throw Error(GSI_ERR_ARG, "fft covariance: at most 2048 grid points per axis (a line must fit LDS)");
-      Mtot *= p->M[a];
+      if (N[a] == 1) continue;
+      p->N[d] = N[a]; p->M[d] = hipk::fft_embed_size(N[a]);
+      if (p->M[d] > 4096) throw Error(GSI_ERR_ARG, "fft covariance: at most 2048 grid points per axis (a line must fit LDS)");
+      Mtot *= p->M[d];
+      ++d;
     }
     // work array: as many column pairs at once as fit ~2 GB, at most 64
     int64_t nb = ((int64_t)2 << 30) / (16 * Mtot);
