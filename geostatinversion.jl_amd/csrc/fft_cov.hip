@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include "hip_common.hpp"
 
 namespace gsi { namespace hipk {
@@ -231,13 +232,17 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
   ps.R1 = 1; ps.S1 = 0; ps.R2 = 1; ps.S2 = 0;
   if (axis == 0) { ps.R1 = N[1]; ps.S1 = stride[1]; ps.R2 = N[2]; ps.S2 = stride[2]; }
   else if (axis == 1) { ps.R1 = N[2]; ps.S1 = stride[2]; }
-  // lines per workgroup: contiguous lines need no neighbours (keep LDS <= ~64 KB so that two workgroups per CU
-  // overlap their load / butterfly / store phases); strided lines want long segments (T up to 16 = 256 bytes; a
-  // 2048-point line is 32 KB, so T = 4 there: 64-byte segments are what LDS capacity allows)
+  // lines per workgroup (measured, tools/fft_budget_sweep.sh): contiguous lines need no neighbours -- <= 32 KB of
+  // LDS so that several workgroups per CU overlap their load / butterfly / store phases; strided lines want long
+  // segments (T up to 16 = 256 bytes) but still two workgroups per CU (<= 76 KB) -- except that fewer than 4 lines
+  // (64-byte segments) is worse than one workgroup per CU, so 2048-point lines (32 KB each) take 152 KB for T = 4.
   const size_t line_bytes = (size_t)(ps.Ma + 1) * sizeof(double2);
-  const size_t budget = (size_t)(axis == 0 ? 64 : 152) * 1024;
+  static const int b0 = getenv("GSI_FFT_B0") ? atoi(getenv("GSI_FFT_B0")) : 32;
+  static const int b1 = getenv("GSI_FFT_B1") ? atoi(getenv("GSI_FFT_B1")) : 76;
   const size_t twb = (size_t)ps.Ma / 2 * sizeof(double2);
-  int T = (budget > twb + line_bytes) ? (int)((budget - twb) / line_bytes) : 1;
+  auto lines_in = [&](size_t kb) -> int { return (kb * 1024 > twb + line_bytes) ? (int)((kb * 1024 - twb) / line_bytes) : 1; };
+  int T = lines_in((size_t)(axis == 0 ? b0 : b1));
+  if (axis != 0 && T < 4) { const int t2 = lines_in(152); T = t2 < 4 ? t2 : 4; }
   if (T > 16) T = 16;
   if (T < 1) T = 1;
   ps.T = T;

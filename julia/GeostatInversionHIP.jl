@@ -116,6 +116,20 @@ function GridCovImplicit(nx::Int, ny::Int, ell::Float64; c::Context=ctx())
 	return op
 end
 
+"Exact, matrix-free covariance of `FFTRF.powerlaw_structuredgrid(Ns, k0, dk, beta)` fields up to the factor dk^2
+(circulant embedding, spectrum |k|^beta, unit diagonal): `gsi_op_fft_powerlaw`.  Acts on `vec(field)`."
+function FFTPowerlawCovariance(Ns::Vector{Int}, beta::Float64; c::Context=ctx())
+	r = Ref{Ptr{Cvoid}}(C_NULL)
+	N64 = Int64.(Ns)
+	check(ccall((:gsi_op_fft_powerlaw, libgsi), Cint,
+		(Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Cint, Ptr{Int64}, Cdouble),
+		c.h, r, length(N64), N64, beta))
+	n = prod(Ns)
+	op = DeviceOperator(r[], c, n, n)
+	finalizer(finalize_op!, op)
+	return op
+end
+
 Base.size(A::DeviceOperator) = (A.m, A.n)
 function Base.size(A::DeviceOperator, i::Int)
 	(i == 1 || i == 2) || error("there is no $i-th dimension in a DeviceOperator")   # lowrank.jl:58
