@@ -65,16 +65,25 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
   // Issue this thread's first row loads before the reduction prologue: they do not depend on the pivot
   // (the one row that does -- the pivot's old position -- is replaced from s_old below), and the
   // prologue is a chain of dependent global/LDS latencies that would otherwise sit in front of them.
+  // Very tall panels give a thread up to LU_PRE rows (rows_per_thread); all of their loads are issued here, back
+  // to back: inside the update loop every row's stores would otherwise sit between one row's loads and the next
+  // (the compiler cannot move loads of Y above stores to Y), one exposed memory latency per row.
   const int64_t base = j + (int64_t)blockIdx.x * 256 * rows_per_thread;
-  double pre_x0 = 0.0;
-  double pre_a[LU_LEAF];
-  {
-    const int64_t i0 = base + tid;
-    if (i0 < m) {
-      const double* row0 = Y + i0;
-      if (do_update) pre_x0 = row0[jp * ld];
+  constexpr int LU_PRE = 4;
+  double pre_x0[LU_PRE];
+  double pre_a[LU_PRE][LU_LEAF];
 #pragma unroll
-      for (int k = 0; k < LU_LEAF; ++k) pre_a[k] = (k < nlive) ? row0[(j + k) * ld] : 0.0;
+  for (int rr = 0; rr < LU_PRE; ++rr) {
+    pre_x0[rr] = 0.0;
+#pragma unroll
+    for (int k = 0; k < LU_LEAF; ++k) pre_a[rr][k] = 0.0;
+    const int64_t i0 = base + tid + 256 * (int64_t)rr;
+    if (rr < rows_per_thread && i0 < m) {
+      const double* row0 = Y + i0;
+      if (do_update) pre_x0[rr] = row0[jp * ld];
+#pragma unroll
+      for (int k = 0; k < LU_LEAF; ++k)
+        if (k < nlive) pre_a[rr][k] = row0[(j + k) * ld];
     }
   }
   if (do_update) {
@@ -143,20 +152,20 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
   double besta[LU_LEAF];
 #pragma unroll
   for (int k = 0; k < LU_LEAF; ++k) besta[k] = 0.0;
-  for (int rr = 0; rr < rows_per_thread; ++rr) {
+  auto do_row = [&](int rr, bool have_pre, double px0, const double* pa) {
     const int64_t i = base + tid + 256 * (int64_t)rr;
     if (i < m) {
       double* row = Y + i;
       double a[LU_LEAF];
       if (do_update) {
         const bool moved = (i == r);           // this position receives the old row j-1
-        const double x0 = moved ? s_old[0] : (rr == 0 ? pre_x0 : row[jp * ld]);
+        const double x0 = moved ? s_old[0] : (have_pre ? px0 : row[jp * ld]);
         const double lij = (rpiv != 0.0) ? x0 * rpiv : x0;
         row[jp * ld] = lij;
 #pragma unroll
         for (int k = 0; k < LU_LEAF; ++k) {
           if (k < nlive) {
-            const double xk = moved ? s_old[1 + k] : (rr == 0 ? pre_a[k] : row[(j + k) * ld]);
+            const double xk = moved ? s_old[1 + k] : (have_pre ? pa[k] : row[(j + k) * ld]);
             a[k] = xk - lij * s_u[1 + k];
             row[(j + k) * ld] = a[k];
           }
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
       } else {
 #pragma unroll
         for (int k = 0; k < LU_LEAF; ++k)
-          if (k < nlive) a[k] = (rr == 0) ? pre_a[k] : row[(j + k) * ld];
+          if (k < nlive) a[k] = have_pre ? pa[k] : row[(j + k) * ld];
       }
       if (do_argmax) {
         if (i == j) {
@@ -180,7 +189,11 @@ __global__ __launch_bounds__(256) void lu_sweep_kernel(
         }
       }
     }
-  }
+  };
+#pragma unroll
+  for (int rr = 0; rr < LU_PRE; ++rr)
+    if (rr < rows_per_thread) do_row(rr, true, pre_x0[rr], pre_a[rr]);
+  for (int rr = LU_PRE; rr < rows_per_thread; ++rr) do_row(rr, false, 0.0, nullptr);
   if (!do_argmax) return;
   __syncthreads();   // s_val / s_idx reuse
   s_val[tid] = best; s_idx[tid] = besti;
