@@ -453,10 +453,23 @@ size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K) {
   return ns > 1 ? (size_t)ns * (size_t)M * (size_t)L : 0;
 }
 
+// The kernel addresses a tile with one uniform 64-bit base per operand plus 32-bit per-thread byte offsets, which
+// span up to 160 columns of B, 128 rows of a transposed A or 32 columns of a plain A.  Leading dimensions beyond
+// that reach (n > ~3.3 million) are refused here -- recorded and reported by the backend's launch check -- instead of
+// wrapping around into a memory fault.
+static thread_local bool g_gemm_dim_refused = false;
+bool gemm_take_dim_error() { const bool r = g_gemm_dim_refused; g_gemm_dim_refused = false; return r; }
+
 static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M, int64_t L, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                         int64_t ldc, double* ws) {
   if (M <= 0 || L <= 0) return;
+  {
+    const uint64_t lim = (uint64_t)1 << 32;
+    const uint64_t bspan = 8ull * ((uint64_t)(NTMAX * 16) * (uint64_t)ldb + BK);
+    const uint64_t aspan = (gen != nullptr) ? 0ull : 8ull * ((uint64_t)(transA ? BMT : BK) * (uint64_t)lda + BMT);
+    if (bspan >= lim || aspan >= lim) { g_gemm_dim_refused = true; return; }
+  }
   // columns are processed in chunks of nt*16 <= 160; balance the chunks
   const int64_t tiles = (L + 15) / 16;
   const int64_t nchunks = (tiles + NTMAX - 1) / NTMAX;

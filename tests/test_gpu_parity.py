@@ -606,3 +606,22 @@ def test_fft_powerlaw_randsvd(gsi, ctx):
     assert rel_sv_err(S, Sr, K) < 1e-9
     assert np.abs(Z @ Z.T - Zr @ Zr.T).max() < 1e-8 * Sr[0]
     op.close()
+
+
+@pytest.mark.gpu
+def test_panel_row_limit_is_an_error_not_a_fault(gsi, ctx):
+    """The contraction kernel's 32-bit tile offsets reach ~3.35 million rows of a panel; beyond that the library must
+    refuse (GSI_ERR_ARG) instead of wrapping addresses.  Exercised with the matrix-free FFT operator (n = 2^22)."""
+    op = gsi.fft_powerlaw_operator(ctx, (2048, 2048), -3.0)      # n = 4 194 304, nothing of size n^2 or n*l is needed
+    n = 2048 * 2048
+    Om = gsi.DeviceMatrix(ctx, n, 4).randn(1)
+    Z = gsi.DeviceMatrix(ctx, n, 4)
+    S = gsi.DeviceMatrix(ctx, 4, 1)
+    status = ctx.lib.gsi_randsvd_dev(ctx.h, op.h, Om.h, 3, 1, 1, Z.h, S.h)
+    assert status == 1, (status, ctx.lib.gsi_last_error())         # GSI_ERR_ARG
+    assert b"3.3 million" in ctx.lib.gsi_last_error()
+    for h in (Om, Z, S, op):
+        h.close()
+    # the context stays usable
+    A = gaussian_cov(8, 8, 2.0)
+    assert np.abs(gsi.gemm(A, A) - A @ A).max() < 1e-12
