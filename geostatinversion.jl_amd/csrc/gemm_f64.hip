@@ -79,12 +79,17 @@ struct GenA {
 // leading dimension).  It keeps the 16-byte stream of the operator and loads the X pairs per column, predicated,
 // with 8-byte alignment (measured at l = 150: 28.0 -> 21.3 ms); folding that into the regular kernel as a
 // second fast path cost the regular case 2.7 %, hence the template parameter.
-template <int NT, bool TRANS_A, bool GEN, bool RAGGED>
+// XMODE 2 = irregular X with 64-bit per-thread offsets: leading dimensions beyond the reach of the 32-bit tile
+// offsets (160 columns * ld * 8 B >= 4 GiB, i.e. panels of more than ~3.3 million rows).  Slower addressing, same code.
+template <int NT, bool TRANS_A, bool GEN, int XMODE>
 __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     int64_t M, int64_t L, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* __restrict__ C, int64_t ldc, double alpha,
     double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, int wide, GenA gen) {
   static_assert(!(GEN && TRANS_A), "the generated operand is symmetric: only the NN form exists");
+  constexpr bool RAGGED = XMODE != 0;
+  constexpr bool BIG = XMODE == 2;
+  using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
   constexpr int A_ELEMS = TRANS_A ? BMT * BKP : BK * BMP;
   constexpr int B_ELEMS = NT * 16 * BKP;
   constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
@@ -127,10 +132,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   const int b_c = tid / (BK / 2);
   const int b_k = 2 * (tid % (BK / 2));
 
-  const uint32_t a_off0 = 8u * (TRANS_A ? (uint32_t)(a_k + (int64_t)a_r * lda) : (uint32_t)(a_r + (int64_t)a_k * lda));
-  const uint32_t a_step_c = 8u * (uint32_t)((TRANS_A ? RSTEP : KSTEP_NN) * lda);
-  const uint32_t b_off0 = 8u * (uint32_t)(b_k + (int64_t)b_c * ldb);
-  const uint32_t b_step_c = 8u * (uint32_t)(RSTEP * ldb);
+  const off_t a_off0 = (off_t)8 * (TRANS_A ? (off_t)(a_k + (int64_t)a_r * lda) : (off_t)(a_r + (int64_t)a_k * lda));
+  const off_t a_step_c = (off_t)8 * (off_t)((TRANS_A ? RSTEP : KSTEP_NN) * lda);
+  const off_t b_off0 = (off_t)8 * (off_t)(b_k + (int64_t)b_c * ldb);
+  const off_t b_step_c = (off_t)8 * (off_t)(RSTEP * ldb);
   // byte distance between the two elements of a pair when they cannot be fetched as one 16-B load
   const char* const Abase = reinterpret_cast<const char*>(TRANS_A ? A + r0 * lda : A + r0);
   const char* const Bbase = reinterpret_cast<const char*>(B + c0 * ldb);
@@ -182,15 +187,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     const char* Bb = Bbase + 8 * k0;                          // uniform
     // launder the strides so the per-load offsets are recomputed per tile (one VALU add each)
     // instead of staying live in VGPRs across the MFMA loop
-    uint32_t a_step = a_step_c, b_step = b_step_c;
-    asm volatile("" : "+s"(a_step), "+s"(b_step));
+    off_t a_step = a_step_c, b_step = b_step_c;
+    if constexpr (!BIG) asm volatile("" : "+s"(a_step), "+s"(b_step));
     if (wide && wg_full && k0 + BK <= kend) {
       if constexpr (!GEN) {
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it)
         {   // A is streamed once: non-temporal, to keep it out of the way of the X tiles in L2
           typedef double nt_double2 __attribute__((ext_vector_type(2)));
-          const nt_double2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_double2*>(Ab + (a_off0 + (uint32_t)it * a_step)));
+          const nt_double2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_double2*>(Ab + (a_off0 + (off_t)it * a_step)));
           a_reg[set][it].x = v.x; a_reg[set][it].y = v.y;
         }
       }
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
           const int cl = b_c + RSTEP * it;
           if (cl < NT * 16 && c0 + cl < L) {   // X may be only 8-byte aligned here (odd n as leading dimension)
             typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
-            const double2_u v = *reinterpret_cast<const double2_u*>(Bb + (b_off0 + (uint32_t)it * b_step));
+            const double2_u v = *reinterpret_cast<const double2_u*>(Bb + (b_off0 + (off_t)it * b_step));
             b_reg[set][it] = make_double2(v.x, v.y);
           } else {
             b_reg[set][it] = make_double2(0.0, 0.0);
@@ -211,14 +216,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 #pragma unroll
       for (int it = 0; it < B_PAIRS; ++it)
         if (!B_RAGGED || b_c + RSTEP * it < NT * 16)
-          b_reg[set][it] = *reinterpret_cast<const double2*>(Bb + (b_off0 + (uint32_t)it * b_step));
+          b_reg[set][it] = *reinterpret_cast<const double2*>(Bb + (b_off0 + (off_t)it * b_step));
       return;
     }
     // general path: element-wise, predicated (edges, odd leading dimensions, unaligned views)
     if constexpr (!GEN) {
 #pragma unroll
     for (int it = 0; it < A_PAIRS; ++it) {
-      const char* p = Ab + (a_off0 + (uint32_t)it * a_step);
+      const char* p = Ab + (a_off0 + (off_t)it * a_step);
       const int64_t r = TRANS_A ? r0 + a_r + RSTEP * it : r0 + a_r;
       const int64_t k = TRANS_A ? k0 + a_k : k0 + a_k + KSTEP_NN * it;
       const bool ok0 = (r < M && k < kend);
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     }
 #pragma unroll
     for (int it = 0; it < B_PAIRS; ++it) {
-      const char* p = Bb + (b_off0 + (uint32_t)it * b_step);
+      const char* p = Bb + (b_off0 + (off_t)it * b_step);
       const int cl = b_c + RSTEP * it;
       const int64_t c = c0 + cl;
       const int64_t k = k0 + b_k;
@@ -384,18 +389,18 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t L, int nsplit, const dou
   }
 }
 
-template <int NT, bool TRANS_A, bool GEN, bool RAGGED>
+template <int NT, bool TRANS_A, bool GEN, int XMODE>
 static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A,
                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha,
                       double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide, const GenA& gen) {
   constexpr size_t shmem = 2 * ((TRANS_A ? BMT * BKP : BK * BMP) + NT * 16 * BKP) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<NT, TRANS_A, GEN, RAGGED>,
+    (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<NT, TRANS_A, GEN, XMODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<NT, TRANS_A, GEN, RAGGED>), grid, dim3(NTHREADS), shmem, st, M, L, K, A, lda, B, ldb, C,
+  hipLaunchKernelGGL((gemm_f64_kernel<NT, TRANS_A, GEN, XMODE>), grid, dim3(NTHREADS), shmem, st, M, L, K, A, lda, B, ldb, C,
                      ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen);
 }
 
@@ -403,13 +408,15 @@ template <bool TRANS_A, bool GEN>
 static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K,
                             const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
                             int64_t ldc, double alpha, double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide,
-                            bool irregular_x, const GenA& gen) {
+                            int xmode, const GenA& gen) {
 #define GSI_CASE(N)                                                                             \
   case N:                                                                                       \
-    if (irregular_x)                                                                              \
-      launch_nt<N, TRANS_A, GEN, true>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
+    if (xmode == 2)                                                                               \
+      launch_nt<N, TRANS_A, GEN, 2>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
+    else if (xmode == 1)                                                                          \
+      launch_nt<N, TRANS_A, GEN, 1>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
     else                                                                                          \
-      launch_nt<N, TRANS_A, GEN, false>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
+      launch_nt<N, TRANS_A, GEN, 0>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
     break;
   switch (nt) {
     GSI_CASE(1) GSI_CASE(2) GSI_CASE(3) GSI_CASE(4) GSI_CASE(5)
@@ -453,23 +460,17 @@ size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K) {
   return ns > 1 ? (size_t)ns * (size_t)M * (size_t)L : 0;
 }
 
-// The kernel addresses a tile with one uniform 64-bit base per operand plus 32-bit per-thread byte offsets, which
-// span up to 160 columns of B, 128 rows of a transposed A or 32 columns of a plain A.  Leading dimensions beyond
-// that reach (n > ~3.3 million) are refused here -- recorded and reported by the backend's launch check -- instead of
-// wrapping around into a memory fault.
-static thread_local bool g_gemm_dim_refused = false;
-bool gemm_take_dim_error() { const bool r = g_gemm_dim_refused; g_gemm_dim_refused = false; return r; }
-
 static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M, int64_t L, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                         int64_t ldc, double* ws) {
   if (M <= 0 || L <= 0) return;
-  {
-    const uint64_t lim = (uint64_t)1 << 32;
-    const uint64_t bspan = 8ull * ((uint64_t)(NTMAX * 16) * (uint64_t)ldb + BK);
-    const uint64_t aspan = (gen != nullptr) ? 0ull : 8ull * ((uint64_t)(transA ? BMT : BK) * (uint64_t)lda + BMT);
-    if (bspan >= lim || aspan >= lim) { g_gemm_dim_refused = true; return; }
-  }
+  // The kernel addresses a tile with one uniform 64-bit base per operand plus per-thread byte offsets spanning up to
+  // 160 columns of B, 128 rows of a transposed A or 32 columns of a plain A: 32 bits reach panels of ~3.3 million
+  // rows; beyond that the 64-bit-offset instantiation (XMODE 2) takes over.
+  const uint64_t lim = (uint64_t)1 << 32;
+  const uint64_t bspan = 8ull * ((uint64_t)(NTMAX * 16) * (uint64_t)ldb + BK);
+  const uint64_t aspan = (gen != nullptr) ? 0ull : 8ull * ((uint64_t)(transA ? BMT : BK) * (uint64_t)lda + BMT);
+  const bool big = bspan >= lim || aspan >= lim;
   // columns are processed in chunks of nt*16 <= 160; balance the chunks
   const int64_t tiles = (L + 15) / 16;
   const int64_t nchunks = (tiles + NTMAX - 1) / NTMAX;
@@ -488,14 +489,15 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   // regular kernel: everything 16-byte loadable and full 16-column tiles; irregular-X kernel: the operator is,
   // X is ragged or only 8-byte aligned; otherwise (operator itself unaligned) the element-wise path of the regular one
   const bool irregular_x = a_ok && (!b_ok || L % ((int64_t)nt * 16) != 0);
-  const int wide = a_ok && (b_ok || irregular_x) ? 1 : 0;
+  const int wide = a_ok ? 1 : 0;
+  const int xmode = big ? 2 : (irregular_x ? 1 : 0);
   const GenA none = {nullptr, nullptr, 1, 0, 0, 0};
   if (gen != nullptr)
-    launch_dispatch<false, true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, irregular_x, *gen);
+    launch_dispatch<false, true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, *gen);
   else if (transA)
-    launch_dispatch<true, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, irregular_x, none);
+    launch_dispatch<true, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, none);
   else
-    launch_dispatch<false, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, irregular_x, none);
+    launch_dispatch<false, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, none);
   if (ns_eff > 1) {
     const int64_t total = M * L;
     int blocks = (int)((total + 255) / 256);

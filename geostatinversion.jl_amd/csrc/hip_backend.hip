@@ -475,9 +475,6 @@ class HipBackend : public Backend {
     return e;
   }
   void check_launch(const char* what) {
-    if (hipk::gemm_take_dim_error())
-      throw Error(GSI_ERR_ARG, std::string(what) + ": a panel has more than ~3.3 million rows; the contraction kernel's "
-                               "32-bit tile offsets do not reach that far (DESIGN.md, limits)");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) throw Error(GSI_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
   }

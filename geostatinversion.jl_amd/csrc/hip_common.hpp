@@ -10,8 +10,6 @@ namespace gsi { namespace hipk {
 size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K);
 void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, double alpha, const double* A,
               int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws);
-// true (once) if a product was refused because a leading dimension exceeds the 32-bit tile-offset reach
-bool gemm_take_dim_error();
 // C = G * B, G(i,k) = ex[|x_i-x_k|] ey[|y_i-y_k|] generated in registers (tab = [ex(nx) | ey(ny)])
 void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* tab, int64_t nx, int64_t ny,
                       int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws);

@@ -609,19 +609,22 @@ def test_fft_powerlaw_randsvd(gsi, ctx):
 
 
 @pytest.mark.gpu
-def test_panel_row_limit_is_an_error_not_a_fault(gsi, ctx):
-    """The contraction kernel's 32-bit tile offsets reach ~3.35 million rows of a panel; beyond that the library must
-    refuse (GSI_ERR_ARG) instead of wrapping addresses.  Exercised with the matrix-free FFT operator (n = 2^22)."""
-    op = gsi.fft_powerlaw_operator(ctx, (2048, 2048), -3.0)      # n = 4 194 304, nothing of size n^2 or n*l is needed
-    n = 2048 * 2048
-    Om = gsi.DeviceMatrix(ctx, n, 4).randn(1)
-    Z = gsi.DeviceMatrix(ctx, n, 4)
-    S = gsi.DeviceMatrix(ctx, 4, 1)
-    status = ctx.lib.gsi_randsvd_dev(ctx.h, op.h, Om.h, 3, 1, 1, Z.h, S.h)
-    assert status == 1, (status, ctx.lib.gsi_last_error())         # GSI_ERR_ARG
-    assert b"3.3 million" in ctx.lib.gsi_last_error()
-    for h in (Om, Z, S, op):
-        h.close()
-    # the context stays usable
-    A = gaussian_cov(8, 8, 2.0)
-    assert np.abs(gsi.gemm(A, A) - A @ A).max() < 1e-12
+def test_panels_beyond_32bit_tile_offsets(gsi, ctx):
+    """Panels of more than ~3.36 million rows: 160 columns * ld * 8 B no longer fits the contraction kernel's 32-bit
+    per-thread offsets, so the 64-bit-offset instantiation carries the panel products inside LU (trailing updates),
+    CholeskyQR (Gram matrices, Y R^-1) and the tall SVD.  Checked against LAPACK on the same panel."""
+    m, l = 3_400_000, 24
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((m, l)) * np.logspace(0, -3, l)[None, :]
+    L, piv = gsi.lu_L(Y, return_pivots=True)
+    assert np.array_equal(piv, orc.lu_pivots(Y))
+    assert np.abs(L - orc.lu_L(Y)).max() < 1e-10
+    del L
+    Q, R = gsi.qr_thinQ(Y, return_R=True)
+    assert np.abs(Q.T @ Q - np.eye(l)).max() < 1e-12
+    assert np.abs(Q @ R - Y).max() < 1e-11
+    del Q
+    S, V = gsi.svd_tall(Y)
+    Sref = np.linalg.svd(Y, compute_uv=False)
+    assert np.abs(S - Sref).max() < 1e-11 * Sref[0]
+    assert np.abs(V.T @ V - np.eye(l)).max() < 1e-11
