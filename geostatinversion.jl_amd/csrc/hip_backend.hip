@@ -120,7 +120,7 @@ class HipBackend : public Backend {
           sizes_.pop_back();
           break;
         }
-      if (bytes != 0 && bytes <= ((size_t)8 << 30)) {   // operators (tens of GB) are not worth caching
+      if (bytes != 0 && bytes <= ((size_t)24 << 30)) {   // stored operators (tens of GB) are not worth caching
         pool_.push_back({p, bytes});
         pooled_ += (int64_t)bytes;
         p = nullptr;
@@ -130,7 +130,10 @@ class HipBackend : public Backend {
       hipStreamSynchronize(st_);
       hipFree(p);
     }
-    if (pooled_ > ((int64_t)4 << 30) && pooled_ > in_use_ / 2) trim_pool(in_use_ / 4);
+    // Panels of the tall problems are GBs each and come back every pass: keep up to 64 GB of them (of 288 GB; a
+    // failed hipMalloc empties the cache and retries, so nothing is ever refused because of it).  A tighter policy
+    // cost 0.7 s of hipFree/hipMalloc per randsvd at n = 1.7e7.
+    if (pooled_ > ((int64_t)64 << 30)) trim_pool((int64_t)32 << 30);
   }
   void trim_pool(int64_t keep_bytes) {
     hipStreamSynchronize(st_);
