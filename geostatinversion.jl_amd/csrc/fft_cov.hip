@@ -37,6 +37,7 @@ __device__ inline double2 csub(double2 a, double2 b) { return make_double2(a.x -
 // pass reads the two real columns of X; SCALE the last forward pass multiplies by the spectrum as it stores; STOREY
 // the last inverse pass writes the two real columns of Y.  sign = -1 forward, +1 inverse (unnormalised).
 enum { FFT_AXIS0 = 1, FFT_LOADX = 2, FFT_SCALE = 4, FFT_STOREY = 8 };
+constexpr int FFT_TW_LEN = 4096;     // longest supported line; the plan stores exp(-2 pi i k / 4096), k < 2048
 struct FftPass {
   int Ma, log2Ma, nin, nout, T;
   int64_t estride, R1, S1, R2, S2;
@@ -44,7 +45,7 @@ struct FftPass {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, int64_t Mtot, FftPass ps,
+__global__ __launch_bounds__(1024) void fft_pass_kernel(double2* __restrict__ W, int64_t Mtot, FftPass ps,
                                                        const double* __restrict__ lam, const double* __restrict__ X,
                                                        int64_t ldx, double* __restrict__ Y, int64_t ldy, int64_t N0,
                                                        int64_t col0, int64_t l) {
@@ -57,10 +58,15 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
   const int lstride = Ma + 1;
   double2* Wb = W + (int64_t)blockIdx.y * Mtot;
   const int64_t ca = col0 + 2 * (int64_t)blockIdx.y, cb = ca + 1;
-  for (int k = tid; k < Ma / 2; k += nth) {
-    double s, c;
-    sincospi(2.0 * (double)k / (double)Ma, &s, &c);
-    tw[k] = make_double2(c, ps.sign * s);
+  // twiddles exp(sign 2 pi i k / Ma) from the plan's table for the longest line (FFT_TW_LEN points): an L2 read
+  // instead of Ma/2 sincospi evaluations per workgroup
+  {
+    const double2* twg = reinterpret_cast<const double2*>(lam + Mtot + 64);
+    const int tstep = FFT_TW_LEN / Ma;
+    for (int k = tid; k < Ma / 2; k += nth) {
+      const double2 w = twg[k * tstep];
+      tw[k] = make_double2(w.x, -ps.sign * w.y);      // table holds the forward sign
+    }
   }
   // tile -> first line; line j of the tile: AXIS0: outer o0 + j, else inner i0 + j of outer o0
   const int64_t nouter = ps.R1 * ps.R2;
@@ -197,8 +203,21 @@ static int ilog2(int64_t v) { int r = 0; while (((int64_t)1 << r) < v) ++r; retu
 
 int64_t fft_embed_size(int64_t N) { int64_t m = 1; while (m < 2 * N) m <<= 1; return (N == 1) ? 1 : m; }
 
+__global__ __launch_bounds__(256) void fft_twiddle_kernel(double2* __restrict__ twg) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < FFT_TW_LEN / 2) {
+    double s, c;
+    sincospi(2.0 * (double)k / (double)FFT_TW_LEN, &s, &c);
+    twg[k] = make_double2(c, -s);
+  }
+}
+
+// lam layout: [Mtot spectrum | 64 scratch | FFT_TW_LEN doubles of twiddles]
+size_t fft_plan_doubles(const int64_t M[3]) { return (size_t)(M[0] * M[1] * M[2]) + 64 + FFT_TW_LEN; }
+
 void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3], double beta) {
   const int64_t Mtot = M[0] * M[1] * M[2];
+  hipLaunchKernelGGL(fft_twiddle_kernel, dim3(FFT_TW_LEN / 2 / 256), dim3(256), 0, st, reinterpret_cast<double2*>(lam + Mtot + 64));
   hipLaunchKernelGGL(fft_spectrum_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, M[0], M[1], M[2], beta);
   hipLaunchKernelGGL(fft_sum_kernel, dim3(64), dim3(256), 0, st, lam, Mtot, part64);
   hipLaunchKernelGGL(fft_normalise_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, part64, 64);
@@ -247,7 +266,7 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
   if (T < 1) T = 1;
   ps.T = T;
   const size_t shmem = twb + (size_t)T * line_bytes;
-  const int threads = ((int64_t)T * ps.Ma >= 4096) ? 512 : 256;
+  const int threads = ((int64_t)T * ps.Ma >= 4096) ? 1024 : (((int64_t)T * ps.Ma >= 2048) ? 512 : 256);
   const int64_t nouter = ps.R1 * ps.R2;
   const int64_t tiles = (axis == 0) ? (nouter + T - 1) / T : ((ps.estride + T - 1) / T) * nouter;
   dim3 grid((unsigned)tiles, (unsigned)nb);

@@ -218,7 +218,7 @@ class HipBackend : public Backend {
     // work array: as many column pairs at once as fit ~2 GB, at most 64
     int64_t nb = ((int64_t)2 << 30) / (16 * Mtot);
     p->nb_max = (int)std::max<int64_t>(1, std::min<int64_t>(nb, 64));
-    p->lam = alloc((size_t)Mtot + 64);
+    p->lam = alloc(hipk::fft_plan_doubles(p->M));
     try { p->W = alloc((size_t)2 * Mtot * p->nb_max); } catch (...) { release(p->lam); throw; }
     hipk::fft_spectrum(st_, p->lam, p->lam + Mtot, p->M, beta);
     check_launch("fft_spectrum");
