@@ -101,6 +101,7 @@ def main():
     use_dist = world > 1 or bool(os.environ.get("GSI_BENCH_FORCE_DIST"))   # the latter: rehearse the N > 1 code on one GPU
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: no hostname resolution for the rendezvous group
         import torch
         import torch.distributed as dist
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # rendezvous / barrier only
