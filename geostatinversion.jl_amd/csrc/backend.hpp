@@ -65,8 +65,11 @@ class Backend {
   // Y (m x l, ld) <- L of lu(Y) in pivoted row order; ipiv (device int32[l]) may be null.
   // Sets *singular_flag (backend int, see flags()) to j+1 on an exactly zero pivot.
   virtual void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv_host_or_null) = 0;
-  // Y (m x l) <- thin Q; R (l x l, ld l) <- upper triangular factor if R != null
-  virtual void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R) = 0;
+  // Y (m x l) <- thin Q; R (l x l, ld l) <- upper triangular factor if R != null.
+  // replicated: the same panel is factored by every rank and the results must be bit-identical everywhere
+  // (stacked R factors of the TSQR, gathered panels): the backend must then not let anything rank-local
+  // (e.g. which algorithm tier an earlier rank-local panel needed) steer the choice of algorithm.
+  virtual void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R, bool replicated = false) = 0;
   // G (l x l, ld l), columns orthogonalised in place by one-sided Jacobi; on return
   // U (l x l) = left singular vectors sorted by descending S, S (l) singular values.
   virtual void svd_small(double* G, int64_t l, double* U, double* S) = 0;

@@ -227,11 +227,9 @@ template <int MODE>
 static void launch_pass(hipStream_t st, dim3 grid, int threads, size_t shmem, double2* W, int64_t Mtot, const FftPass& ps,
                         const double* lam, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t N0, int64_t col0,
                         int64_t l) {
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr_mask{0};
+  if (first_use_on_this_device(attr_mask))
     (void)hipFuncSetAttribute((const void*)fft_pass_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    attr = true;
-  }
   hipLaunchKernelGGL((fft_pass_kernel<MODE>), grid, dim3(threads), shmem, st, W, Mtot, ps, lam, X, ldx, Y, ldy, N0, col0, l);
 }
 

@@ -394,12 +394,10 @@ static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K
                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha,
                       double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide, const GenA& gen) {
   constexpr size_t shmem = 2 * ((TRANS_A ? BMT * BKP : BK * BMP) + NT * 16 * BKP) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_mask{0};
+  if (first_use_on_this_device(attr_mask))
     (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<NT, TRANS_A, GEN, XMODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    attr_set = true;
-  }
   hipLaunchKernelGGL((gemm_f64_kernel<NT, TRANS_A, GEN, XMODE>), grid, dim3(NTHREADS), shmem, st, M, L, K, A, lda, B, ldb, C,
                      ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen);
 }

@@ -265,7 +265,7 @@ class HipBackend : public Backend {
       HIP_CHECK(hipStreamSynchronize(st_));
     }
   }
-  void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R) override {
+  void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R, bool replicated) override {
     bind();
     const int64_t nb = hipk::qr_max_blocks(m);
     const int NB = hipk::QR_NB;
@@ -292,15 +292,16 @@ class HipBackend : public Backend {
     // Three tiers, each leaving Y untouched until it is known to have worked (one 4-byte flag read):
     //   CholeskyQR2 (a handful of MFMA passes; needs cond(Y) < ~1e7), shifted CholeskyQR3 (cond up to ~1e13: sketches
     //   of fast-decaying covariance spectra), Householder reflectors (anything, including exact rank deficiency).
-    // A panel that needed the second tier makes the next few factorizations OF THE SAME HEIGHT start there:
-    // consecutive panels of one operator are alike, and a failed first attempt costs ~1.2 ms at C2.  Keyed by the
-    // height so that, with several ranks, the replicated factorizations (stacked R factors, G*l rows: identical
-    // input everywhere) never see a hint left by a rank's own row block and stay bit-identical across ranks.
+    // A panel that needed the second tier makes the next few factorizations OF THE SAME HEIGHT AND KIND start there:
+    // consecutive panels of one operator are alike, and a failed first attempt costs ~1.2 ms at C2.  Keyed by
+    // (height, replicated) so that, with several ranks, the replicated factorizations (stacked R factors, gathered
+    // panels: identical input everywhere) never see a hint left by a rank's own row block -- not even when a row
+    // block happens to have G*l rows -- and stay bit-identical across ranks.
     static const bool no_cholqr = (getenv("GSI_NO_CHOLQR") != nullptr);
     if (!no_cholqr && l <= 1024 && m >= 2 * l) {
       const int64_t ldt = (m + 1) & ~(int64_t)1;   // even: 16-byte loads in the contraction kernel
       int32_t f = 0;
-      int& skip_tier1_ = skip_tier1_by_height_[m];
+      int& skip_tier1_ = skip_tier1_by_height_[std::make_pair(m, replicated)];
       if (skip_tier1_ > 0) {
         --skip_tier1_;
       } else {
@@ -515,7 +516,7 @@ class HipBackend : public Backend {
   int64_t acc_n_[PH_COUNT] = {0};
   int last_svd_sweeps_ = 0;
   int64_t n_cholqr_ = 0, n_householder_ = 0, n_scholqr3_ = 0;
-  std::map<int64_t, int> skip_tier1_by_height_;
+  std::map<std::pair<int64_t, bool>, int> skip_tier1_by_height_;
 };
 
 // ---- RCCL, bound lazily so a single-GPU user never needs librccl to resolve -----------------

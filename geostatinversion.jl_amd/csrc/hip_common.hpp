@@ -1,10 +1,21 @@
 // hip_common.hpp -- declarations shared by the gfx950 kernel files and hip_backend.hip
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstddef>
 
 namespace gsi { namespace hipk {
+
+// The > 64 KB dynamic-LDS opt-in (hipFuncSetAttribute) is a property of a kernel ON ONE DEVICE.  A process may
+// hold one context per GPU (one thread per GPU, include/gsi_hip.h), so "done once" is tracked per device: one
+// bit per device ordinal, one mask per kernel instantiation.  Racing first calls both set the attribute (idempotent).
+inline bool first_use_on_this_device(std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown: set the attribute again
+  const uint64_t bit = (uint64_t)1 << dev;
+  return (mask.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+}
 
 // ---- gemm_f64.hip ----
 size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K);

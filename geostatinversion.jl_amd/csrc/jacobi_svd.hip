@@ -153,12 +153,10 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
   if (nblk < 2) nblk = 2;
   if (nblk & 1) ++nblk;
   const size_t shmem = (size_t)SVD_C * lp * sizeof(double) + 16;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_mask{0};
+  if (first_use_on_this_device(attr_mask))
     (void)hipFuncSetAttribute((const void*)jacobi_block_kernel<SVD_W>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024 - 64);
-    attr_set = true;
-  }
   const double tol = sqrt((double)l) * DBL_EPSILON;
   const double tol2 = tol * tol;
   const int max_sweeps = 40;

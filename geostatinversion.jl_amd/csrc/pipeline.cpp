@@ -38,7 +38,9 @@ Operator::~Operator() {
 void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* Yloc, int64_t ldy) {
   Context& c = *A.ctx;
   Backend* be = c.be.get();
-  if (A.mloc == 0) return;
+  // a rank without rows (m < rank * ceil(m / G)) has nothing to compute, but it still takes part in every
+  // collective below: only the collective-free operator kinds may leave early
+  if (A.mloc == 0 && A.kind != OP_LOWRANK) return;
   if (A.kind == OP_FFT_COV) {     // matrix-free: pad, FFT passes, spectrum, inverse passes, restrict (single rank)
     ScopedPhase ph(be, PH_GEMM_N);
     be->fftcov_apply(A.plan, l, X, ldx, Yloc, ldy);
@@ -58,13 +60,14 @@ void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* 
   Buf T(be, (size_t)A.N * l);
   {
     ScopedPhase ph(be, PH_GEMM_T);
-    be->gemm_tn(A.N, l, A.mloc, 1.0, A.data.p, A.ld, X + A.row0, ldx, 0.0, T.p, A.N);
+    if (A.mloc > 0) be->gemm_tn(A.N, l, A.mloc, 1.0, A.data.p, A.ld, X + A.row0, ldx, 0.0, T.p, A.N);
+    else be->fill_zero(T.p, (size_t)A.N * l);
   }
   if (c.comm) {
     ScopedPhase ph(be, PH_COMM);
     c.comm->allreduce_sum(T.p, (size_t)A.N * l);
   }
-  {
+  if (A.mloc > 0) {
     ScopedPhase ph(be, PH_GEMM_N);
     be->gemm_nn(A.mloc, l, A.N, 1.0 / (double)(A.N - 1), A.data.p, A.ld, T.p, A.N, 0.0, Yloc, ldy);
   }
@@ -242,7 +245,7 @@ static void tsqr(Context& c, int64_t m, int64_t row0, int64_t mloc, Buf& Yloc, i
     gather_rows(c, shape, Yloc.p, mloc, l, Yfull.p);
     {
       ScopedPhase ph(be, PH_QR);
-      be->qr_thinQ(Yfull.p, m, l, m, Rout);
+      be->qr_thinQ(Yfull.p, m, l, m, Rout, true);
     }
     be->copy2d(Yloc.p, mloc, Yfull.p + row0, m, mloc, l);
     return;
@@ -260,7 +263,7 @@ static void tsqr(Context& c, int64_t m, int64_t row0, int64_t mloc, Buf& Yloc, i
   for (int g = 0; g < G; ++g) be->copy2d(stack.p + (int64_t)g * l, sl, Rall.p + (size_t)g * l * l, l, l, l);
   {
     ScopedPhase ph(be, PH_QR);
-    be->qr_thinQ(stack.p, sl, l, sl, Rout);
+    be->qr_thinQ(stack.p, sl, l, sl, Rout, true);
   }
   Buf Qn(be, (size_t)mloc * l);
   {
@@ -317,7 +320,7 @@ void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, doub
   Buf R(be, (size_t)l * l), U(be, (size_t)l * l);
   {
     ScopedPhase ph(be, PH_QR);
-    be->qr_thinQ(W, n, l, n, R.p);                          // B' = Q_B R
+    be->qr_thinQ(W, n, l, n, R.p, c.comm != nullptr);        // B' = Q_B R (W replicated)
   }
   {
     ScopedPhase ph(be, PH_SVD);

@@ -158,7 +158,7 @@ class CpuBackend : public Backend {
     const int info = gsio_lu_L(Y, m, l, ld, ipiv);
     if (info && !lu_info_) lu_info_ = info;
   }
-  void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R) override {
+  void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R, bool /*replicated*/) override {
     gsio_qr_thinQ(Y, m, l, ld, 0, R, nullptr);   // unpivoted, like the HIP backend (same range)
   }
   void svd_small(double* G, int64_t l, double* U, double* S) override {

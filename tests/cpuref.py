@@ -6,8 +6,9 @@ import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CPUREF = os.path.join(ROOT, "oracle", "_build", "libgsi_cpuref.so")
-ORACLE_C = os.path.join(ROOT, "oracle", "_build", "libgsi_oracle.so")
+# GSI_CPUREF_LIB / GSI_ORACLE_C_LIB: point the CPU suite at the sanitizer builds (`make -C oracle asan`)
+CPUREF = os.environ.get("GSI_CPUREF_LIB") or os.path.join(ROOT, "oracle", "_build", "libgsi_cpuref.so")
+ORACLE_C = os.environ.get("GSI_ORACLE_C_LIB") or os.path.join(ROOT, "oracle", "_build", "libgsi_oracle.so")
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64)
 ALLGATHER_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)

@@ -95,6 +95,17 @@ def _worker(rank, world, port, q):
         X = rng.standard_normal((81, 4))
         results["lowrank_mul"] = float(np.abs(lr.matmul(X) - orc.LowRankCovMatrix(fields).matmul(X)).max())
         lr.close()
+        # LowRankCovMatrix whose last rank holds NO rows (n = 4: shards 2/2/0 at world 3, 2/2 at world 2): the
+        # empty rank must still enter the all-reduce of S'X inside every product (a skipped collective hangs RCCL)
+        small = [rng.standard_normal(4) for _ in range(6)]
+        lr4 = gsi.LowRankCovMatrix(small, ctx=ctx)
+        X4 = rng.standard_normal((4, 3))
+        results["lowrank_empty_rank_mul"] = float(np.abs(lr4.matmul(X4) - orc.LowRankCovMatrix(small).matmul(X4)).max())
+        Om4 = rng.standard_normal((4, 3))
+        Z4, S4 = gsi.randsvd(lr4, 2, 1, 1, Omega=Om4, return_S=True)
+        x4, _ = orc.getxis_fields(small, 2, 1, 1, Om4)
+        results["lowrank_empty_rank_xis"] = orc.xis_error_up_to_sign(Z4, np.array(x4).T, 2)
+        lr4.close()
         # operator products gathered to every rank
         op = gsi.dense_operator(ctx, B)
         X = rng.standard_normal((60, 3))
@@ -147,7 +158,7 @@ def test_sharded_pipeline_gloo(world):
     for rank, _, res in out:
         for k, v in res.items():
             tol = 1e-6 if k.endswith("xis") else 1e-9
-            if k.endswith("orth") or k in ("mul", "mul_t", "lowrank_mul", "implicit_mul", "implicit_mul_t"):
+            if k.endswith("orth") or k in ("mul", "mul_t", "lowrank_mul", "lowrank_empty_rank_mul", "implicit_mul", "implicit_mul_t"):
                 tol = 1e-11
             assert v < tol, (rank, k, v)
     # every rank computed the same replicated result
