@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- randSVD throughput of the HIP path on MI355X.
+"""bench.py -- randSVD throughput of the HIP path on MI355X, on the configuration BASELINE.json's metric names.
 
-One "step" = one `randsvd(A, K, p, q)` (RandMatFact.jl:83-90) with the operator A and the Gaussian
-test matrix Omega already resident in HBM.  Workload at N = 1: BASELINE.json configs[1] -- dense
-fp64 65536 x 65536 Gaussian covariance (256 x 256 unit grid, ell = 16), K = 128, p = 32 (l = 160),
-q = 2.  For N > 1 the matrix is row-sharded over the ranks, RCCL all-reduce / all-gather between the
-passes.  Default `--scaling weak`: every GPU keeps the SAME 34 GB row shard as at
-N = 1 (n grows as sqrt(N): 256 x round(256 sqrt(N)) grid, per-GPU contraction work fixed) -- multi-GPU exists
-here to factor covariances that do not fit one GPU.  `--scaling strong` shards the N = 1 matrix instead.
+One "step" = one `randsvd(A, K, p, q)` (RandMatFact.jl:83-90) with the operator A and the Gaussian test matrix
+Omega already resident in HBM.
 
-metric value   = algorithmic GB/s of the whole job: (2q+2) * (8 n^2 + 16 n l) bytes / step time
-roofline       = the dominant kernel (the fp64 MFMA contraction A*X / A'*X): 2 n^2 l flop per
-                 launch / its average launch duration, HIP events on the library's stream inside
-                 the timed region; peak = 78.6 TFLOP/s dense fp64 MFMA
-cpu_baseline   = the numpy/scipy oracle (same LAPACK/BLAS call sequence as the Julia reference) on
-                 a bounded sample of the same workload (n = 50176), all host cores; the same sample
-                 gives `sv_rel_err` (top-K singular values, GPU vs oracle, same Omega)
+Headline workload (N = 1, BASELINE.json metric "n=1e6 rank=256"): n = 10^6 grid points,
+A = LowRankCovMatrix over N_s = 1024 synthetic sample fields (8.2 GB of mean-removed samples in HBM, generated on
+the device), K = 256, p = 64 (l = 320), q = 2.  Every product A*X is two MFMA contractions S (S'X)/(N_s-1).
+For --gpus N > 1 the SAME problem is row-sharded over the ranks (`--scaling strong`, the default: north_star's
+">= 6x at 8 GPUs" is a strong-scaling statement); `--scaling weak` gives every rank 10^6 rows instead.
+
+metric value = algorithmic GB/s of the whole job: [(2q+2) products x (16 n N_s + 16 n l) + (2q + 2) panel
+               factorizations x 16 n l] bytes / step time        
+roofline     = the dominant kernel, the fp64 MFMA contraction gemm_f64_kernel: 2 n N_s l flop per launch over its
+               average launch duration (HIP events on the library's stream around every operator contraction inside
+               the timed region), against the 78.6 TFLOP/s dense fp64 MFMA peak; the same launches against the HBM
+               peak ("hbm"); `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of this very command
+               (tools/profile_bench.sh -> profiles/r02_bench_traffic.json; null when that file was collected on a
+               different build of the kernel)
+phases_hbm   = the HBM-bound panel phases (LU, QR, Z = Q_W U): one read + one write of the n x l panel per
+               factorization over the measured time per factorization, against 8 TB/s
+secondary    = BASELINE.json configs[1] (dense fp64 65536^2, K = 128, q = 2: the MFMA-bound stored operator) and ONE
+               step of the n = 10^6 implicit dense covariance (entries generated in the contraction kernel)
+cpu_baseline = the numpy/scipy oracle (the reference's algorithm: N_s rank-1 ger!/gemv sweeps per product,
+               dgetrf/dgeqp3/dgesdd panels) on a bounded sample of the same operator class, all host cores; the
+               same sample gives `sv_rel_err` (top-K singular values, GPU vs oracle, same Omega)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,43 +39,87 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
+KERNEL_SOURCES = ["gemm_f64.hip"]          # what `traffic` was measured on (hash recorded next to the counters)
 
 
-def algorithmic_bytes(n, l, q):
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "geostatinversion.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def lrcm_bytes(n, Ns, l, q):
+    P = 2 * q + 2
+    return P * (16.0 * n * Ns + 16.0 * n * l) + (2 * q + 2) * 16.0 * n * l
+
+
+def dense_bytes(n, l, q):
     P = 2 * q + 2
     return P * (8.0 * n * n + 16.0 * n * l)
 
 
-def cpu_baseline_and_parity(gsi, ctx, K, p, q, grid=224, ell=14.0):
-    """Oracle timed on the host on a bounded sample; GPU result on the same inputs for parity."""
+def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234):
+    """warmup + timed randsvd steps on device-resident inputs; returns (elapsed_s, phases, counters)."""
+    l = K + p
+    Omega = gsi.DeviceMatrix(ctx, n, l).randn(seed)
+    Z = gsi.DeviceMatrix(ctx, n, l)
+    S = gsi.DeviceMatrix(ctx, l, 1)
+    lib = ctx.lib
+
+    def step():
+        gsi._lib.check(lib.gsi_randsvd_dev(ctx.h, op.h, Omega.h, K, p, q, Z.h, S.h), lib)
+
+    for _ in range(warmup):
+        step()
+    ctx.profile(True)
+    ctx.phase_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    phases = ctx.phase_times()
+    ctx.profile(False)
+    Sh = S.to_host()[:, 0].copy()
+    for m in (Omega, Z, S):
+        m.close()
+    return elapsed, phases, Sh
+
+
+def host_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([i.get("num_threads", 1) for i in threadpool_info()] + [1]))
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline_and_parity(gsi, ctx, Ns, K, p, q, n_s, decay):
+    """Oracle timed on the host on a bounded sample of the same operator class; GPU on the same inputs for parity."""
     import numpy as np
     from oracle import oracle as orc
     from helpers import rel_sv_err
-    n, l = grid * grid, K + p
-    gx = np.repeat(np.arange(grid, dtype=np.float64), grid)          # point i = (i // grid, i % grid)
-    gy = 1.3 * np.tile(np.arange(grid, dtype=np.float64), grid)      # anisotropic spacing: no x<->y degenerate pairs
-    A = (gx[:, None] - gx[None, :]) ** 2
-    A += (gy[:, None] - gy[None, :]) ** 2
-    A *= -1.0 / (2.0 * ell * ell)
-    np.exp(A, out=A)
+    l = K + p
     rng = np.random.default_rng(0)
-    Omega = rng.standard_normal((n, l))
+    S = rng.standard_normal((Ns, n_s)) * (np.arange(1, Ns + 1.0) ** -decay)[:, None]     # sample j = row j
+    Omega = rng.standard_normal((n_s, l))
+    A = orc.LowRankCovMatrix(S)
     t0 = time.perf_counter()
     Zref, Sref, _ = orc.randsvd_full(A, K, p, q, Omega)
     t_cpu = time.perf_counter() - t0
-    Z, S = gsi.randsvd(A, K, p, q, Omega=Omega, return_S=True, ctx=ctx)
-    err = rel_sv_err(S, Sref, K)
+    lr = gsi.LowRankCovMatrix(S, ctx=ctx)
+    Z, Sv = gsi.randsvd(lr, K, p, q, Omega=Omega, return_S=True)
+    lr.close()
+    err = rel_sv_err(Sv, Sref, K)
     xerr = orc.xis_error_up_to_sign(Z, Zref, K)
-    del A
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
     return {
-        "value": algorithmic_bytes(n, l, q) / t_cpu / 1e9, "unit": "GB/s", "cores": int(cores), "kind": "port",
-        "sample": f"same workload at n={n} ({grid}x{grid} grid, y spacing 1.3, ell={ell}), K={K}, p={p}, q={q}: "
-                  f"numpy/scipy oracle (dgemm/dgetrf/dgeqp3/dgesdd, OpenBLAS) {t_cpu:.2f} s",
+        "value": lrcm_bytes(n_s, Ns, l, q) / t_cpu / 1e9, "unit": "GB/s", "cores": host_threads(), "kind": "port",
+        "sample": f"same operator class at n={n_s}: LowRankCovMatrix over {Ns} samples (decay {decay}), K={K}, p={p}, "
+                  f"q={q}; numpy/scipy oracle = the reference's algorithm (lowrank.jl:115-121: {Ns} rank-1 "
+                  f"gemv/ger sweeps per product; dgetrf/dgeqp3/dgesdd panels, OpenBLAS) {t_cpu:.2f} s",
         "seconds": t_cpu,
     }, err, xerr
 
@@ -78,15 +132,18 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", type=int, default=256, help="nx = ny of the unit grid (n = grid^2)")
-    ap.add_argument("--ell", type=float, default=16.0)
-    ap.add_argument("--K", type=int, default=128)
-    ap.add_argument("--p", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1000000, help="grid points of the headline LowRankCovMatrix")
+    ap.add_argument("--samples", type=int, default=1024, help="sample fields N_s")
+    ap.add_argument("--decay", type=float, default=0.75, help="sample j is scaled by (j+1)^-decay")
+    ap.add_argument("--K", type=int, default=256)
+    ap.add_argument("--p", type=int, default=64)
     ap.add_argument("--q", type=int, default=2)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 dense and the implicit 10^6 steps")
+    ap.add_argument("--cpu-sample-n", type=int, default=16384)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,91 +165,139 @@ def main():
 
     ctx = gsi.Context(local_rank)
     if use_dist:
-        import torch
         ids = [ctx.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(world, rank, ids[0])                  # RCCL communicator over xGMI
-
-    nx = args.grid
-    ny = args.grid if args.scaling == "strong" else int(round(args.grid * world ** 0.5))   # n^2 / N fixed
-    n = nx * ny
-    K, p, q = args.K, args.p, args.q
-    l = K + p
-    op = gsi.gridcov_operator(ctx, nx, ny, args.ell, 0)                     # A resident in HBM
-    Omega = gsi.DeviceMatrix(ctx, n, l).randn(1234)                          # Omega resident in HBM
-    Z = gsi.DeviceMatrix(ctx, n, l)
-    S = gsi.DeviceMatrix(ctx, l, 1)
-    lib = ctx.lib
-
-    def step():
-        gsi._lib.check(lib.gsi_randsvd_dev(ctx.h, op.h, Omega.h, K, p, q, Z.h, S.h), lib)
 
     def barrier():
         ctx.sync()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.profile(True)
-    ctx.phase_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    phases = ctx.phase_times()
-    ctx.profile(False)
-    if dist is not None:
+    def max_over_ranks(x):
+        if dist is None:
+            return x
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    # ---------------- headline: n = 1e6 LowRankCovMatrix, rank 256 -------------------------------------------
+    n = args.n if args.scaling == "strong" else args.n * world
+    Ns, K, p, q = args.samples, args.K, args.p, args.q
+    l = K + p
+    op = gsi.lowrank_synthetic_operator(ctx, n, Ns, seed=0, decay=args.decay)      # samples generated + centred in HBM
+    elapsed, phases, Sv = run_steps(gsi, ctx, op, n, K, p, q, args.steps, args.warmup, barrier)
+    elapsed = max_over_ranks(elapsed)
+    counters = ctx.counters()
+    dev_bytes = ctx.device_bytes()
+    op.close()
 
     ms_per_step = 1e3 * elapsed / args.steps
-    value = algorithmic_bytes(n, l, q) * args.steps / elapsed / 1e9
-
-    # dominant kernel: the fp64 MFMA contraction over the operator (this rank's row shard)
-    row0, mloc = ctx.shard(n)
+    value = lrcm_bytes(n, Ns, l, q) * args.steps / elapsed / 1e9
+    row0, nloc = ctx.shard(n)
     g_ms = phases["gemm_n"][0] + phases["gemm_t"][0]
     g_cnt = phases["gemm_n"][1] + phases["gemm_t"][1]
     avg_ms = g_ms / max(g_cnt, 1)
-    flops_per_launch = 2.0 * mloc * n * l
+    flops_per_launch = 2.0 * nloc * Ns * l                   # both S'X (N_s x l, K = n) and S T (n x l, K = N_s)
+    bytes_per_launch = 8.0 * nloc * (Ns + l)                 # the sample shard once + the tall panel once
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    hbm_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-    if os.path.exists(tpath) and world == 1 and n == 65536 and l == 160:   # counters were collected on this shape
+    tpath = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
+    if os.path.exists(tpath) and world == 1:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            t = json.load(open(tpath))
+            if (t.get("kernel_source_hash") == kernel_source_hash() and t.get("n") == n and t.get("samples") == Ns
+                    and t.get("l") == l):
+                traffic = t.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                "kernel": "gemm_f64_kernel<NT,TRANS_A,GEN> (v_mfma_f64_16x16x4_f64)",
-                "avg_launch_ms": avg_ms, "launches": int(g_cnt),
-                "hbm_frac_of_A_stream": (8.0 * mloc * n / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if avg_ms > 0 else 0.0}
+    roofline = {
+        "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+        "kernel": "gemm_f64_kernel<NT,TRANS_A,GEN,XMODE> (v_mfma_f64_16x16x4_f64) + its fixed-order split-K slab reduction",
+        "avg_launch_ms": avg_ms, "launches": int(g_cnt),
+        "flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+        "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
+                "note": "intensity 2 N_s l / (8 (N_s + l)) = %.0f flop/B >> ridge 9.8: the contraction is MFMA-bound; "
+                        "at full MFMA peak this stream would reach %.2f of the HBM peak" % (
+                            2.0 * Ns * l / (8.0 * (Ns + l)),
+                            (bytes_per_launch / (flops_per_launch / (PEAK_FP64_MFMA_TFLOPS * 1e12))) / 1e9 / PEAK_HBM_GBS)},
+    }
+    panel_bytes = 16.0 * n * l                               # one read + one write of the (replicated) n x l panel
+    phases_hbm = {}
+    for name, key in (("lu", "lu"), ("qr", "qr"), ("z_product", "small_gemm")):
+        ms, cnt = phases[key]
+        if cnt > 0 and ms > 0:
+            per = ms / cnt
+            phases_hbm[name] = {"ms_per_factorization": per, "factorizations_per_step": cnt / args.steps,
+                                "algorithmic_bytes": panel_bytes, "GB/s": panel_bytes / (per * 1e-3) / 1e9,
+                                "frac_of_hbm_peak": panel_bytes / (per * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    phases_hbm["svd_small_jacobi_ms_per_step"] = phases["svd"][0] / args.steps
 
     if rank == 0:
         out = {
-            "metric": "randSVD GB/s + top-k singular-value rel-err", "value": value, "unit": "GB/s",
+            "metric": "randSVD GB/s + top-k singular-value rel-err, n=1e6 rank=256", "value": value, "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"dense fp64 {n}x{n} Gaussian covariance ({nx}x{ny} grid, "
-                                   f"ell={args.ell}), K={K}, p={p}, q={q} (BASELINE.json configs[1]"
-                                   + ("" if world == 1 else
-                                      (", n scaled by sqrt(N): same 34 GB row shard per GPU" if args.scaling == "weak"
-                                       else ", same matrix row-sharded")) + ")",
-                       "n": n, "K": K, "p": p, "q": q, "parallelism": f"row-shard x{world}",
-                       "operator_bytes_per_gpu": 8.0 * mloc * n},
+            "config": {"workload": f"n={n} grid points, LowRankCovMatrix over N_s={Ns} synthetic sample fields "
+                                   f"({8.0 * n * Ns / 1e9:.1f} GB in HBM), rank K={K}, p={p} (l={l}), q={q} "
+                                   f"(BASELINE.json metric config; SURVEY.md 8d C4-ii)"
+                                   + ("" if world == 1 else (", same problem row-sharded" if args.scaling == "strong"
+                                                              else ", 1e6 rows per GPU")),
+                       "n": n, "samples": Ns, "K": K, "p": p, "q": q, "parallelism": f"row-shard x{world}",
+                       "operator_bytes_per_gpu": 8.0 * nloc * Ns, "device_bytes_in_use": dev_bytes},
             "roofline": roofline,
+            "phases_hbm": phases_hbm,
             "phases_ms_per_step": {k: v[0] / args.steps for k, v in phases.items()},
             "phase_launch_groups_per_step": {k: v[1] / args.steps for k, v in phases.items()},
-            "path_counters": ctx.counters(),
+            "path_counters": counters,
+            "algorithmic_bytes_per_step": lrcm_bytes(n, Ns, l, q),
         }
+        # size-independent property at the full size: the trailing p singular values exist, descending, positive
+        out["sv_descending_positive"] = bool(all(Sv[i] >= Sv[i + 1] for i in range(l - 1)) and Sv[K - 1] > 0)
+
+    # ---------------- secondary workloads (one GPU only) -------------------------------------------------------
+    if world == 1 and not args.no_secondary:
+        sec = {}
+        # BASELINE.json configs[1]: dense fp64 65536^2 Gaussian covariance, K = 128, p = 32, q = 2
+        g, K2, p2, q2 = 256, 128, 32, 2
+        n2, l2 = g * g, K2 + p2
+        op2 = gsi.gridcov_operator(ctx, g, g, 16.0, 0)
+        e2, ph2, _ = run_steps(gsi, ctx, op2, n2, K2, p2, q2, 5, 1, barrier)
+        op2.close()
+        gm = ph2["gemm_n"][0] + ph2["gemm_t"][0]
+        gc = ph2["gemm_n"][1] + ph2["gemm_t"][1]
+        tf = 2.0 * n2 * n2 * l2 / (gm / gc * 1e-3) / 1e12
+        sec["c2_dense_65536"] = {
+            "workload": f"dense fp64 {n2}x{n2} Gaussian covariance (256x256 grid, ell=16), K={K2}, p={p2}, q={q2} "
+                        "(BASELINE.json configs[1])",
+            "steps": 5, "ms_per_step": 1e3 * e2 / 5, "GB/s": dense_bytes(n2, l2, q2) * 5 / e2 / 1e9,
+            "gemm_TFLOP/s": tf, "gemm_frac_of_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
+            "hbm_frac_of_A_stream": 8.0 * n2 * n2 / (gm / gc * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "phases_ms_per_step": {k: v[0] / 5 for k, v in ph2.items()}}
+        # n = 1e6 dense covariance, never stored (north_star "10^6 x 10^6-implicit"): ONE step, no warm-up
+        gi, K3, p3, q3 = 1000, 256, 64, 2
+        n3, l3 = gi * gi, K3 + p3
+        op3 = gsi.gridcov_implicit_operator(ctx, gi, gi, 50.0)
+        e3, ph3, _ = run_steps(gsi, ctx, op3, n3, K3, p3, q3, 1, 0, barrier)
+        op3.close()
+        gm = ph3["gemm_n"][0] + ph3["gemm_t"][0]
+        gc = ph3["gemm_n"][1] + ph3["gemm_t"][1]
+        tf = 2.0 * n3 * n3 * l3 / (gm / gc * 1e-3) / 1e12
+        sec["implicit_dense_1e6"] = {
+            "workload": f"implicit dense fp64 {n3}x{n3} Gaussian grid covariance (1000x1000 grid, ell=50; 8 TB if stored), "
+                        f"K={K3}, p={p3}, q={q3}: entries generated inside the contraction kernel",
+            "steps": 1, "ms_per_step": 1e3 * e3, "equivalent_stored_GB/s": dense_bytes(n3, l3, q3) / e3 / 1e9,
+            "gemm_TFLOP/s": tf, "gemm_frac_of_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
+            "phases_ms_per_step": {k: v[0] for k, v in ph3.items()}}
+        out["secondary"] = sec
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            cb, err, xerr = cpu_baseline_and_parity(gsi, ctx, K, p, q)
+            cb, err, xerr = cpu_baseline_and_parity(gsi, ctx, Ns, K, p, q, args.cpu_sample_n, args.decay)
             out["cpu_baseline"] = cb
             out["sv_rel_err"] = err
             out["xis_err_up_to_sign"] = xerr

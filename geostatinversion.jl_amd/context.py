@@ -161,6 +161,16 @@ def gridcov_operator(ctx, nx, ny, ell, kind=0):
     return Operator(ctx, h)
 
 
+def lowrank_synthetic_operator(ctx, n, N, seed=0, decay=0.75):
+    """`LowRankCovMatrix` over N synthetic sample fields of n points generated and centred in HBM (SURVEY.md 8d,
+    C4-ii): sample j = (j+1)^-decay * iid N(0,1).  Row-sharded like every operator."""
+    row0, nloc = ctx.shard(n)
+    h = C.c_void_p()
+    L.check(ctx.lib.gsi_op_lowrank_synthetic(ctx.h, C.byref(h), int(n), int(N), int(seed), float(decay), row0, nloc),
+            ctx.lib)
+    return Operator(ctx, h)
+
+
 def gridcov_implicit_operator(ctx, nx, ny, ell):
     """The Gaussian grid covariance of `gridcov_operator(kind=0)` as an implicit operator: entries are
     regenerated inside the product kernel, nothing of size n^2 is stored."""

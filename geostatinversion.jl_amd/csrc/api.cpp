@@ -162,6 +162,24 @@ int gsi_op_lowrank(gsi_ctx* ctx, gsi_op** op, const double* samples, int64_t n, 
   });
 }
 
+int gsi_op_lowrank_synthetic(gsi_ctx* ctx, gsi_op** op, int64_t n, int64_t N, uint64_t seed, double decay,
+                             int64_t row0, int64_t n_local) {
+  return guarded([&] {
+    REQUIRE(ctx && op, "NULL argument");
+    *op = nullptr;
+    REQUIRE(n >= 1 && N >= 2 && decay >= 0.0, "bad synthetic sample parameters (need N >= 2 samples, decay >= 0)");
+    check_shard(ctx->c, n, row0, n_local);
+    std::unique_ptr<gsi_op> o(new gsi_op());
+    Operator& A = o->op;
+    A.ctx = &ctx->c; A.kind = OP_LOWRANK; A.m = n; A.n = n; A.row0 = row0; A.mloc = n_local; A.N = N;
+    A.ld = n_local > 0 ? ((n_local + 15) / 16) * 16 : 16;
+    A.data = Buf(ctx->c.be.get(), (size_t)A.ld * N);
+    ctx->c.be->fill_lowrank_samples(A.data.p, A.ld, n_local, N, row0, seed, decay);
+    ctx->c.be->center_rows(A.data.p, n_local, N, A.ld);   // lowrank.jl:17-27
+    *op = o.release();
+  });
+}
+
 int gsi_op_dense_gridcov(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, double ell, int kind,
                          int64_t row0, int64_t m_local) {
   return guarded([&] {

@@ -87,6 +87,10 @@ class Backend {
   // synthetic covariance rows [row0,row0+mloc) of an (nx*ny)^2 grid covariance
   virtual void fill_gridcov(double* A, int64_t lda, int64_t nx, int64_t ny, double ell, int kind,
                             int64_t row0, int64_t mloc) = 0;
+  // synthetic sample fields (benchmark / test input): S(i, j) = g(row0 + i, j) (j+1)^-decay, g iid N(0,1) addressed
+  // by the global index (identical for every rank layout)
+  virtual void fill_lowrank_samples(double* S, int64_t ld, int64_t nloc, int64_t N, int64_t row0, uint64_t seed,
+                                    double decay) = 0;
   // column norms of Y (m x c) -> host array
   virtual void colnorms(const double* Y, int64_t m, int64_t c, int64_t ld, double* host_out) = 0;
   // y <- y - Q (Q' y) for Q m x j (classical Gram-Schmidt step of Alg 4.2), y length m

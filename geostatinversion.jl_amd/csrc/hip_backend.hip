@@ -383,6 +383,12 @@ class HipBackend : public Backend {
     hipk::fill_gridcov(st_, A, lda, nx, ny, ell, kind, row0, mloc);
     check_launch("fill_gridcov");
   }
+  void fill_lowrank_samples(double* S, int64_t ld, int64_t nloc, int64_t N, int64_t row0, uint64_t seed,
+                            double decay) override {
+    bind();
+    hipk::fill_lowrank_samples(st_, S, ld, nloc, N, row0, seed, decay);
+    check_launch("fill_lowrank_samples");
+  }
   void colnorms(const double* Y, int64_t m, int64_t c, int64_t ld, double* host_out) override {
     bind();
     if (c > 64) throw Error(GSI_ERR_ARG, "colnorms: at most 64 columns at a time");

@@ -92,6 +92,8 @@ void scale_cols_sqrt(hipStream_t st, double* U, int64_t l, const double* S, int6
 void randn_fill(hipStream_t st, double* p, size_t count, uint64_t seed);
 void fill_gridcov(hipStream_t st, double* A, int64_t lda, int64_t nx, int64_t ny, double ell, int kind,
                   int64_t row0, int64_t mloc);
+void fill_lowrank_samples(hipStream_t st, double* S, int64_t ld, int64_t nloc, int64_t N, int64_t row0, uint64_t seed,
+                          double decay);
 void colnorms_sq(hipStream_t st, const double* Y, int64_t m, int64_t c, int64_t ld, double* out_dev);
 void chol_upper(hipStream_t st, double* B, int64_t j, int32_t* info);
 void trsm_right_upper(hipStream_t st, double* F, int64_t m, int64_t j, int64_t ldf, const double* C);

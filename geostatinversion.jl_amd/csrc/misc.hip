@@ -83,6 +83,45 @@ void randn_fill(hipStream_t st, double* p, size_t count, uint64_t seed) {
                      (uint64_t)count, seed);
 }
 
+// ---- synthetic sample fields for a LowRankCovMatrix: S(i, j) = g(i, j) (j+1)^-decay with
+// g iid N(0,1) addressed by the GLOBAL (row, sample) index, so every row shard of every rank layout draws the
+// same matrix.  Benchmark / test input only (the reference's fields come from FFTRF on the host).
+__global__ void lowrank_samples_kernel(double* __restrict__ S, int64_t ld, int64_t nloc, int64_t N, int64_t row0,
+                                       uint64_t seed, double decay) {
+  const int64_t j = blockIdx.y;
+  for (int64_t jj = j; jj < N; jj += gridDim.y) {
+    const double scale = pow((double)(jj + 1), -decay);
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nloc; r += (int64_t)gridDim.x * blockDim.x) {
+      const uint64_t g = (uint64_t)(row0 + r);
+      const uint64_t pair = g >> 1;
+      uint32_t c0 = (uint32_t)pair, c1 = (uint32_t)(pair >> 32), c2 = (uint32_t)jj, c3 = 0x10c0ffeeu;
+      uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+      for (int rd = 0; rd < 10; ++rd) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+      }
+      const uint64_t a = ((uint64_t)c0 << 32) | c1;
+      const uint64_t b = ((uint64_t)c2 << 32) | c3;
+      const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+      const double u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+      const double rad = sqrt(-2.0 * log(u1));
+      double sn, cs;
+      sincospi(2.0 * u2, &sn, &cs);
+      S[r + jj * ld] = scale * rad * ((g & 1) ? sn : cs);
+    }
+  }
+}
+void fill_lowrank_samples(hipStream_t st, double* S, int64_t ld, int64_t nloc, int64_t N, int64_t row0, uint64_t seed,
+                          double decay) {
+  if (nloc <= 0 || N <= 0) return;
+  int gx = (int)((nloc + 255) / 256);
+  if (gx > 256) gx = 256;
+  const int gy = (int)((N < 4096) ? N : 4096);
+  hipLaunchKernelGGL(lowrank_samples_kernel, dim3(gx, gy), dim3(256), 0, st, S, ld, nloc, N, row0, seed, decay);
+}
+
 // ---- synthetic covariance of an nx x ny unit grid ------------------------------
 // point i = (i / ny, i % ny).  kind 0: exp(-d^2/(2 ell^2)); kind 1: exp(-d/ell).
 __global__ void gridcov_kernel(double* __restrict__ A, int64_t lda, int64_t nx, int64_t ny, double ell,

@@ -195,6 +195,16 @@ class CpuBackend : public Backend {
         A[r + c * lda] = kind == 0 ? std::exp(-d2 / (2 * ell * ell)) : std::exp(-std::sqrt(d2) / ell);
       }
   }
+  void fill_lowrank_samples(double* S, int64_t ld, int64_t nloc, int64_t N, int64_t row0, uint64_t seed,
+                            double decay) override {
+    // any generator addressed by the global (row, sample) index will do here (not the HIP backend's stream)
+    for (int64_t j = 0; j < N; ++j)
+      for (int64_t r = 0; r < nloc; ++r) {
+        std::mt19937_64 g(seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(row0 + r + 1)) ^ (0xC2B2AE3D27D4EB4Full * (uint64_t)(j + 1)));
+        std::normal_distribution<double> d;
+        S[r + j * ld] = d(g) * std::pow((double)(j + 1), -decay);
+      }
+  }
   void colnorms(const double* Y, int64_t m, int64_t c, int64_t ld, double* out) override {
     for (int64_t j = 0; j < c; ++j) {
       double s = 0.0;

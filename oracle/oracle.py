@@ -38,6 +38,7 @@ same array is handed to the oracle and to the HIP path.
 from __future__ import annotations
 
 import numpy as np
+from scipy.linalg import blas as _blas
 import scipy.linalg as sl
 
 __all__ = [
@@ -228,11 +229,18 @@ class LowRankCovMatrix:
         B = np.asarray(B, dtype=np.float64)
         vec = B.ndim == 1
         B2 = B[:, None] if vec else B
-        out = np.zeros((self.n, B2.shape[1]))
         alpha = 1.0 / (self.N - 1)
+        if vec:
+            out = np.zeros(self.n)
+            for s in self.samples:
+                out += alpha * (s * np.dot(B, s))             # BLAS.axpy!(1/(N-1), s * dot(x, s), v)   :75-81
+            return out
+        # BLAS.ger!(1/(N-1), s, B's, result), in place like the reference (:115-121)
+        out = np.zeros((self.n, B2.shape[1]), order="F")
+        Bt = np.ascontiguousarray(B2.T)
         for s in self.samples:
-            out += alpha * np.outer(s, B2.T @ s)
-        return out[:, 0] if vec else out
+            out = _blas.dger(alpha, s, Bt @ s, a=out, overwrite_a=1)
+        return out
 
     def rmatmul(self, B: np.ndarray) -> np.ndarray:
         """``*(B::Matrix, A::LowRankCovMatrix)``  (lowrank.jl:123-129)."""
