@@ -46,6 +46,7 @@ class HipBackend : public Backend {
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device_));
     arch_ = prop.gcnArchName;
+    ncus_ = prop.multiProcessorCount;
     if (arch_.find("gfx950") == std::string::npos)
       throw Error(GSI_ERR_HIP, "libgsi_hip is built for gfx950 (MI355X); device reports " + arch_);
     HIP_CHECK(hipStreamCreate(&st_));
@@ -240,6 +241,29 @@ class HipBackend : public Backend {
   // ---- panels ----
   void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv_host) override {
     bind();
+    // Panels of up to 4096 rows per CU: leaves held in registers, left-looking blocks, streaming rank-64 updates
+    // (panel_lu_leaf.hip).  Taller panels (and GSI_LU_SWEEPS=1, the A/B knob) take the per-column sweeps below.
+    static const bool force_sweeps = (getenv("GSI_LU_SWEEPS") != nullptr);
+    hipk::Lu2Work w2;
+    if (!force_sweeps && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid)) {
+      static const int nb_env = getenv("GSI_LU_NB") ? atoi(getenv("GSI_LU_NB")) : 0;
+      w2.nb = (nb_env == 32 || nb_env == 64) ? nb_env : hipk::LU2_NB;
+      const size_t rec_bytes = sizeof(unsigned long long) * 2 * ((size_t)w2.grid + hipk::LU2_RES_COPIES) * hipk::LU2_REC_GRANULES;
+      const size_t u12_bytes = sizeof(double) * (size_t)w2.nb * (size_t)l;
+      grow(ws_lu_, rec_bytes + u12_bytes + sizeof(int32_t) * (l + 4) + 256);
+      char* base = (char*)ws_lu_.p;
+      w2.recs = (unsigned long long*)base; base += rec_bytes;
+      w2.u12 = (double*)base; base += u12_bytes;
+      w2.ipiv = (int32_t*)base;
+      w2.info = flags_ + 0;
+      hipk::lu2_L(st_, Y, m, l, ld, w2);
+      check_launch("lu2_L");
+      if (ipiv_host) {
+        HIP_CHECK(hipMemcpyAsync(ipiv_host, w2.ipiv, sizeof(int32_t) * l, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+      }
+      return;
+    }
     const int64_t nb = hipk::lu_max_blocks(m);
     const size_t per_set = sizeof(double) * (size_t)nb + sizeof(int64_t) * (size_t)nb +
                            sizeof(double) * (size_t)nb * (hipk::LU_LEAF + 1) + sizeof(double) * 16;
@@ -426,6 +450,10 @@ class HipBackend : public Backend {
     HIP_CHECK(hipGetLastError());
     if (h[0] != 0 || h[1] != 0) {
       HIP_CHECK(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), st_));
+      if (h[0] < 0) {
+        if (msg) *msg = "lu(): the pivot exchange between workgroups timed out (GPU shared with another job?)";
+        return GSI_ERR_INTERNAL;
+      }
       if (h[0] != 0) {
         if (msg) *msg = "SingularException(" + std::to_string(h[0]) + "): exactly zero pivot in lu()";
         return GSI_ERR_SINGULAR;
@@ -505,6 +533,7 @@ class HipBackend : public Backend {
   }
 
   int device_;
+  int ncus_ = 0;
   std::string arch_;
   hipStream_t st_ = nullptr;
   int32_t* flags_ = nullptr;  // [0] lu info, [1] chol info, [8] jacobi rotation counter

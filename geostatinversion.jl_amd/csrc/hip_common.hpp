@@ -49,6 +49,22 @@ constexpr int LU_LEAF = 8;    // columns factored by per-column sweeps; blocks i
 int64_t lu_max_blocks(int64_t m);
 void lu_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const LuWork& w, double* gemm_ws);
 
+// ---- panel_lu_leaf.hip: register-resident leaves + streaming rank-K updates (panels of <= 4096 rows per CU) ----
+constexpr int LU2_LEAF = 8;           // leaf width: columns a thread keeps in registers
+constexpr int LU2_NB = 64;            // widest block (left-looking leaves inside, one rank-NB update per block)
+constexpr int LU2_RES_COPIES = 8;     // copies of the per-step result record (one per group of pollers)
+constexpr int LU2_REC_GRANULES = 64;  // one published record per workgroup and pivot step: 64 8-byte granules (512 B)
+struct Lu2Work {
+  unsigned long long* recs;   // [2][grid][LU2_REC_GRANULES] candidate records, then [2][LU2_RES_COPIES][LU2_REC_GRANULES] results
+  double* u12;      // [nb * l]
+  int32_t* ipiv;    // [l]
+  int32_t* info;    // [1] first exactly-zero pivot (1-based); -1: the exchange between workgroups timed out
+  int bs, rpt, grid, nb;
+};
+// launch geometry for an m-row panel on a chip with `ncus` CUs; false: the panel does not fit the register file
+bool lu2_config(int64_t m, int ncus, int* bs, int* rpt, int* grid);
+void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu2Work& w);
+
 // ---- panel_qr.hip ----
 constexpr int QR_NB = 16;
 struct QrWork {

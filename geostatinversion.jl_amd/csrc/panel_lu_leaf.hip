@@ -1,0 +1,684 @@
+// panel_lu_leaf.hip -- the register-resident form of `F = lu(Y); Q = F.L` (RandMatFact.jl:60-61, 68-69, 72-73)
+// for panels of up to 4096 rows per CU (n = 10^6 at l = 320 is the case it is built for).  Same pivots as
+// LAPACK dgetrf (first maximal |entry| wins), L in pivoted row order, exactly as panel_lu.hip; what changes
+// is how often the panel crosses HBM.
+//
+// Per-column sweeps (panel_lu.hip) read and write the <= 8 live columns of a leaf once PER COLUMN: 88 column
+// passes per 8-column leaf, and the blocks in between are brought up to date by K = 8/16/32 products that the big
+// contraction kernel runs at 1.3-1.7 TB/s.  Here:
+//   * lu_leaf_kernel: ONE persistent launch per 8-column leaf.  Every thread keeps its rows' 8 leaf values in
+//     registers for all 8 pivot steps (10^6 x 8 doubles = 64 MB = half of the chip's register file), so a leaf costs
+//     one read and one write of its columns.  The launch is also LEFT-LOOKING inside its 64-column block: on load it
+//     applies the pending update of the block's earlier columns (reads kp = j0 - jb columns of L, U12 = L11^-1 A12
+//     is a kp x 8 solve done redundantly by every workgroup, one wave per leaf column), so no in-block trailing
+//     update is ever written back.  Per 64-column block: 8 (0 + 8 + ... + 56) + 128 = 352 column passes.
+//     One exchange per pivot step: every workgroup publishes {max |value|, row, that row's 8 values} (workgroup 0
+//     also row j's values) as one 256-byte record with write-through (sc1) stores, a drained flag store after them;
+//     every workgroup polls all flags, reads all records and reduces them in the same fixed order, so the pivot row's
+//     values are known everywhere without touching rows another workgroup owns (MI355X_MICROARCH.md, "Valid forms":
+//     sc1 payload -> vmcnt(0) -> sc1 flag, sc1 polls and loads; no fences, no atomics).  Two record sets by parity of
+//     the step: a workgroup can publish step s+2 only after it has seen every record of step s+1, which its owner
+//     wrote after it had read step s.
+//   * lu_u12_kernel + lu_rankk_kernel: the block's trailing update A22 -= L21 (L11^-1 A12) as a streaming kernel:
+//     a wave holds 32 rows' K = 64 multipliers as MFMA fragments in registers and walks the trailing columns,
+//     C tile in, 16 x K/4 MFMAs, C tile out (8 flop per byte of C: MFMA time = HBM time at K = 64).
+// Column passes at l = 320, NB = 64: 5 * 352 + 1536 = 3296 (26 GB at n = 10^6) against ~52 GB before.
+#include "hip_common.hpp"
+#include <type_traits>
+#include <cstdio>
+#include <cstdlib>
+
+namespace gsi { namespace hipk {
+
+namespace {
+
+constexpr int LW = LU2_LEAF;           // leaf width (columns kept in registers)
+constexpr int KPMAX = LU2_NB - LW;     // deepest pending update inside a block
+constexpr int LSP = KPMAX + 1;         // padded row stride of the L11 image
+constexpr int REC = LU2_REC_GRANULES;  // 8-byte granules per published record (512 B): unit u = granules 2u (low half), 2u + 1
+constexpr int POLL_LIMIT = 4000000;    // ~ seconds: a record that never arrives ends the launch with info = -1
+
+__device__ inline double readlane_d(double x, int srclane) {   // srclane wave-uniform
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, srclane);
+  hi = __builtin_amdgcn_readlane(hi, srclane);
+  return __hiloint2double(hi, lo);
+}
+// idamax over the wave: the largest value (values are >= 0 or the "no candidate" marker -1, never NaN), then the
+// SMALLEST row among the lanes that hold it (first maximal entry wins, like LAPACK); "no candidate" rows are -1 =
+// 0xFFFFFFFF and lose every tie.  All lanes end with the result.  DPP row shifts / broadcasts (register-file speed:
+// the whole reduction is ~40 VALU instructions), not ds_bpermute shuffles -- 12 dependent LDS round trips measured
+// 0.66 us per reduction, 2-3 of them on the critical path of every pivot step.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_fmax(double v) {
+  // the two halves move as 32-bit integers (the builtin is an integer builtin: a double argument would be VALUE-converted);
+  // lanes without a source lane keep the identity -1.0 = 0xbff00000'00000000
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)0xbff00000, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return fmax(v, __hiloint2double(hi, lo));
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_umin(uint32_t v) {
+  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, ROW_MASK, 0xf, false);
+  return o < v ? o : v;
+}
+__device__ inline void wave_argmax(double& v, int32_t& i) {
+  double mx = v;
+  mx = dpp_fmax<0x111, 0xf>(mx);   // row_shr:1
+  mx = dpp_fmax<0x112, 0xf>(mx);   // row_shr:2
+  mx = dpp_fmax<0x114, 0xf>(mx);   // row_shr:4
+  mx = dpp_fmax<0x118, 0xf>(mx);   // row_shr:8   -> lane 15 of every row holds the row's maximum
+  mx = dpp_fmax<0x142, 0xa>(mx);   // row_bcast:15 into rows 1 and 3
+  mx = dpp_fmax<0x143, 0xc>(mx);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+  mx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mx), 63), __builtin_amdgcn_readlane(__double2loint(mx), 63));
+  uint32_t key = (v == mx) ? (uint32_t)i : 0xFFFFFFFFu;
+  key = dpp_umin<0x111, 0xf>(key);
+  key = dpp_umin<0x112, 0xf>(key);
+  key = dpp_umin<0x114, 0xf>(key);
+  key = dpp_umin<0x118, 0xf>(key);
+  key = dpp_umin<0x142, 0xa>(key);
+  key = dpp_umin<0x143, 0xc>(key);
+  v = mx;
+  i = (int32_t)__builtin_amdgcn_readlane((int)key, 63);
+}
+
+// the same over entries that sit in lanes 0 .. 7 only (per-wave candidates of a workgroup, <= 8 waves): three
+// shifts inside row 0, result read from lane 7
+__device__ inline void wave_argmax8(double& v, int32_t& i) {
+  double mx = v;
+  mx = dpp_fmax<0x111, 0xf>(mx);
+  mx = dpp_fmax<0x112, 0xf>(mx);
+  mx = dpp_fmax<0x114, 0xf>(mx);
+  mx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mx), 7), __builtin_amdgcn_readlane(__double2loint(mx), 7));
+  uint32_t key = (v == mx) ? (uint32_t)i : 0xFFFFFFFFu;
+  key = dpp_umin<0x111, 0xf>(key);
+  key = dpp_umin<0x112, 0xf>(key);
+  key = dpp_umin<0x114, 0xf>(key);
+  v = mx;
+  i = (int32_t)__builtin_amdgcn_readlane((int)key, 7);
+}
+
+#ifdef GSI_LU_TRACE
+// debug build only (hipcc -DGSI_LU_TRACE): 100 MHz wall-clock stamps of the phases of every pivot step of the kp = 0
+// leaves, for 4 workgroups; dumped by lu2_L to $GSI_LU_TRACE
+__device__ unsigned long long g_lu_trace[4 * 8 * 8];
+#define LU_STAMP(ph)                                                                                    \
+  do {                                                                                                  \
+    if (tid == 0 && kp == 0) {                                                                          \
+      const int tw = (g == 0) ? 0 : (g == 1) ? 1 : (g == G / 2) ? 2 : (g == G - 1) ? 3 : -1;              \
+      if (tw >= 0) g_lu_trace[(tw * 8 + s) * 8 + (ph)] = wall_clock64();                                   \
+    }                                                                                                   \
+  } while (0)
+#else
+#define LU_STAMP(ph) do { } while (0)
+#endif
+
+}  // namespace
+
+// One leaf [j0, j0 + w) of the block that starts at column jb (kp = j0 - jb columns of the block already factored).
+// Grid: G workgroups of BS threads, all resident (G <= number of CUs).  Rows j0 .. j0+7 (the leaf's diagonal block:
+// the rows that become pivot rows) are held by threads 0..7 of workgroup 0 in `d`; every other row i >= j0 + 8 by
+// thread (g, tid) as row j0 + 8 + (g R + rr) BS + tid, rr < R, in `a` -- those rows are active in every step and
+// never final, so the code that touches the 8 x R register-resident values is straight-line: no per-row bookkeeping,
+// no control-flow joins (a first version with early exits and per-step conditions made the compiler copy all of them
+// at every join: 2x the registers, 900 spills at R = 8).
+// Few fat waves on purpose: a pivot step is a chain of short dependent phases, and what it costs is the instruction
+// stream per SIMD (a version with 16 waves per CU spent 10 us per step issuing ~1800 instructions per wave).
+//
+// Exchange format.  A record is 18 "units" (doubles): [0] max |value|, [1] row, [2..10) that row's leaf values,
+// [10..18) row j's leaf values (workgroup 0 only).  Every unit travels as two 8-byte granules {32 value bits, 32-bit
+// step tag}, each written by ONE sc1 store: a granule is the unit of atomicity, so a reader that sees the tag of this
+// step in a granule has the data of this step -- no flag, no drain wait, no second round trip behind a flag.
+// Two hops: the LEADER (last workgroup) reads every record, reduces them in a fixed order and publishes ONE result
+// record {max, pivot row, its 8 values, row j's 8 values}; every other workgroup polls only that result (36 granules,
+// one wave).  (Every workgroup sweeping all 256 records itself pulled 10 MB of write-through lines across the fabric
+// per step and measured slower.)
+// A leaf narrower than 8 columns (the panel's last) still runs 8 steps; steps s >= w see zero columns and are
+// gated: no pivot is recorded, nothing is interchanged, the update multiplies zeros.
+template <int BS, int R>
+__global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int64_t ld, int32_t m, int32_t l,
+                                                     int32_t jb, int32_t j0, int w, unsigned long long* __restrict__ recs,
+                                                     uint32_t epoch_base, int32_t* __restrict__ ipiv,
+                                                     int32_t* __restrict__ info) {
+  constexpr int NW = BS / 64;
+  constexpr int LPR = BS / 256;               // leader: consumer lanes per record (G <= 256 records)
+  constexpr int GPL = (2 * (2 + LW)) / LPR;   // leader: granules per consumer lane
+  static_assert(GPL * LPR == 2 * (2 + LW), "record does not divide over its consumer lanes");
+  static_assert(LW == 8, "the step list below is written out for 8-column leaves");
+  __shared__ double Ls[KPMAX * LSP];
+  __shared__ double Us[KPMAX * LW];
+  __shared__ double s_val[NW];
+  __shared__ int32_t s_idx[NW];
+  __shared__ double s_cand[NW][LW];
+  __shared__ double s_oldpub[LW];
+  __shared__ double c_val[NW];
+  __shared__ int32_t c_idx[NW];
+  __shared__ uint32_t c_rowbits[NW][2 * LW];  // the wave-local winner's 8 row values as 16 halves
+  __shared__ uint32_t c_oldbits[2 * LW];
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, G = gridDim.x;
+  const int kp = j0 - jb;
+  if (tid == 0) s_abort = 0;
+
+  // addressing: one uniform 64-bit column base (SGPRs) + a 32-bit per-thread byte offset, so no 64-bit per-element
+  // address stays live in VGPRs between the load at the top and the store at the bottom (m < 2^28 rows)
+  auto colbase = [&](int32_t c) -> char* { return reinterpret_cast<char*>(Y + (int64_t)c * ld); };
+  auto elem = [&](char* base, int32_t i) -> double* { return reinterpret_cast<double*>(base + (uint32_t)i * 8u); };
+  const int32_t row0 = j0 + LW + g * (R * BS) + tid;       // regular rows: row0 + rr BS
+  const bool isdiag = (g == 0 && tid < LW);                // holds row j0 + tid of the diagonal block in d
+  const int32_t drow = j0 + tid;
+  double a[R][LW];
+  double d[LW];
+#pragma unroll
+  for (int k = 0; k < LW; ++k) {
+    char* cb = colbase(j0 + (k < w ? k : 0));
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const int32_t i = row0 + rr * BS;
+      a[rr][k] = (i < m && k < w) ? *elem(cb, i) : 0.0;   // rows beyond m, columns beyond w: zeros
+    }
+    d[k] = (isdiag && drow < m && k < w) ? *elem(cb, drow) : 0.0;
+  }
+
+  // ---- pending update of the block's earlier columns: a -= L[:, jb:j0] * (L11^-1 A12) ----------------------
+  if (kp > 0) {
+    for (int e = tid; e < kp * kp; e += BS) {
+      const int r = e % kp, c = e / kp;
+      Ls[r * LSP + c] = Y[(jb + r) + (int64_t)(jb + c) * ld];
+    }
+    __syncthreads();
+    for (int v = wave; v < LW; v += NW) {          // one wave per leaf column: forward substitution along the lanes
+      double x = (lane < kp && v < w) ? Y[(jb + lane) + (int64_t)(j0 + v) * ld] : 0.0;
+      for (int cp = 0; cp < kp; ++cp) {
+        const double xc = readlane_d(x, __builtin_amdgcn_readfirstlane(cp));
+        if (lane > cp && lane < kp) x -= Ls[lane * LSP + cp] * xc;
+      }
+      if (lane < kp) Us[lane * LW + v] = x;
+    }
+    __syncthreads();
+    for (int c = 0; c < kp; c += 2) {              // kp is a multiple of the leaf width
+      double lv[2][R];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        char* cb = colbase(jb + c + cc);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+          const int32_t i = row0 + rr * BS;
+          lv[cc][rr] = (i < m) ? *elem(cb, i) : 0.0;
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        double u[LW];
+#pragma unroll
+        for (int k = 0; k < LW; ++k) u[k] = Us[(c + cc) * LW + k];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+          for (int k = 0; k < LW; ++k) a[rr][k] -= lv[cc][rr] * u[k];
+      }
+    }
+    if (isdiag && drow < m) {                      // (8 threads of the grid) the diagonal block's rows
+      for (int c = 0; c < kp; ++c) {
+        const double lvd = *elem(colbase(jb + c), drow);
+#pragma unroll
+        for (int k = 0; k < LW; ++k) d[k] -= lvd * Us[c * LW + k];
+      }
+    }
+  }
+
+  // Row interchanges of the columns OUTSIDE the leaf (LAPACK swaps whole rows): column c belongs to workgroup
+  // c % G, thread c / G.  Pipelined one step behind: the two loads of step s are issued when its pivot is known and
+  // stored swapped at step s + 1, so their latency hides behind the next exchange (same thread, program order:
+  // a later load of the same element sees the earlier store).
+  const int32_t swc = g + G * tid;
+  const bool has_col = swc < l && !(swc >= j0 && swc < j0 + w);
+  double* const swcol = Y + (int64_t)(has_col ? swc : 0) * ld;
+  bool pend = false;
+  double pa0 = 0.0, pa1 = 0.0;
+  int32_t pj = 0, pr = 0;
+
+  // one pivot step; S = leaf column (compile time: register index)
+  auto step = [&](auto S_) {
+    constexpr int s = decltype(S_)::value;
+    const bool live = s < w;
+    const int32_t j = j0 + s;
+    const uint32_t epoch = epoch_base + (uint32_t)s + 1u;
+    unsigned long long* rec_set = recs + (size_t)(epoch & 1u) * (size_t)G * REC;
+    LU_STAMP(0);
+    // (a) this thread's, this wave's, this workgroup's candidate for column s; lowest rows first, strict >
+    double best = -1.0;
+    int32_t besti = -1;
+    if (isdiag && tid >= s) { best = fabs(d[s]); besti = drow; }
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const double av = fabs(a[rr][s]);
+      if (av > best) { best = av; besti = row0 + rr * BS; }
+    }
+    double wv = best;
+    int32_t wi = besti;
+    wave_argmax(wv, wi);
+    if (lane == 0) { s_val[wave] = wv; s_idx[wave] = wi; }
+    if (besti >= 0 && besti == wi) {            // the ONE lane of the wave that owns its candidate row: one copy per
+      if (isdiag && besti == drow) {            // wave (~40 instructions) is cheaper than two more barriers
+#pragma unroll
+        for (int k = 0; k < LW; ++k) s_cand[wave][k] = d[k];
+      }
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+        if (row0 + rr * BS == besti) {
+#pragma unroll
+          for (int k = 0; k < LW; ++k) s_cand[wave][k] = a[rr][k];
+        }
+    }
+    if (isdiag && tid == s) {                   // row j itself (the row the pivot row will be exchanged with)
+#pragma unroll
+      for (int k = 0; k < LW; ++k) s_oldpub[k] = d[k];
+    }
+    __syncthreads();
+    LU_STAMP(1);
+    // (b) wave 0 reduces the waves' candidates and publishes the workgroup's record: one granule per lane
+    if (wave == 0) {
+      double pv = (lane < NW) ? s_val[lane] : -1.0;
+      int32_t pi = (lane < NW) ? s_idx[lane] : -1;
+      const int32_t mywi = pi;
+      static_assert(NW <= 8, "wave_argmax8 reduces lanes 0..7");
+      wave_argmax8(pv, pi);
+      const unsigned long long own = __ballot(lane < NW && pi >= 0 && mywi == pi);
+      const int ww = own ? (__ffsll((long long)own) - 1) : 0;
+      const int unit = lane >> 1;
+      if (unit < 2 + LW || (g == 0 && unit < 2 + 2 * LW)) {
+        unsigned long long bits;
+        if (unit == 0) bits = (unsigned long long)__double_as_longlong(pv);
+        else if (unit == 1) bits = (unsigned long long)(long long)pi;
+        else if (unit < 2 + LW) bits = (unsigned long long)__double_as_longlong(s_cand[ww][unit - 2]);
+        else bits = (unsigned long long)__double_as_longlong(s_oldpub[unit - 2 - LW]);
+        const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+        __hip_atomic_store(rec_set + (size_t)g * REC + lane, ((unsigned long long)epoch << 32) | half,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // (c) leader: sweep all records, reduce, publish the result; everyone else: poll the result
+    const bool leader = (g == G - 1);
+    // the result is published in LU2_RES_COPIES copies on lines of their own; workgroup g polls copy g % LU2_RES_COPIES
+    // (255 workgroups polling the same three lines serialise on one memory channel)
+    unsigned long long* res = recs + (size_t)2 * (size_t)G * REC + (size_t)(epoch & 1u) * (size_t)LU2_RES_COPIES * REC;
+    const int ncw = leader ? (G * LPR + 63) / 64 : 1;                     // waves that hold entries of the reduction
+    if (leader) {
+      const int slot = tid / LPR, part = tid % LPR;
+      const bool mine = slot < G;
+      const unsigned long long* src = rec_set + (size_t)(mine ? slot : 0) * REC + part * GPL;
+      const bool extra = tid < 2 * LW;                                    // workgroup 0's copy of row j
+      const unsigned long long* xsrc = rec_set + 2 * (2 + LW) + (extra ? tid : 0);
+      if (wave < ncw) {
+        unsigned long long gl[GPL], gx = 0;
+        int tries = s_abort ? POLL_LIMIT : 0;   // a timed-out launch drains without polling again
+        bool ok;
+        for (;;) {
+#pragma unroll
+          for (int i = 0; i < GPL; ++i) gl[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (extra) gx = __hip_atomic_load(xsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = true;
+          if (mine) {
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) ok = ok && ((uint32_t)(gl[i] >> 32) == epoch);
+          }
+          if (extra) ok = ok && ((uint32_t)(gx >> 32) == epoch);
+          if (__all(ok)) break;
+          if (++tries > POLL_LIMIT) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!__all(ok)) s_abort = 1;
+        LU_STAMP(2);
+        if (extra) c_oldbits[tid] = (uint32_t)gx;
+        // candidate (value, row) sits in the record's first four granules = part 0's gl[0..4)
+        double cv = -1.0;
+        int32_t ci = -1;
+        if (mine && part == 0) {
+          cv = __longlong_as_double((long long)(((unsigned long long)(uint32_t)gl[1] << 32) | (uint32_t)gl[0]));
+          ci = (int32_t)(uint32_t)gl[2];
+        }
+        double rv = cv;
+        int32_t ri = ci;
+        wave_argmax(rv, ri);
+        // the lanes of the wave-local winner's record drop its row values (granules 4..20) into LDS
+        const int32_t myi = __shfl(ci, lane - part);       // the record's row, known to all of its lanes
+        if (mine && ri >= 0 && myi == ri) {
+#pragma unroll
+          for (int i = 0; i < GPL; ++i) {
+            const int gi = part * GPL + i;
+            if (gi >= 4) c_rowbits[wave][gi - 4] = (uint32_t)gl[i];
+          }
+        }
+        if (lane == 0) { c_val[wave] = rv; c_idx[wave] = ri; }
+      }
+      __syncthreads();
+      if (wave == 0) {                          // finish the reduction and publish the result: one granule per lane
+        double fv = (lane < ncw) ? c_val[lane] : -1.0;
+        int32_t fi = (lane < ncw) ? c_idx[lane] : -1;
+        const int32_t myfi = fi;
+        wave_argmax8(fv, fi);
+        const unsigned long long own = __ballot(lane < ncw && fi >= 0 && myfi == fi);
+        const int fw = own ? (__ffsll((long long)own) - 1) : 0;
+        const int unit = lane >> 1;
+        unsigned long long bits = 0;
+        if (unit < 2 + 2 * LW) {
+          if (unit == 0) bits = (unsigned long long)__double_as_longlong(fv);
+          else if (unit == 1) bits = (unsigned long long)(long long)fi;
+          else if (unit < 2 + LW) bits = reinterpret_cast<const unsigned long long*>(c_rowbits[fw])[unit - 2];
+          else bits = reinterpret_cast<const unsigned long long*>(c_oldbits)[unit - 2 - LW];
+          const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+#pragma unroll
+          for (int cpy = 0; cpy < LU2_RES_COPIES; ++cpy)
+            __hip_atomic_store(res + (size_t)cpy * REC + lane, ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        LU_STAMP(3);
+        // the leader's own threads read the result from slot 0, like everybody else
+        if (lane == 0) { c_val[0] = fv; c_idx[0] = fi; }
+        if (unit >= 2 && unit < 2 + LW && (lane & 1) == 0) reinterpret_cast<unsigned long long*>(c_rowbits[0])[unit - 2] = bits;
+      }
+      __syncthreads();
+    } else {
+      if (wave == 0) {                          // poll the leader's result: granule `lane`
+        const bool mine = lane < 2 * (2 + 2 * LW);
+        unsigned long long gv = 0;
+        int tries = s_abort ? POLL_LIMIT : 0;
+        bool ok;
+        for (;;) {
+          if (mine) gv = __hip_atomic_load(res + (size_t)(g % LU2_RES_COPIES) * REC + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = !mine || ((uint32_t)(gv >> 32) == epoch);
+          if (__all(ok)) break;
+          if (++tries > POLL_LIMIT) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!__all(ok)) s_abort = 1;
+        LU_STAMP(3);
+        // lay the result out exactly as the leader's own LDS image: c_val / c_idx [0], c_rowbits[0], c_oldbits
+        if (lane < 2) reinterpret_cast<uint32_t*>(&c_val[0])[lane] = (uint32_t)gv;
+        else if (lane == 2) c_idx[0] = (int32_t)(uint32_t)gv;
+        else if (lane >= 4 && lane < 4 + 2 * LW) c_rowbits[0][lane - 4] = (uint32_t)gv;
+        else if (lane >= 4 + 2 * LW && lane < 4 + 4 * LW) c_oldbits[lane - 4 - 2 * LW] = (uint32_t)gv;
+      }
+      __syncthreads();
+    }
+    LU_STAMP(4);
+    // (d) the result: slot 0 of the LDS image
+    const double bestv = c_val[0];
+    int32_t r = c_idx[0];
+    const bool valid = live && (r >= j && r < m);
+    if (!valid) r = j;                           // all-NaN column (or a gated step): no interchange
+    const double* c_old = reinterpret_cast<const double*>(c_oldbits);
+    const double* c_row = reinterpret_cast<const double*>(c_rowbits[0]);
+    double u[LW];
+#pragma unroll
+    for (int k = 0; k < LW; ++k) u[k] = valid ? c_row[k] : c_old[k];
+    const double piv = u[s];
+    const double rpiv = (piv != 0.0) ? 1.0 / piv : 0.0;
+    // (e) bookkeeping by workgroup 0; pipelined interchange of this thread's column outside the leaf
+    if (g == 0 && tid == 0 && live) {
+      ipiv[j] = r;
+      if (!(bestv > 0.0)) atomicCAS(info, 0, j + 1);
+    }
+    if (has_col) {
+      if (pend) { swcol[pj] = pa1; swcol[pr] = pa0; }
+      pend = (r != j);
+      if (pend) { pa0 = swcol[j]; pa1 = swcol[r]; pj = j; pr = r; }
+    }
+    // (f) rank-1 update in registers: regular rows are all active, none is row j
+    bool hit = false;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) hit = hit || (row0 + rr * BS == r);
+    if (hit) {                                   // (one thread of the whole grid) the old row j moves here
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+        if (row0 + rr * BS == r) {
+#pragma unroll
+          for (int k = 0; k < LW; ++k) a[rr][k] = c_old[k];
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const double x0 = a[rr][s];
+      const double lij = (rpiv != 0.0) ? x0 * rpiv : x0;
+      a[rr][s] = lij;
+#pragma unroll
+      for (int k = s + 1; k < LW; ++k) a[rr][k] -= lij * u[k];
+    }
+    if (isdiag && tid >= s) {                    // the diagonal block's rows (8 threads of the grid)
+      if (tid == s) {                            // this position receives the pivot row and is final
+#pragma unroll
+        for (int k = 0; k < LW; ++k) d[k] = u[k];
+      } else {
+        if (drow == r) {                         // the old row j moves here
+#pragma unroll
+          for (int k = 0; k < LW; ++k) d[k] = c_old[k];
+        }
+        const double x0 = d[s];
+        const double lij = (rpiv != 0.0) ? x0 * rpiv : x0;
+        d[s] = lij;
+#pragma unroll
+        for (int k = s + 1; k < LW; ++k) d[k] -= lij * u[k];
+      }
+    }
+    LU_STAMP(5);
+  };
+
+  // straight-line step list
+  {
+    using std::integral_constant;
+    step(integral_constant<int, 0>{});
+    step(integral_constant<int, 1>{});
+    step(integral_constant<int, 2>{});
+    step(integral_constant<int, 3>{});
+    step(integral_constant<int, 4>{});
+    step(integral_constant<int, 5>{});
+    step(integral_constant<int, 6>{});
+    step(integral_constant<int, 7>{});
+  }
+  if (s_abort && tid == 0) atomicExch(info, -1);
+  if (has_col && pend) { swcol[pj] = pa1; swcol[pr] = pa0; }
+#pragma unroll
+  for (int k = 0; k < LW; ++k) {
+    if (k < w) {
+      char* cb = colbase(j0 + k);
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        const int32_t i = row0 + rr * BS;
+        if (i < m) *elem(cb, i) = a[rr][k];
+      }
+      if (isdiag && drow < m) *elem(cb, drow) = d[k];
+    }
+  }
+}
+
+// U12 = L11^-1 A12 for the K x K unit-lower block at (jb, jb) and the columns [c0, c1): out[k + (c - c0) K].
+// Thread = one column; L11 in LDS (broadcast reads), the column in registers.
+template <int K>
+__global__ __launch_bounds__(64) void lu_u12_kernel(const double* __restrict__ Y, int64_t ld, int64_t jb, int64_t c0,
+                                                    int64_t c1, double* __restrict__ out) {
+  __shared__ double L11[K * K];
+  for (int e = threadIdx.x; e < K * K; e += 64) {
+    const int r = e % K, c = e / K;
+    L11[r * K + c] = Y[(jb + r) + (jb + c) * ld];       // [row][col]: a row's multipliers are contiguous
+  }
+  __syncthreads();
+  const int64_t c = c0 + (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (c >= c1) return;
+  double x[K];
+  const double* col = Y + jb + c * ld;
+#pragma unroll
+  for (int r = 0; r < K; ++r) x[r] = col[r];
+#pragma unroll
+  for (int r = 1; r < K; ++r) {
+    double v = x[r];
+#pragma unroll
+    for (int p = 0; p < r; ++p) v -= L11[r * K + p] * x[p];
+    x[r] = v;
+  }
+  double* o = out + (c - c0) * K;
+#pragma unroll
+  for (int r = 0; r < K; ++r) o[r] = x[r];
+}
+
+// A22 -= L21 * U12: rows [r_begin, m), columns [c0, c0 + t), L21 = Y[:, jb:jb+K], U12 (K x t, ld K) from lu_u12_kernel.
+// Workgroup = 4 waves x 32 rows; column chunk of <= RK_CHUNK columns per blockIdx.y (its U12 slice sits in LDS).
+// MFMA operands swapped like the big contraction kernel: lane (jl = lane & 15, kk = lane >> 4) holds, for C row
+// jl (+16 h), the columns kk + 4 reg of a 16-column tile.
+constexpr int RK_CHUNK = 128;
+template <int K>
+__global__ __launch_bounds__(256) void lu_rankk_kernel(double* __restrict__ Y, int64_t ld, int64_t m, int64_t r_begin,
+                                                       int64_t jb, int64_t c0, int64_t t,
+                                                       const double* __restrict__ U12) {
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  constexpr int KP = K + 2;                     // padded k stride of the U image [col][k] (KP / 2 odd: conflict-free b64 reads)
+  extern __shared__ double us[];                // RK_CHUNK * KP doubles
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 15, kk = lane >> 4;
+  const int64_t rb = r_begin + ((int64_t)blockIdx.x * 4 + wave) * 32;
+  // this wave's 32 rows of multipliers as MFMA fragments: fa[h][s] = L[rb + 16 h + jl, jb + 4 s + kk]
+  double fa[2][K / 4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t rrow = rb + 16 * h + jl;
+#pragma unroll
+    for (int s = 0; s < K / 4; ++s) fa[h][s] = (rrow < m) ? Y[rrow + (jb + 4 * s + kk) * ld] : 0.0;
+  }
+  for (int64_t cc0 = 0; cc0 < t; cc0 += RK_CHUNK) {   // the workgroup walks ALL trailing columns: L21 is read once
+    const int tc = (int)((t - cc0 < RK_CHUNK) ? (t - cc0) : RK_CHUNK);
+    __syncthreads();                                  // the previous chunk's U image is no longer read
+    for (int e = tid; e < RK_CHUNK * K; e += 256) {
+      const int k = e % K, c = e / K;
+      us[c * KP + k] = (c < tc) ? U12[k + (cc0 + c) * K] : 0.0;
+    }
+    __syncthreads();
+    if (rb >= m) continue;
+    const int ntile = (tc + 15) / 16;
+    double cin[2][4];
+    auto load_tile = [&](int tt, double (&dst)[2][4]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t rrow = rb + 16 * h + jl;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int cl = 16 * tt + kk + 4 * reg;
+          dst[h][reg] = (rrow < m && cl < tc) ? Y[rrow + (c0 + cc0 + cl) * ld] : 0.0;
+        }
+      }
+    };
+    load_tile(0, cin);
+    for (int tt = 0; tt < ntile; ++tt) {
+      double4_t acc[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[h] = (double4_t){cin[h][0], cin[h][1], cin[h][2], cin[h][3]};
+      if (tt + 1 < ntile) load_tile(tt + 1, cin);     // next tile's C in flight behind this tile's MFMAs
+#pragma unroll
+      for (int s = 0; s < K / 4; ++s) {
+        const double fb = -us[(16 * tt + jl) * KP + 4 * s + kk];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb, fa[h][s], acc[h], 0, 0, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t rrow = rb + 16 * h + jl;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int cl = 16 * tt + kk + 4 * reg;
+          if (rrow < m && cl < tc) Y[rrow + (c0 + cc0 + cl) * ld] = acc[h][reg];
+        }
+      }
+    }
+  }
+}
+
+template <int K>
+static void launch_rankk(hipStream_t st, unsigned grid, double* Y, int64_t ld, int64_t m, int64_t r_begin, int64_t jb,
+                         int64_t c0, int64_t t, const double* U12) {
+  constexpr size_t shmem = (size_t)RK_CHUNK * (K + 2) * sizeof(double);
+  static std::atomic<uint64_t> attr_mask{0};
+  if (first_use_on_this_device(attr_mask))
+    (void)hipFuncSetAttribute((const void*)lu_rankk_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL((lu_rankk_kernel<K>), dim3(grid), dim3(256), shmem, st, Y, ld, m, r_begin, jb, c0, t, U12);
+}
+
+// top l x l: unit diagonal, zero strict upper triangle (what Julia's F.L returns)
+__global__ void lu2_extract_L_kernel(double* __restrict__ Y, int64_t ld, int64_t l) {
+  const int64_t total = l * l;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e % l, c = e / l;
+    if (r == c) Y[r + c * ld] = 1.0;
+    else if (r < c) Y[r + c * ld] = 0.0;
+  }
+}
+
+bool lu2_config(int64_t m, int ncus, int* bs, int* rpt, int* grid) {
+  if (ncus < 1) return false;
+  if (ncus > 256) ncus = 256;               // the leader reads one record per workgroup with <= 2 lanes each
+  static const int cfg[4][2] = {{256, 1}, {256, 4}, {512, 4}, {512, 8}};
+  for (int c = 0; c < 4; ++c) {
+    const int64_t per = (int64_t)cfg[c][0] * cfg[c][1];
+    if (m <= (int64_t)ncus * per) { *bs = cfg[c][0]; *rpt = cfg[c][1]; *grid = (int)((m + per - 1) / per); return true; }
+  }
+  return false;
+}
+
+template <int BS, int R>
+static void launch_leaf(hipStream_t st, int grid, double* Y, int64_t ld, int64_t m, int64_t l, int64_t jb, int64_t j0,
+                        int w, unsigned long long* recs, uint32_t epoch_base, int32_t* ipiv, int32_t* info) {
+  hipLaunchKernelGGL((lu_leaf_kernel<BS, R>), dim3(grid), dim3(BS), 0, st, Y, ld, (int32_t)m, (int32_t)l, (int32_t)jb,
+                     (int32_t)j0, w, recs, epoch_base, ipiv, info);
+}
+
+void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu2Work& w) {
+  // the record tags count pivot steps from 1: clear both record sets
+  (void)hipMemsetAsync(w.recs, 0, sizeof(unsigned long long) * 2 * ((size_t)w.grid + LU2_RES_COPIES) * REC, st);
+  uint32_t epoch = 0;
+  const int nb = w.nb;
+  for (int64_t jb = 0; jb < l; jb += nb) {
+    const int b = (int)((l - jb < nb) ? (l - jb) : nb);
+    for (int64_t j0 = jb; j0 < jb + b; j0 += LW) {
+      const int wd = (int)((jb + b - j0 < LW) ? (jb + b - j0) : LW);
+      // every leaf keeps the same grid: workgroups whose rows lie beyond m still take part in the exchange
+      if (w.bs == 256 && w.rpt == 1) launch_leaf<256, 1>(st, w.grid, Y, ld, m, l, jb, j0, wd, w.recs, epoch, w.ipiv, w.info);
+      else if (w.bs == 256) launch_leaf<256, 4>(st, w.grid, Y, ld, m, l, jb, j0, wd, w.recs, epoch, w.ipiv, w.info);
+      else if (w.rpt == 4) launch_leaf<512, 4>(st, w.grid, Y, ld, m, l, jb, j0, wd, w.recs, epoch, w.ipiv, w.info);
+      else launch_leaf<512, 8>(st, w.grid, Y, ld, m, l, jb, j0, wd, w.recs, epoch, w.ipiv, w.info);
+      epoch += (uint32_t)LW;            // a narrow last leaf still runs (gated) 8 steps
+    }
+    const int64_t c0 = jb + b, t = l - c0;
+    if (t > 0) {                               // only full blocks have columns to their right
+      const int64_t mr = m - c0;
+      const unsigned gu = (unsigned)((t + 63) / 64);
+      const unsigned gr = (unsigned)((mr + 127) / 128);
+      if (b == 64) {
+        hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(64), 0, st, Y, ld, jb, c0, l, w.u12);
+        if (mr > 0) launch_rankk<64>(st, gr, Y, ld, m, c0, jb, c0, t, w.u12);
+      } else {
+        hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(64), 0, st, Y, ld, jb, c0, l, w.u12);
+        if (mr > 0) launch_rankk<32>(st, gr, Y, ld, m, c0, jb, c0, t, w.u12);
+      }
+    }
+  }
+  int eb = (int)((l * l + 255) / 256);
+  if (eb > 1024) eb = 1024;
+  hipLaunchKernelGGL(lu2_extract_L_kernel, dim3(eb), dim3(256), 0, st, Y, ld, l);
+#ifdef GSI_LU_TRACE
+  if (const char* path = getenv("GSI_LU_TRACE")) {
+    unsigned long long h[4 * 8 * 8];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lu_trace), sizeof(h));
+    if (FILE* f = fopen(path, "w")) {
+      for (int tw = 0; tw < 4; ++tw)
+        for (int s = 0; s < 8; ++s) {
+          fprintf(f, "wg%d step%d", tw, s);
+          for (int ph = 0; ph < 6; ++ph) fprintf(f, " %llu", h[(tw * 8 + s) * 8 + ph]);
+          fprintf(f, "\n");
+        }
+      fclose(f);
+    }
+  }
+#endif
+}
+
+}}  // namespace gsi::hipk
