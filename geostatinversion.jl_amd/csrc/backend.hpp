@@ -103,6 +103,19 @@ class Backend {
   virtual void pcga_params(const double* Z, int64_t n, int64_t K, const double* s, const double* X, double delta,
                            double* out) = 0;
 
+  virtual void scal(int64_t n, double a, double* x) = 0;                          // x *= a
+  virtual void diag_mul_add(int64_t n, const double* d, const double* x, double* y) = 0;   // y += d .* x
+
+  // ---- fp32-STORED xi-basis (BASELINE configs[4], "fp32 mixed precision"): the n x K basis is the one big HBM stream
+  //      of the PCGA iteration's own algebra; stored in fp32 it is half the bytes, every sum stays in fp64 ----
+  virtual void f64_to_f32(const double* src, void* dst32, size_t count) = 0;
+  // as pcga_params with Z given in fp32 (n x K, ld n); out is fp64
+  virtual void pcga_params_f32(const void* Z32, int64_t n, int64_t K, const double* s, const double* X, double delta,
+                               double* out) = 0;
+  // y (n) = beta * X + Z32 (n x K, fp32) * w (K): fp64 accumulation   (direct.jl:59-65 with the basis in fp32)
+  virtual void basis_gemv_f32(const void* Z32, int64_t n, int64_t K, const double* w, double beta, const double* X,
+                              double* y) = 0;
+
   // error flags raised asynchronously by kernels (zero pivot, non-posdef); checked and
   // cleared by the pipeline at the end of each entry point. Returns GSI_* code or 0.
   virtual int take_error(std::string* msg) = 0;

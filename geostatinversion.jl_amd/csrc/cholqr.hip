@@ -143,6 +143,16 @@ __global__ __launch_bounds__(256) void cq_orth_check_kernel(const double* __rest
   if (bad) atomicOr(flag, 2);
 }
 
+// ---- G <- symmetric: the strictly lower triangle mirrors the upper one (the symmetric product computes only the
+// tiles that touch the upper triangle) ----
+__global__ void cq_mirror_upper_kernel(double* __restrict__ G, int l) {
+  const int64_t total = (int64_t)l * l;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e % l), c = (int)(e / l);
+    if (r > c) G[e] = G[c + (int64_t)r * l];
+  }
+}
+
 // ---- R = R2 * R1 (both upper triangular l x l) ----
 __global__ void cq_triprod_kernel(const double* __restrict__ R2, const double* __restrict__ R1, int l,
                                   double* __restrict__ R) {
@@ -211,7 +221,8 @@ inline CqBufs cq_bufs(double* small, int l) {
 void cq_round(hipStream_t st, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t m, int l, double* Rp,
               double* X, const CqBufs& b, bool check, int32_t* flag, double* gemm_ws, bool apply, bool shift = false) {
   const int nblk = (l + CQ_TB - 1) / CQ_TB;
-  gemm_f64(st, true, l, l, m, 1.0, src, lds, src, lds, 0.0, Rp, l, gemm_ws);          // G = Y'Y
+  gemm_f64_syrk_upper(st, l, m, src, lds, Rp, l, gemm_ws);                            // G = Y'Y (upper tiles)
+  hipLaunchKernelGGL(cq_mirror_upper_kernel, dim3(64), dim3(256), 0, st, Rp, l);
   if (check)
     hipLaunchKernelGGL(cq_orth_check_kernel, dim3(grid_for((int64_t)l * l, 64)), dim3(256), 0, st, Rp, l, 0.1, flag);
   if (shift) hipLaunchKernelGGL(cq_shift_kernel, dim3(1), dim3(256), 0, st, Rp, l, (double)m);
@@ -237,7 +248,7 @@ void cq_round(hipStream_t st, const double* src, int64_t lds, double* dst, int64
     hipLaunchKernelGGL(cq_right_mult_kernel, dim3(grid_for(j0 + bb, 1024)), dim3(256), 0, st, X, j0 + bb, (int64_t)l,
                        j0, bb, b.Rinv + (size_t)jb * CQ_TB * CQ_TB);
   }
-  if (apply) gemm_f64(st, false, m, l, l, 1.0, src, lds, X, l, 0.0, dst, ldd, gemm_ws);   // dst = src R^-1
+  if (apply) gemm_f64_trmm_upper(st, m, l, l, src, lds, X, l, dst, ldd, gemm_ws);         // dst = src R^-1 (R^-1 upper)
 }
 }  // namespace
 
@@ -257,7 +268,7 @@ void cholqr2_apply(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld
                    double* R, double* small, double* gemm_ws) {
   const int l = (int)l64;
   const CqBufs b = cq_bufs(small, l);
-  gemm_f64(st, false, m, l, l, 1.0, T, ldt, b.X2, l, 0.0, Y, ld, gemm_ws);
+  gemm_f64_trmm_upper(st, m, l, l, T, ldt, b.X2, l, Y, ld, gemm_ws);
   if (R != nullptr)
     hipLaunchKernelGGL(cq_triprod_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, b.R2, b.R1, l, R);
 }
@@ -279,7 +290,7 @@ void scholqr3_apply(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t l
                     double* R, double* small, double* gemm_ws) {
   const int l = (int)l64;
   const CqBufs b = cq_bufs(small, l);
-  gemm_f64(st, false, m, l, l, 1.0, S, lds_, b.X3, l, 0.0, Y, ld, gemm_ws);
+  gemm_f64_trmm_upper(st, m, l, l, S, lds_, b.X3, l, Y, ld, gemm_ws);
   if (R != nullptr) {
     const int g = grid_for((int64_t)l * l, 256);
     hipLaunchKernelGGL(cq_triprod_kernel, dim3(g), dim3(256), 0, st, b.R2, b.R1, l, b.X1);   // X1 is free: R2 R1

@@ -42,6 +42,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
+#include <algorithm>
 #include "hip_common.hpp"
 
 namespace gsi { namespace hipk {
@@ -85,7 +86,7 @@ template <int NT, bool TRANS_A, bool GEN, int XMODE>
 __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     int64_t M, int64_t L, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* __restrict__ C, int64_t ldc, double alpha,
-    double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, int wide, GenA gen) {
+    double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, int wide, int tri, GenA gen) {
   static_assert(!(GEN && TRANS_A), "the generated operand is symmetric: only the NN form exists");
   constexpr bool RAGGED = XMODE != 0;
   constexpr bool BIG = XMODE == 2;
@@ -103,10 +104,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   constexpr int NTW = (NT + 1) / 2;
   const int jl = lane & 15;   // MFMA "column" index -> C row within a 16-row tile
   const int kk = lane >> 4;   // MFMA k index within a k4 step
-  const int64_t r0 = (int64_t)(blockIdx.x / nchunks_x) * BMT;   // column chunk folded into x: chunk-mates are dispatched together
-  const int64_t c0 = (int64_t)(blockIdx.x % nchunks_x) * (NT * 16);
+  int64_t r0 = (int64_t)(blockIdx.x / nchunks_x) * BMT;   // column chunk folded into x: chunk-mates are dispatched together
+  int64_t c0 = (int64_t)(blockIdx.x % nchunks_x) * (NT * 16);
+  if (tri == 1) {
+    // symmetric product: blockIdx.x counts only the tiles that touch the upper triangle (tiles entirely below the
+    // diagonal are not part of the grid -- as idle workgroups they pushed the grid past one round of 256)
+    int left = (int)blockIdx.x;
+    const int nrb = (int)((M + BMT - 1) / BMT);
+    for (int rb = 0; rb < nrb; ++rb) {
+      const int first = (rb * BMT) / (NT * 16);           // first chunk with a column at or right of the block's first row
+      const int cnt = nchunks_x - first;
+      if (left < cnt) { r0 = (int64_t)rb * BMT; c0 = (int64_t)(first + left) * (NT * 16); break; }
+      left -= cnt;
+    }
+  }
+  // tri == 1 (TN, C = A'A symmetric): tiles entirely below the diagonal are not computed (the caller mirrors the
+  //   upper triangle); tri == 2 (NN, B upper triangular): rows of B below the chunk's last column are zero, so the
+  //   reduction stops there.  CholeskyQR spends 4 n l^2 flop instead of 8 n l^2 this way.
   const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
-  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  if (tri == 2 && kend > c0 + NT * 16) kend = c0 + NT * 16;
   const int64_t ntiles = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
 
   double4_t acc[MT][NTW];
@@ -392,29 +409,29 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t L, int nsplit, const dou
 template <int NT, bool TRANS_A, bool GEN, int XMODE>
 static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A,
                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha,
-                      double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide, const GenA& gen) {
+                      double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide, int tri, const GenA& gen) {
   constexpr size_t shmem = 2 * ((TRANS_A ? BMT * BKP : BK * BMP) + NT * 16 * BKP) * sizeof(double);
   static std::atomic<uint64_t> attr_mask{0};
   if (first_use_on_this_device(attr_mask))
     (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<NT, TRANS_A, GEN, XMODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   hipLaunchKernelGGL((gemm_f64_kernel<NT, TRANS_A, GEN, XMODE>), grid, dim3(NTHREADS), shmem, st, M, L, K, A, lda, B, ldb, C,
-                     ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen);
+                     ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen);
 }
 
 template <bool TRANS_A, bool GEN>
 static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K,
                             const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
                             int64_t ldc, double alpha, double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide,
-                            int xmode, const GenA& gen) {
+                            int xmode, int tri, const GenA& gen) {
 #define GSI_CASE(N)                                                                             \
   case N:                                                                                       \
     if (xmode == 2)                                                                               \
-      launch_nt<N, TRANS_A, GEN, 2>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
+      launch_nt<N, TRANS_A, GEN, 2>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen); \
     else if (xmode == 1)                                                                          \
-      launch_nt<N, TRANS_A, GEN, 1>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
+      launch_nt<N, TRANS_A, GEN, 1>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen); \
     else                                                                                          \
-      launch_nt<N, TRANS_A, GEN, 0>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, gen); \
+      launch_nt<N, TRANS_A, GEN, 0>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen); \
     break;
   switch (nt) {
     GSI_CASE(1) GSI_CASE(2) GSI_CASE(3) GSI_CASE(4) GSI_CASE(5)
@@ -457,10 +474,19 @@ size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K) {
   const int ns = gemm_choose_split(nwg, K);
   return ns > 1 ? (size_t)ns * (size_t)M * (size_t)L : 0;
 }
+// the symmetric product C = A'A (l x l, K = m): fewer active tiles, so possibly more splits; bound by the chooser's cap
+size_t gemm_syrk_workspace_doubles(int64_t l, int64_t m) {
+  return (m >= 8 * BK) ? (size_t)64 * (size_t)l * (size_t)l : 0;
+}
+
+// number of 16-column tiles per workgroup pass.  (128-column chunks for the symmetric product, so that chunk and
+// row-block boundaries coincide, were measured SLOWER at l = 320: 320 is not a multiple of 128, the product then runs
+// through the irregular-X instantiation: 6.3 vs 5.3 ms.)
+static int gemm_chunk_tiles(int) { return NTMAX; }
 
 static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M, int64_t L, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
-                        int64_t ldc, double* ws) {
+                        int64_t ldc, double* ws, int tri = 0) {
   if (M <= 0 || L <= 0) return;
   // The kernel addresses a tile with one uniform 64-bit base per operand plus per-thread byte offsets spanning up to
   // 160 columns of B, 128 rows of a transposed A or 32 columns of a plain A: 32 bits reach panels of ~3.3 million
@@ -471,15 +497,23 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   const bool big = bspan >= lim || aspan >= lim;
   // columns are processed in chunks of nt*16 <= 160; balance the chunks
   const int64_t tiles = (L + 15) / 16;
-  const int64_t nchunks = (tiles + NTMAX - 1) / NTMAX;
+  const int ntmax = gemm_chunk_tiles(tri);
+  const int64_t nchunks = (tiles + ntmax - 1) / ntmax;
   const int nt = (int)((tiles + nchunks - 1) / nchunks);
   const int64_t rowblocks = (M + BMT - 1) / BMT;
-  const int nsplit = (K > 0) ? gemm_choose_split(rowblocks * nchunks, K) : 1;
+  int64_t active = rowblocks * nchunks;
+  if (tri == 1) {                                 // tiles with a column at or right of the row block's first row
+    active = 0;
+    for (int64_t rb = 0; rb < rowblocks; ++rb)
+      for (int64_t cb = 0; cb < nchunks; ++cb)
+        if (cb >= (rb * BMT) / ((int64_t)nt * 16)) ++active;
+  }
+  const int nsplit = (K > 0) ? gemm_choose_split(active, K) : 1;
   int64_t kchunk = (K + nsplit - 1) / nsplit;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   if (kchunk == 0) kchunk = BK;
   const int ns_eff = (K > 0) ? (int)((K + kchunk - 1) / kchunk) : 1;
-  dim3 grid((unsigned)(rowblocks * nchunks), (unsigned)ns_eff, 1);
+  dim3 grid((unsigned)active, (unsigned)ns_eff, 1);
   double* slabs = (ns_eff > 1) ? ws : nullptr;
   // 16-byte loads need 16-B aligned bases and even leading dimensions (sub-panel views often are not)
   const bool a_ok = ((uintptr_t)A & 15) == 0 && (lda & 1) == 0;
@@ -491,11 +525,11 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   const int xmode = big ? 2 : (irregular_x ? 1 : 0);
   const GenA none = {nullptr, nullptr, 1, 0, 0, 0};
   if (gen != nullptr)
-    launch_dispatch<false, true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, *gen);
+    launch_dispatch<false, true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, *gen);
   else if (transA)
-    launch_dispatch<true, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, none);
+    launch_dispatch<true, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none);
   else
-    launch_dispatch<false, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, none);
+    launch_dispatch<false, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none);
   if (ns_eff > 1) {
     const int64_t total = M * L;
     int blocks = (int)((total + 255) / 256);
@@ -509,6 +543,19 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
 void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, double alpha, const double* A,
               int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws) {
   gemm_launch(st, transA, nullptr, M, L, K, alpha, A, lda, B, ldb, beta, C, ldc, ws);
+}
+
+// C (l x l, ld ldc) = A'A for A m x l: only tiles that touch the upper triangle are computed, the rest of C is
+// unspecified (cholqr.hip mirrors the upper triangle afterwards).  ws: gemm_syrk_workspace_doubles(l, m).
+void gemm_f64_syrk_upper(hipStream_t st, int64_t l, int64_t m, const double* A, int64_t lda, double* C, int64_t ldc,
+                         double* ws) {
+  gemm_launch(st, true, nullptr, l, l, m, 1.0, A, lda, A, lda, 0.0, C, ldc, ws, 1);
+}
+// C (M x L) = A (M x K) * B with B (K x L) upper triangular: entries below the diagonal must be ZERO (those beyond
+// a column chunk's last column are not read, the ones inside the chunk are)
+void gemm_f64_trmm_upper(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A, int64_t lda, const double* B,
+                         int64_t ldb, double* C, int64_t ldc, double* ws) {
+  gemm_launch(st, false, nullptr, M, L, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, ws, 2);
 }
 
 // C (M x L) = G * B with G(i, k) = ex[|x_i - x_k|] ey[|y_i - y_k|], i = roff + row, k = koff + reduction index;

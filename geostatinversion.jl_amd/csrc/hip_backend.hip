@@ -52,7 +52,7 @@ class HipBackend : public Backend {
     HIP_CHECK(hipStreamCreate(&st_));
     HIP_CHECK(hipMalloc(&flags_, 16 * sizeof(int32_t)));
     HIP_CHECK(hipMemsetAsync(flags_, 0, 16 * sizeof(int32_t), st_));
-    HIP_CHECK(hipMalloc(&scal_, 64 * sizeof(double)));
+    HIP_CHECK(hipMalloc(&scal_, (64 + 8 + 256) * sizeof(double)));   // scalars + partial sums of long dot products
   }
   ~HipBackend() override {
     hipSetDevice(device_);
@@ -309,6 +309,7 @@ class HipBackend : public Backend {
     size_t gmax = hipk::gemm_workspace_doubles(l, NB, m);
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(NB, NB, m));
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, l, m));
+    gmax = std::max(gmax, hipk::gemm_syrk_workspace_doubles(l, m));     // CholeskyQR: Gram matrix, upper tiles only
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(m, l, l));       // CholeskyQR2: Y R^-1 as one product
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, 32, l));      //             : the l x l inverse
     for (int64_t t = NB; t <= l; t += NB) gmax = std::max(gmax, hipk::gemm_workspace_doubles(t, NB, m));
@@ -440,6 +441,29 @@ class HipBackend : public Backend {
     bind();
     hipk::pcga_params(st_, Z, n, K, s, X, delta, out);
     check_launch("pcga_params");
+  }
+  void scal(int64_t n, double a, double* x) override { bind(); hipk::scal(st_, n, a, x); }
+  void diag_mul_add(int64_t n, const double* d, const double* x, double* y) override {
+    bind();
+    hipk::diag_mul_add(st_, n, d, x, y);
+  }
+  void f64_to_f32(const double* src, void* dst32, size_t count) override {
+    bind();
+    hipk::f64_to_f32(st_, src, (float*)dst32, count);
+    check_launch("f64_to_f32");
+  }
+  void pcga_params_f32(const void* Z32, int64_t n, int64_t K, const double* s, const double* X, double delta,
+                       double* out) override {
+    bind();
+    hipk::pcga_params_f32(st_, (const float*)Z32, n, K, s, X, delta, out);
+    check_launch("pcga_params_f32");
+  }
+  void basis_gemv_f32(const void* Z32, int64_t n, int64_t K, const double* w, double beta, const double* X,
+                      double* y) override {
+    bind();
+    if (K > 8000) throw Error(GSI_ERR_ARG, "basis_gemv_f32: K too large for the LDS-resident weights");
+    hipk::basis_gemv_f32(st_, (const float*)Z32, n, K, w, beta, X, y);
+    check_launch("basis_gemv_f32");
   }
 
   int take_error(std::string* msg) override {

@@ -21,6 +21,12 @@ inline bool first_use_on_this_device(std::atomic<uint64_t>& mask) {
 size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K);
 void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, double alpha, const double* A,
               int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws);
+// C (l x l) = A'A, upper-triangle tiles only; C = A * B with B upper triangular (CholeskyQR: half the flops each)
+size_t gemm_syrk_workspace_doubles(int64_t l, int64_t m);
+void gemm_f64_syrk_upper(hipStream_t st, int64_t l, int64_t m, const double* A, int64_t lda, double* C, int64_t ldc,
+                         double* ws);
+void gemm_f64_trmm_upper(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A, int64_t lda, const double* B,
+                         int64_t ldb, double* C, int64_t ldc, double* ws);
 // C = G * B, G(i,k) = ex[|x_i-x_k|] ey[|y_i-y_k|] generated in registers (tab = [ex(nx) | ey(ny)])
 void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* tab, int64_t nx, int64_t ny,
                       int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws);
@@ -115,7 +121,14 @@ void chol_upper(hipStream_t st, double* B, int64_t j, int32_t* info);
 void trsm_right_upper(hipStream_t st, double* F, int64_t m, int64_t j, int64_t ldf, const double* C);
 void axpy(hipStream_t st, int64_t n, double a, const double* x, double* y);
 void scal_copy(hipStream_t st, int64_t n, double a, const double* x, double* y);
-void dot_dev(hipStream_t st, int64_t n, const double* x, const double* y, double* out_dev);
+void dot_dev(hipStream_t st, int64_t n, const double* x, const double* y, double* out_dev);   // out_dev: >= 8 + 256 doubles
+void scal(hipStream_t st, int64_t n, double a, double* x);
+void diag_mul_add(hipStream_t st, int64_t n, const double* d, const double* x, double* y);
+void f64_to_f32(hipStream_t st, const double* src, float* dst, size_t count);
+void pcga_params_f32(hipStream_t st, const float* Z, int64_t n, int64_t K, const double* s, const double* X, double delta,
+                     double* out);
+void basis_gemv_f32(hipStream_t st, const float* Z, int64_t n, int64_t K, const double* w, double beta, const double* X,
+                    double* y);
 void extract_upper(hipStream_t st, const double* Y, int64_t ld, int64_t l, double* R);
 void pcga_params(hipStream_t st, const double* Z, int64_t n, int64_t K, const double* s, const double* X,
                  double delta, double* out);

@@ -185,8 +185,33 @@ __global__ __launch_bounds__(1024) void dot_kernel(int64_t n, const double* __re
     *out = t;
   }
 }
+// long vectors: 256 workgroups leave partial sums, one more launch adds them in index order (deterministic)
+__global__ __launch_bounds__(256) void dot_partial_kernel(int64_t n, const double* __restrict__ x,
+                                                          const double* __restrict__ y, double* __restrict__ part) {
+  __shared__ double s[4];
+  double v = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v += x[i] * y[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+__global__ __launch_bounds__(64) void dot_final_kernel(int nparts, const double* __restrict__ part, double* __restrict__ out) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 64) v += part[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if (threadIdx.x == 0) *out = v;
+}
 void dot_dev(hipStream_t st, int64_t n, const double* x, const double* y, double* out_dev) {
-  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, st, n, x, y, out_dev);
+  if (n < 65536) {
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, st, n, x, y, out_dev);
+    return;
+  }
+  double* part = out_dev + 8;     // the backend's scalar scratch holds 64 + 256 doubles
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(256), dim3(256), 0, st, n, x, y, part);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(64), 0, st, 256, part, out_dev);
 }
 
 __global__ void axpy_kernel(int64_t n, double a, const double* __restrict__ x, double* __restrict__ y) {
@@ -202,6 +227,74 @@ __global__ void scal_copy_kernel(int64_t n, double a, const double* __restrict__
 }
 void scal_copy(hipStream_t st, int64_t n, double a, const double* x, double* y) {
   hipLaunchKernelGGL(scal_copy_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, a, x, y);
+}
+
+__global__ void scal_kernel(int64_t n, double a, double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= a;
+}
+void scal(hipStream_t st, int64_t n, double a, double* x) {
+  hipLaunchKernelGGL(scal_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, a, x);
+}
+__global__ void diag_mul_add_kernel(int64_t n, const double* __restrict__ d, const double* __restrict__ x,
+                                    double* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] += d[i] * x[i];
+}
+void diag_mul_add(hipStream_t st, int64_t n, const double* d, const double* x, double* y) {
+  hipLaunchKernelGGL(diag_mul_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, d, x, y);
+}
+
+// ---- fp32-stored xi-basis (mixed precision: fp32 storage, fp64 arithmetic) ------------------------------------
+__global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = (float)src[i];
+}
+void f64_to_f32(hipStream_t st, const double* src, float* dst, size_t count) {
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(grid_for((int64_t)count, 8192)), dim3(256), 0, st, src, dst, count);
+}
+__global__ void pcga_params_f32_kernel(const float* __restrict__ Z, int64_t n, int64_t K, const double* __restrict__ s,
+                                       const double* __restrict__ X, double delta, double* __restrict__ out) {
+  const int64_t col = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double si = s[i];
+    double v;
+    if (col < K) v = si + delta * (double)Z[i + col * n];
+    else if (col == K) v = si + delta * X[i];
+    else if (col == K + 1) v = si + delta * si;
+    else v = si;
+    out[i + col * n] = v;
+  }
+}
+void pcga_params_f32(hipStream_t st, const float* Z, int64_t n, int64_t K, const double* s, const double* X,
+                     double delta, double* out) {
+  hipLaunchKernelGGL(pcga_params_f32_kernel, dim3(grid_for(n, 256), (unsigned)(K + 3)), dim3(256), 0, st, Z, n, K, s, X,
+                     delta, out);
+}
+// y = beta X + Z w: thread = one row, the K weights in LDS; every global access is a coalesced column segment of the
+// fp32 basis (HBM-bound: 4 n K bytes)
+__global__ __launch_bounds__(256) void basis_gemv_f32_kernel(const float* __restrict__ Z, int64_t n, int64_t K,
+                                                             const double* __restrict__ w, double beta,
+                                                             const double* __restrict__ X, double* __restrict__ y) {
+  extern __shared__ double ws[];
+  for (int64_t k = threadIdx.x; k < K; k += 256) ws[k] = w[k];
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double acc0 = beta * X[i], acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int64_t k = 0;
+    for (; k + 4 <= K; k += 4) {
+      acc0 += (double)Z[i + (k + 0) * n] * ws[k + 0];
+      acc1 += (double)Z[i + (k + 1) * n] * ws[k + 1];
+      acc2 += (double)Z[i + (k + 2) * n] * ws[k + 2];
+      acc3 += (double)Z[i + (k + 3) * n] * ws[k + 3];
+    }
+    for (; k < K; ++k) acc0 += (double)Z[i + k * n] * ws[k];
+    y[i] = (acc0 + acc1) + (acc2 + acc3);
+  }
+}
+void basis_gemv_f32(hipStream_t st, const float* Z, int64_t n, int64_t K, const double* w, double beta, const double* X,
+                    double* y) {
+  hipLaunchKernelGGL(basis_gemv_f32_kernel, dim3(grid_for(n, 4096)), dim3(256), (size_t)K * sizeof(double), st, Z, n, K, w,
+                     beta, X, y);
 }
 
 // ---- R (l x l, ld l) <- upper triangle of the top of Y --------------------------------------

@@ -224,6 +224,30 @@ class CpuBackend : public Backend {
         out[i + c * n] = s[i] + delta * d;
       }
   }
+  void scal(int64_t n, double a, double* x) override { for (int64_t i = 0; i < n; ++i) x[i] *= a; }
+  void diag_mul_add(int64_t n, const double* d, const double* x, double* y) override { for (int64_t i = 0; i < n; ++i) y[i] += d[i] * x[i]; }
+  void f64_to_f32(const double* src, void* dst32, size_t count) override {
+    float* d = (float*)dst32;
+    for (size_t i = 0; i < count; ++i) d[i] = (float)src[i];
+  }
+  void pcga_params_f32(const void* Z32, int64_t n, int64_t K, const double* s, const double* X, double delta,
+                       double* out) override {
+    const float* Z = (const float*)Z32;
+    for (int64_t c = 0; c < K + 3; ++c)
+      for (int64_t i = 0; i < n; ++i) {
+        const double d = c < K ? (double)Z[i + c * n] : (c == K ? X[i] : (c == K + 1 ? s[i] : 0.0));
+        out[i + c * n] = s[i] + delta * d;
+      }
+  }
+  void basis_gemv_f32(const void* Z32, int64_t n, int64_t K, const double* w, double beta, const double* X,
+                      double* y) override {
+    const float* Z = (const float*)Z32;
+    for (int64_t i = 0; i < n; ++i) {
+      double acc = beta * X[i];
+      for (int64_t k = 0; k < K; ++k) acc += (double)Z[i + k * n] * w[k];
+      y[i] = acc;
+    }
+  }
   int take_error(std::string* msg) override {
     if (lu_info_) {
       if (msg) *msg = "SingularException(" + std::to_string(lu_info_) + "): exactly zero pivot in lu()";
