@@ -64,6 +64,16 @@ SIGNATURES = {
     "gsi_pcga_params_dev": (C.c_int, [c_vp, c_vp, c_i64, c_dp, c_dp, C.c_double, c_dp]),
     "gsi_pcga_update_dev": (C.c_int, [c_vp, c_vp, c_i64, c_dp, C.c_double, c_dp, c_i64, c_dp, c_dp]),
     "gsi_mat_download_col": (C.c_int, [c_vp, c_vp, c_i64, c_dp]),
+    "gsi_op_lowrank_solve": (C.c_int, [c_vp, c_vp, c_dp, c_dp, C.POINTER(c_i64)]),
+    "gsi_pcgamat_create": (C.c_int, [c_vp, C.POINTER(c_vp), c_dp, c_i64, c_i64, c_dp, c_dp, C.c_int]),
+    "gsi_pcgamat_destroy": (C.c_int, [c_vp]),
+    "gsi_pcgamat_mul": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
+    "gsi_pcgamat_lsqr": (C.c_int, [c_vp, c_vp, c_dp, c_dp, C.POINTER(c_i64)]),
+    "gsi_basis_create": (C.c_int, [c_vp, C.POINTER(c_vp), c_vp, c_i64, C.c_int]),
+    "gsi_basis_destroy": (C.c_int, [c_vp]),
+    "gsi_pcga_params_basis": (C.c_int, [c_vp, c_vp, c_dp, c_dp, C.c_double, c_dp]),
+    "gsi_pcga_update_basis": (C.c_int, [c_vp, c_vp, c_dp, C.c_double, c_dp, c_i64, c_dp, c_dp]),
+    "gsi_basis_download_col": (C.c_int, [c_vp, c_vp, c_i64, c_dp]),
     "gsi_ctx_profile": (C.c_int, [c_vp, C.c_int]),
     "gsi_ctx_phase_reset": (C.c_int, [c_vp]),
     "gsi_ctx_phase_times": (C.c_int, [c_vp, c_dp, C.POINTER(c_i64)]),

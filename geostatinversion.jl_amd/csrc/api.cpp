@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -21,6 +22,17 @@ struct gsi_mat {
   gsi_ctx* ctx;
   Buf buf;
   int64_t rows, cols;
+};
+struct gsi_pcgamat {
+  gsi_ctx* ctx;
+  PcgaLowRank A;
+};
+struct gsi_basis {
+  gsi_ctx* ctx;
+  int64_t n, K;
+  int precision;          // 64: Z64 points into the gsi_mat; 32: own fp32 copy in buf32
+  const double* Z64;
+  Buf buf32;
 };
 
 namespace {
@@ -571,6 +583,155 @@ int gsi_mat_download_col(gsi_ctx* ctx, const gsi_mat* mat, int64_t col, double* 
     REQUIRE(ctx && mat && host && mat->ctx == ctx, "bad argument");
     REQUIRE(col >= 0 && col < mat->cols, "column out of range");
     ctx->c.be->download2d(host, mat->rows, mat->buf.p + (size_t)col * mat->rows, mat->rows, mat->rows, 1);
+  });
+}
+
+// ---- LSQR consumers ------------------------------------------------------------------
+int gsi_op_lowrank_solve(gsi_ctx* ctx, const gsi_op* op, const double* b, double* x_out, int64_t* iters_out) {
+  return guarded([&] {
+    REQUIRE(ctx && op && b && x_out, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c, "operator belongs to another context");
+    const Operator& A = op->op;
+    Backend* be = ctx->c.be.get();
+    Buf bd(be, (size_t)A.n), xd(be, (size_t)A.n);
+    be->upload2d(bd.p, A.n, b, A.n, A.n, 1);
+    const int64_t it = lowrank_solve(A, bd.p, xd.p);
+    be->download2d(x_out, A.n, xd.p, A.n, A.n, 1);
+    if (iters_out) *iters_out = it;
+    check_async_errors(ctx->c);
+  });
+}
+
+int gsi_pcgamat_create(gsi_ctx* ctx, gsi_pcgamat** mat, const double* etas, int64_t nobs, int64_t K, const double* HX,
+                       const double* R, int r_is_diag) {
+  return guarded([&] {
+    REQUIRE(ctx && mat && etas && HX && R, "NULL argument");
+    *mat = nullptr;
+    REQUIRE(nobs >= 1 && K >= 1, "bad shape");
+    Backend* be = ctx->c.be.get();
+    std::unique_ptr<gsi_pcgamat> m(new gsi_pcgamat());
+    m->ctx = ctx;
+    PcgaLowRank& A = m->A;
+    A.ctx = &ctx->c; A.nobs = nobs; A.K = K; A.r_diag = (r_is_diag != 0);
+    A.E = Buf(be, (size_t)nobs * K);
+    A.HX = Buf(be, (size_t)nobs);
+    A.R = Buf(be, A.r_diag ? (size_t)nobs : (size_t)nobs * nobs);
+    be->upload2d(A.E.p, nobs, etas, nobs, nobs, K);
+    be->upload2d(A.HX.p, nobs, HX, nobs, nobs, 1);
+    if (A.r_diag) be->upload2d(A.R.p, nobs, R, nobs, nobs, 1);
+    else be->upload2d(A.R.p, nobs, R, nobs, nobs, nobs);
+    *mat = m.release();
+  });
+}
+int gsi_pcgamat_destroy(gsi_pcgamat* mat) {
+  return guarded([&] { delete mat; });
+}
+int gsi_pcgamat_mul(gsi_ctx* ctx, const gsi_pcgamat* mat, const double* x, double* y) {
+  return guarded([&] {
+    REQUIRE(ctx && mat && x && y && mat->ctx == ctx, "bad argument");
+    Backend* be = ctx->c.be.get();
+    const int64_t n1 = mat->A.nobs + 1;
+    Buf xd(be, (size_t)n1), yd(be, (size_t)n1);
+    be->upload2d(xd.p, n1, x, n1, n1, 1);
+    mat->A.mul(xd.p, yd.p);
+    be->download2d(y, n1, yd.p, n1, n1, 1);
+    check_async_errors(ctx->c);
+  });
+}
+int gsi_pcgamat_lsqr(gsi_ctx* ctx, const gsi_pcgamat* mat, const double* b, double* x_out, int64_t* iters_out) {
+  return guarded([&] {
+    REQUIRE(ctx && mat && b && x_out && mat->ctx == ctx, "bad argument");
+    Backend* be = ctx->c.be.get();
+    const int64_t n1 = mat->A.nobs + 1;
+    Buf bd(be, (size_t)n1), xd(be, (size_t)n1);
+    be->upload2d(bd.p, n1, b, n1, n1, 1);
+    LsqrOperator L;
+    L.nrows = L.ncols = n1;
+    const PcgaLowRank* A = &mat->A;
+    L.mul = [A](const double* xin, double* y) { A->mul(xin, y); };
+    L.mul_t = L.mul;                                     // the saddle-point matrix is symmetric
+    const int64_t it = lsqr(ctx->c, L, bd.p, xd.p, -1);  // maxiter = max(size(A))   IterativeSolvers default
+    be->download2d(x_out, n1, xd.p, n1, n1, 1);
+    if (iters_out) *iters_out = it;
+    check_async_errors(ctx->c);
+  });
+}
+
+// ---- xi-basis objects ------------------------------------------------------------------
+int gsi_basis_create(gsi_ctx* ctx, gsi_basis** basis, const gsi_mat* Z, int64_t K, int precision) {
+  return guarded([&] {
+    REQUIRE(ctx && basis && Z && Z->ctx == ctx, "bad argument");
+    *basis = nullptr;
+    REQUIRE(K >= 1 && K <= Z->cols, "K out of range for this matrix");
+    REQUIRE(precision == 64 || precision == 32, "precision must be 64 or 32");
+    std::unique_ptr<gsi_basis> b(new gsi_basis());
+    b->ctx = ctx; b->n = Z->rows; b->K = K; b->precision = precision; b->Z64 = Z->buf.p;
+    if (precision == 32) {
+      const size_t count = (size_t)b->n * (size_t)K;
+      b->buf32 = Buf(ctx->c.be.get(), (count + 1) / 2);               // fp32 elements in a double-typed allocation
+      ctx->c.be->f64_to_f32(Z->buf.p, b->buf32.p, count);
+      b->Z64 = nullptr;
+    }
+    *basis = b.release();
+  });
+}
+int gsi_basis_destroy(gsi_basis* basis) {
+  return guarded([&] { delete basis; });
+}
+int gsi_pcga_params_basis(gsi_ctx* ctx, const gsi_basis* basis, const double* s, const double* X, double delta,
+                          double* out) {
+  return guarded([&] {
+    REQUIRE(ctx && basis && s && X && out && basis->ctx == ctx, "bad argument");
+    if (basis->precision == 64) {
+      pcga_params_impl(ctx->c, basis->Z64, basis->n, basis->K, s, X, delta, out);
+      return;
+    }
+    Backend* be = ctx->c.be.get();
+    const int64_t n = basis->n, K = basis->K;
+    Buf O(be, (size_t)n * (K + 3)), sv(be, (size_t)n), Xv(be, (size_t)n);
+    be->upload2d(sv.p, n, s, n, n, 1);
+    be->upload2d(Xv.p, n, X, n, n, 1);
+    be->pcga_params_f32(basis->buf32.p, n, K, sv.p, Xv.p, delta, O.p);
+    be->download2d(out, n, O.p, n, n, K + 3);
+  });
+}
+int gsi_pcga_update_basis(gsi_ctx* ctx, const gsi_basis* basis, const double* X, double beta_bar, const double* etas,
+                          int64_t nobs, const double* xi_bar, double* s_out) {
+  return guarded([&] {
+    REQUIRE(ctx && basis && X && etas && xi_bar && s_out && basis->ctx == ctx && nobs >= 1, "bad argument");
+    if (basis->precision == 64) {
+      pcga_update_impl(ctx->c, basis->Z64, basis->n, basis->K, X, beta_bar, etas, nobs, xi_bar, s_out);
+      return;
+    }
+    Backend* be = ctx->c.be.get();
+    const int64_t n = basis->n, K = basis->K;
+    Buf E(be, (size_t)nobs * K), xb(be, (size_t)nobs), w(be, (size_t)K), sd(be, (size_t)n), Xd(be, (size_t)n);
+    be->upload2d(E.p, nobs, etas, nobs, nobs, K);
+    be->upload2d(xb.p, nobs, xi_bar, nobs, nobs, 1);
+    be->upload2d(Xd.p, n, X, n, n, 1);
+    be->gemm_tn(K, 1, nobs, 1.0, E.p, nobs, xb.p, nobs, 0.0, w.p, K);          // w_i = dot(eta_i, xi_bar)
+    be->basis_gemv_f32(basis->buf32.p, n, K, w.p, beta_bar, Xd.p, sd.p);      // s = X beta_bar + sum_i xis[i] w_i
+    be->download2d(s_out, n, sd.p, n, n, 1);
+  });
+}
+int gsi_basis_download_col(gsi_ctx* ctx, const gsi_basis* basis, int64_t col, double* host) {
+  return guarded([&] {
+    REQUIRE(ctx && basis && host && basis->ctx == ctx, "bad argument");
+    REQUIRE(col >= 0 && col < basis->K, "column out of range");
+    Backend* be = ctx->c.be.get();
+    const int64_t n = basis->n;
+    if (basis->precision == 64) {
+      be->download2d(host, n, basis->Z64 + (size_t)col * n, n, n, 1);
+      return;
+    }
+    // unit weight on column `col`: the fp32 column widened exactly
+    std::vector<double> w((size_t)basis->K, 0.0), zero((size_t)n, 0.0);
+    w[(size_t)col] = 1.0;
+    Buf wd(be, (size_t)basis->K), Xd(be, (size_t)n), sd(be, (size_t)n);
+    be->upload2d(wd.p, basis->K, w.data(), basis->K, basis->K, 1);
+    be->fill_zero(Xd.p, (size_t)n);
+    be->basis_gemv_f32(basis->buf32.p, n, basis->K, wd.p, 0.0, Xd.p, sd.p);
+    be->download2d(host, n, sd.p, n, n, 1);
   });
 }
 

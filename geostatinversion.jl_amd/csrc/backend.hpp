@@ -103,6 +103,12 @@ class Backend {
   virtual void pcga_params(const double* Z, int64_t n, int64_t K, const double* s, const double* X, double delta,
                            double* out) = 0;
 
+  // BLAS-2 (adaptive range finder, saddle-point products): y (m) = alpha A x + beta y; y (k) = alpha A' x (A m x k);
+  // Y[:, c] -= dot(q, Y[:, c]) q for c < ncols <= 64  (RandMatFact.jl:42-45) -- no scalar leaves the backend
+  virtual void gemv_n(int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double beta,
+                      double* y) = 0;
+  virtual void gemv_t(int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double* y) = 0;
+  virtual void project_out(int64_t m, int64_t ncols, const double* q, double* Y, int64_t ld) = 0;
   virtual void scal(int64_t n, double a, double* x) = 0;                          // x *= a
   virtual void diag_mul_add(int64_t n, const double* d, const double* x, double* y) = 0;   // y += d .* x
 

@@ -57,7 +57,7 @@ class HipBackend : public Backend {
   ~HipBackend() override {
     hipSetDevice(device_);
     hipStreamSynchronize(st_);
-    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_}) if (b->p) hipFree(b->p);
+    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_}) if (b->p) hipFree(b->p);
     for (auto& b : pool_) hipFree(b.p);
     for (auto& ev : ev_pool_) hipEventDestroy(ev);
     for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -146,7 +146,7 @@ class HipBackend : public Backend {
     }
   }
   int64_t bytes_in_use() const override {
-    return in_use_ + pooled_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes);
+    return in_use_ + pooled_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes + ws_blas2_.bytes);
   }
   void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) override {
     if (rows <= 0 || cols <= 0) return;
@@ -442,6 +442,25 @@ class HipBackend : public Backend {
     hipk::pcga_params(st_, Z, n, K, s, X, delta, out);
     check_launch("pcga_params");
   }
+  void gemv_n(int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double beta,
+              double* y) override {
+    bind();
+    hipk::gemv_n(st_, m, k, alpha, A, lda, x, beta, y);
+    check_launch("gemv_n");
+  }
+  void gemv_t(int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double* y) override {
+    bind();
+    grow(ws_blas2_, sizeof(double) * hipk::gemv_t_workspace_doubles(k));
+    hipk::gemv_t(st_, m, k, alpha, A, lda, x, y, (double*)ws_blas2_.p);
+    check_launch("gemv_t");
+  }
+  void project_out(int64_t m, int64_t ncols, const double* q, double* Y, int64_t ld) override {
+    bind();
+    if (ncols > 64) throw Error(GSI_ERR_ARG, "project_out: at most 64 columns at a time");
+    grow(ws_blas2_, sizeof(double) * hipk::gemv_t_workspace_doubles(ncols));
+    hipk::project_out(st_, m, ncols, q, Y, ld, (double*)ws_blas2_.p);
+    check_launch("project_out");
+  }
   void scal(int64_t n, double a, double* x) override { bind(); hipk::scal(st_, n, a, x); }
   void diag_mul_add(int64_t n, const double* d, const double* x, double* y) override {
     bind();
@@ -562,7 +581,7 @@ class HipBackend : public Backend {
   hipStream_t st_ = nullptr;
   int32_t* flags_ = nullptr;  // [0] lu info, [1] chol info, [8] jacobi rotation counter
   double* scal_ = nullptr;
-  DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_;
+  DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_, ws_blas2_;
   std::mutex mu_;
   std::vector<DevBuf> sizes_;
   std::vector<DevBuf> pool_;

@@ -123,6 +123,12 @@ void axpy(hipStream_t st, int64_t n, double a, const double* x, double* y);
 void scal_copy(hipStream_t st, int64_t n, double a, const double* x, double* y);
 void dot_dev(hipStream_t st, int64_t n, const double* x, const double* y, double* out_dev);   // out_dev: >= 8 + 256 doubles
 void scal(hipStream_t st, int64_t n, double a, double* x);
+void gemv_n(hipStream_t st, int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double beta,
+            double* y);
+size_t gemv_t_workspace_doubles(int64_t k);
+void gemv_t(hipStream_t st, int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double* y,
+            double* part);
+void project_out(hipStream_t st, int64_t m, int64_t ncols, const double* q, double* Y, int64_t ld, double* part);
 void diag_mul_add(hipStream_t st, int64_t n, const double* d, const double* x, double* y);
 void f64_to_f32(hipStream_t st, const double* src, float* dst, size_t count);
 void pcga_params_f32(hipStream_t st, const float* Z, int64_t n, int64_t K, const double* s, const double* X, double delta,

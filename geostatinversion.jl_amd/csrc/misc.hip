@@ -229,6 +229,96 @@ void scal_copy(hipStream_t st, int64_t n, double a, const double* x, double* y) 
   hipLaunchKernelGGL(scal_copy_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, a, x, y);
 }
 
+// ---- BLAS-2 for the adaptive range finder (RandMatFact.jl:30-45: gemv!, axpy!, dot) and the nobs-sized saddle-point
+//      products of pcgalsqr: HBM-bound, no matrix core involved, no host round trip per scalar --------------------
+// y (m) = alpha A x + beta y, A m x k column-major: thread = one row (coalesced column segments), x in LDS chunks
+__global__ __launch_bounds__(256) void gemv_n_kernel(int64_t m, int64_t k, double alpha, const double* __restrict__ A,
+                                                     int64_t lda, const double* __restrict__ x, double beta,
+                                                     double* __restrict__ y) {
+  __shared__ double xs[1024];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (int64_t k0 = 0; k0 < k; k0 += 1024) {
+    const int kc = (int)((k - k0 < 1024) ? (k - k0) : 1024);
+    __syncthreads();
+    for (int j = threadIdx.x; j < kc; j += 256) xs[j] = x[k0 + j];
+    __syncthreads();
+    if (i < m) {
+      const double* row = A + i + k0 * lda;
+      int j = 0;
+      for (; j + 4 <= kc; j += 4) {
+        a0 += row[(int64_t)(j + 0) * lda] * xs[j + 0];
+        a1 += row[(int64_t)(j + 1) * lda] * xs[j + 1];
+        a2 += row[(int64_t)(j + 2) * lda] * xs[j + 2];
+        a3 += row[(int64_t)(j + 3) * lda] * xs[j + 3];
+      }
+      for (; j < kc; ++j) a0 += row[(int64_t)j * lda] * xs[j];
+    }
+  }
+  if (i < m) {
+    const double v = alpha * ((a0 + a1) + (a2 + a3));
+    y[i] = (beta != 0.0) ? v + beta * y[i] : v;
+  }
+}
+void gemv_n(hipStream_t st, int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double beta,
+            double* y) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, k, alpha, A, lda, x, beta, y);
+}
+// y (k) = alpha A' x, A m x k: workgroup (column j, slab s) leaves a partial sum, a second launch adds the slabs in
+// index order (deterministic).  part: k * GEMV_T_SLABS doubles.
+constexpr int GEMV_T_SLABS = 32;
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(int64_t m, const double* __restrict__ A, int64_t lda,
+                                                             const double* __restrict__ x, double* __restrict__ part) {
+  __shared__ double s[4];
+  const int64_t j = blockIdx.x;
+  const int64_t per = (m + GEMV_T_SLABS - 1) / GEMV_T_SLABS;
+  const int64_t i0 = (int64_t)blockIdx.y * per, i1 = (i0 + per < m) ? i0 + per : m;
+  const double* col = A + j * lda;
+  double v = 0.0;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) v += col[i] * x[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) part[j * GEMV_T_SLABS + blockIdx.y] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+__global__ void gemv_t_final_kernel(int64_t k, double alpha, const double* __restrict__ part, double* __restrict__ y) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  double v = 0.0;
+  for (int s = 0; s < GEMV_T_SLABS; ++s) v += part[j * GEMV_T_SLABS + s];
+  y[j] = alpha * v;
+}
+size_t gemv_t_workspace_doubles(int64_t k) { return (size_t)k * GEMV_T_SLABS; }
+void gemv_t(hipStream_t st, int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double* y,
+            double* part) {
+  if (k <= 0) return;
+  hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)k, GEMV_T_SLABS), dim3(256), 0, st, m, A, lda, x, part);
+  hipLaunchKernelGGL(gemv_t_final_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, k, alpha, part, y);
+}
+// Y[:, c] -= dot(q, Y[:, c]) q for c < ncols (RandMatFact.jl:42-45): the dots stay on the device.  part: ncols * GEMV_T_SLABS.
+__global__ __launch_bounds__(256) void project_apply_kernel(int64_t m, int64_t ncols, const double* __restrict__ q,
+                                                            const double* __restrict__ part, double* __restrict__ Y,
+                                                            int64_t ld) {
+  __shared__ double d[64];
+  if (threadIdx.x < ncols) {
+    double v = 0.0;
+    for (int s = 0; s < GEMV_T_SLABS; ++s) v += part[threadIdx.x * GEMV_T_SLABS + s];
+    d[threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+    const double qi = q[i];
+    for (int64_t c = 0; c < ncols; ++c) Y[i + c * ld] -= d[c] * qi;
+  }
+}
+void project_out(hipStream_t st, int64_t m, int64_t ncols, const double* q, double* Y, int64_t ld, double* part) {
+  if (ncols <= 0) return;
+  hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)ncols, GEMV_T_SLABS), dim3(256), 0, st, m, Y, ld, q, part);
+  hipLaunchKernelGGL(project_apply_kernel, dim3(grid_for(m, 1024)), dim3(256), 0, st, m, ncols, q, part, Y, ld);
+}
+
 __global__ void scal_kernel(int64_t n, double a, double* __restrict__ x) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= a;
 }

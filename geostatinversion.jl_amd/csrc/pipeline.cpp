@@ -391,6 +391,110 @@ void eig_nystrom(const Operator& A, const double* Q, int64_t j, double* U, doubl
   svd_tall(c, B1.p, n, j, -1, U, Sigma);                    // U, Sigmavec, V = svd(F)        :97
 }
 
+// ---- IterativeSolvers.lsqr (third-party, Project.toml:21; not under the reference tree): Paige & Saunders' LSQR
+//      with that package's defaults, restated from the published algorithm exactly as oracle/oracle.py:lsqr does
+//      (same order of operations, same stopping rules); vectors live in backend memory, the scalar recurrences on
+//      the host (two norms per iteration cross the bus).
+int64_t lsqr(Context& c, const LsqrOperator& A, const double* b, double* x, int64_t maxiter) {
+  Backend* be = c.be.get();
+  const int64_t m = A.nrows, n = A.ncols;
+  const double tol = std::sqrt(2.220446049250313e-16);
+  const double atol = tol, btol = tol, conlim = 1e8;
+  const double ctol = 1.0 / conlim;
+  if (maxiter < 0) maxiter = std::max(m, n);
+  Buf u(be, (size_t)m), v(be, (size_t)n), w(be, (size_t)n), t(be, (size_t)std::max(m, n));
+  be->fill_zero(x, (size_t)n);
+  be->copy2d(u.p, m, b, m, m, 1);
+  double beta = be->nrm2(m, u.p);
+  if (beta == 0.0) return 0;
+  be->scal(m, 1.0 / beta, u.p);
+  A.mul_t(u.p, v.p);
+  double alpha = be->nrm2(n, v.p);
+  if (alpha == 0.0) return 0;
+  be->scal(n, 1.0 / alpha, v.p);
+  be->copy2d(w.p, n, v.p, n, n, 1);
+  double rhobar = alpha, phibar = beta;
+  const double bnorm = beta;
+  double Anorm = 0.0, ddnorm = 0.0, xxnorm = 0.0, res2 = 0.0, z = 0.0, cs2 = -1.0, sn2 = 0.0;
+  int64_t it = 0;
+  while (it < maxiter) {
+    ++it;
+    A.mul(v.p, t.p);                                   // u = A v - alpha u
+    be->scal(m, -alpha, u.p);
+    be->axpy(m, 1.0, t.p, u.p);
+    beta = be->nrm2(m, u.p);
+    if (beta > 0.0) {
+      be->scal(m, 1.0 / beta, u.p);
+      Anorm = std::sqrt(Anorm * Anorm + alpha * alpha + beta * beta);
+      A.mul_t(u.p, t.p);                               // v = A' u - beta v
+      be->scal(n, -beta, v.p);
+      be->axpy(n, 1.0, t.p, v.p);
+      alpha = be->nrm2(n, v.p);
+      if (alpha > 0.0) be->scal(n, 1.0 / alpha, v.p);
+    }
+    const double rhobar1 = rhobar;                     // damp = 0
+    const double rho = std::sqrt(rhobar1 * rhobar1 + beta * beta);
+    const double cs = rhobar1 / rho, sn = beta / rho;
+    const double theta = sn * alpha;
+    rhobar = -cs * alpha;
+    const double phi = cs * phibar;
+    phibar = sn * phibar;
+    const double tau = sn * phi;
+    const double t1 = phi / rho, t2 = -theta / rho;
+    const double wn = be->nrm2(n, w.p);
+    ddnorm += (wn / rho) * (wn / rho);
+    be->axpy(n, t1, w.p, x);                           // x = x + t1 w
+    be->scal(n, t2, w.p);                              // w = v + t2 w
+    be->axpy(n, 1.0, v.p, w.p);
+    const double delta = sn2 * rho, gambar = -cs2 * rho, rhs = phi - delta * z;
+    const double zbar = rhs / gambar;
+    const double xnorm = std::sqrt(xxnorm + zbar * zbar);
+    const double gamma = std::sqrt(gambar * gambar + theta * theta);
+    cs2 = gambar / gamma;
+    sn2 = theta / gamma;
+    z = rhs / gamma;
+    xxnorm += z * z;
+    const double Acond = Anorm * std::sqrt(ddnorm);
+    const double rnorm = std::sqrt(phibar * phibar + res2);
+    const double Arnorm = alpha * std::fabs(tau);
+    const double test1 = rnorm / bnorm;
+    const double test2 = (Anorm * rnorm > 0.0) ? Arnorm / (Anorm * rnorm) : 0.0;
+    const double test3 = (Acond > 0.0) ? 1.0 / Acond : 0.0;
+    const double t1c = test1 / (1.0 + Anorm * xnorm / bnorm);
+    const double rtol = btol + atol * Anorm * xnorm / bnorm;
+    if (1.0 + test3 <= 1.0 || 1.0 + test2 <= 1.0 || 1.0 + t1c <= 1.0) break;
+    if (test3 <= ctol || test2 <= atol || test1 <= rtol) break;
+  }
+  return it;
+}
+
+int64_t lowrank_solve(const Operator& A, const double* b, double* x) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  if (A.kind != OP_LOWRANK) throw Error(GSI_ERR_ARG, "lowrank_solve: the operator is not a LowRankCovMatrix");
+  LsqrOperator L;
+  L.nrows = L.ncols = A.n;
+  Buf yloc(be, (size_t)std::max<int64_t>(A.mloc, 1));
+  L.mul = [&](const double* xin, double* y) {          // adjoint(A) === A (lowrank.jl:38-40)
+    op_mul(A, xin, A.n, 1, yloc.p, A.mloc);
+    gather_rows(c, A, yloc.p, A.mloc, 1, y);
+  };
+  L.mul_t = L.mul;
+  return lsqr(c, L, b, x, A.N);                        // maxiter = length(A.samples)   lowrank.jl:142
+}
+
+// v[1:end-1] = R xs + sum_i eta_i dot(eta_i, xs) + HX x[end];  v[end] = dot(HX, xs)      lowrank.jl:83-97
+void PcgaLowRank::mul(const double* x, double* y) const {
+  Backend* be = ctx->be.get();
+  Buf t(be, (size_t)K);
+  be->gemv_t(nobs, K, 1.0, E.p, nobs, x, t.p);                                    // t_i = dot(eta_i, xs)
+  be->gemv_n(nobs, K, 1.0, E.p, nobs, t.p, 0.0, y);                               // sum_i eta_i t_i
+  if (r_diag) be->diag_mul_add(nobs, R.p, x, y);                                  // + R xs
+  else be->gemv_n(nobs, nobs, 1.0, R.p, nobs, x, 1.0, y);
+  be->gemv_n(nobs, 1, 1.0, HX.p, nobs, x + nobs, 1.0, y);                         // + HX x[end]
+  be->gemv_t(nobs, 1, 1.0, HX.p, nobs, x, y + nobs);                              // dot(HX, xs)
+}
+
 int64_t rangefinder_adaptive(const Operator& A, randn_fn rn, void* user, double epsilon, int64_t r,
                              double* Q_host) {
   Context& c = *A.ctx;
@@ -421,25 +525,21 @@ int64_t rangefinder_adaptive(const Operator& A, randn_fn rn, void* user, double 
     double* Yj = Yfull.p + (j - 1) * n;
     double* Qj = Qfull.p + (j - 1) * m;
     if (j > 1) {
-      be->gemm_tn(j - 1, 1, m, 1.0, Qfull.p, m, Yj, n, 0.0, tmp.p, kmax);      // QtYj = gemv('T',1,Q,Yj)   :30
+      be->gemv_t(m, j - 1, 1.0, Qfull.p, m, Yj, tmp.p);                        // QtYj = gemv('T',1,Q,Yj)   :30
       // the reference's `Yj -= Q*QtYj` rebinds Yj to a new vector; the view in Yfull keeps the old
       // values.  Column j of Yfull is never read again, so updating it in place is equivalent.
-      be->gemm_nn(m, 1, j - 1, -1.0, Qfull.p, m, tmp.p, kmax, 1.0, Yj, n);     // Yj - Q*QtYj               :31
+      be->gemv_n(m, j - 1, -1.0, Qfull.p, m, tmp.p, 1.0, Yj);                  // Yj - Q*QtYj               :31
     }
     const double nrm = be->nrm2(m, Yj);
     be->axpy(m, 1.0 / nrm, Yj, Qj);                         // axpy!(1/norm(Yj), Yj, Qj)      :32-34
     rn(user, host.data(), n);                               // randn!(omega)                  :36
     be->upload2d(om.p, n, host.data(), n, n, 1);
-    be->gemm_nn(m, 1, n, 1.0, A.data.p, A.ld, om.p, n, 0.0, Aom.p, m);          // gemv!('N',1,A,omega,0,Aomega) :37
-    be->gemm_tn(j, 1, m, 1.0, Qfull.p, m, Aom.p, m, 0.0, tmp.p, kmax);          // QtAomega                 :38
+    be->gemv_n(m, n, 1.0, A.data.p, A.ld, om.p, 0.0, Aom.p);                    // gemv!('N',1,A,omega,0,Aomega) :37
+    be->gemv_t(m, j, 1.0, Qfull.p, m, Aom.p, tmp.p);                            // QtAomega                 :38
     double* ynew = Yfull.p + (r + j - 1) * n;
     be->scal_copy(m, 1.0, Aom.p, ynew);
-    be->gemm_nn(m, 1, j, -1.0, Qfull.p, m, tmp.p, kmax, 1.0, ynew, n);          // ynew = Aomega - Q*QtAomega :39-40
-    for (int64_t i = j + 1; i <= j + r - 1; ++i) {          //                                :42-45
-      double* Yi = Yfull.p + (i - 1) * n;
-      const double d = be->dot(m, Qj, Yi);
-      be->axpy(m, -d, Qj, Yi);
-    }
+    be->gemv_n(m, j, -1.0, Qfull.p, m, tmp.p, 1.0, ynew);                       // ynew = Aomega - Q*QtAomega :39-40
+    be->project_out(m, r - 1, Qj, Yfull.p + j * n, n);      // Yi -= dot(Qj, Yi) Qj, i = j+1 .. j+r-1   :42-45
   }
   if (j > 0) be->download2d(Q_host, m, Qfull.p, m, m, j);   // return Qfull[:, 1:j]           :47
   return j;

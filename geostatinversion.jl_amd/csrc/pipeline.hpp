@@ -2,6 +2,7 @@
 // row-sharded over gsi::Comm ranks.  No kernel code here.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <vector>
 #include "backend.hpp"
@@ -75,6 +76,24 @@ void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, doub
 typedef void (*randn_fn)(void* user, double* buf, int64_t count);
 int64_t rangefinder_adaptive(const Operator& A, randn_fn rn, void* user, double epsilon, int64_t r,
                              double* Q_host);
+// IterativeSolvers.jl 0.9 `lsqr(A, b; maxiter)` (Paige & Saunders 1982) with that package's defaults
+// (atol = btol = sqrt(eps), conlim = 1e8) on backend-resident vectors.  Call sites in the reference: lsqr.jl:54,
+// lowrank.jl:142.  mul(x, y): y = A x (x: ncols, y: nrows); mul_t(x, y): y = A' x.  Returns the iteration count.
+struct LsqrOperator {
+  int64_t nrows = 0, ncols = 0;
+  std::function<void(const double*, double*)> mul, mul_t;
+};
+int64_t lsqr(Context& c, const LsqrOperator& A, const double* b, double* x, int64_t maxiter);
+// x = A \ b for a LowRankCovMatrix: lsqr with maxiter = number of samples  (lowrank.jl:141-144); b, x replicated (n)
+int64_t lowrank_solve(const Operator& A, const double* b, double* x);
+// PCGALowRankMatrix(etas, HX, R)  (lowrank.jl:32-36, 83-97): [(HQH + R) HX; HX' 0], HQH = sum eta_i eta_i' kept implicit.
+struct PcgaLowRank {
+  Context* ctx = nullptr;
+  int64_t nobs = 0, K = 0;
+  Buf E, HX, R;        // E: nobs x K (eta_i as columns); R: nobs x nobs dense, or nobs values when r_diag
+  bool r_diag = false;
+  void mul(const double* x, double* y) const;   // x, y: nobs + 1
+};
 // throws Error if a kernel raised an asynchronous flag
 void check_async_errors(Context& c);
 

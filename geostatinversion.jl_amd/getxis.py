@@ -43,10 +43,10 @@ def _getxis_matrix(Q, numxis, p, q=3, seed=None, *, Omega=None):
     return [np.ascontiguousarray(Z[:, i]) for i in range(numxis)]   # :66-68
 
 
-def getxis_device(Q, numxis, p, q=3, seed=None, *, Omega=None, ctx=None):
+def getxis_device(Q, numxis, p, q=3, seed=None, *, Omega=None, ctx=None, precision=64):
     """`getxis` whose result stays in HBM: returns a `DeviceBasis` usable wherever the
     reference takes `xis` (`pcgadirect`, `pcgalsqr`, `rga`).  Q: a matrix, a `LowRankCovMatrix` or a device
-    `Operator`."""
+    `Operator`.  `precision=32`: the basis is kept in fp32 (mixed precision, BASELINE configs[4])."""
     import ctypes as C
     from . import _lib as L
     from .context import DeviceMatrix, Operator, dense_operator, default_context
@@ -69,7 +69,7 @@ def getxis_device(Q, numxis, p, q=3, seed=None, *, Omega=None, ctx=None):
         Z = DeviceMatrix(cx, n, l)
         L.check(cx.lib.gsi_randsvd_dev(cx.h, op.h, Omd.h, int(numxis), int(p), int(q), Z.h, None), cx.lib)
         Omd.close()
-        return DeviceBasis(Z, numxis)
+        return DeviceBasis(Z, numxis, precision=precision)
     finally:
         if owned:
             op.close()

@@ -65,6 +65,19 @@ class LowRankCovMatrix:
     def todense(self):
         return self.matmul(np.eye(self.n))
 
+    def solve(self, b, *, return_iterations=False):
+        """`\\(A::LowRankCovMatrix, b::Vector)`  (lowrank.jl:141-144): `lsqr(A, b; maxiter=length(A.samples))` with
+        IterativeSolvers' defaults, every vector resident in HBM (`gsi_op_lowrank_solve`)."""
+        op = self._device_operator()
+        bv = np.ascontiguousarray(b, dtype=np.float64)
+        if bv.shape != (self.n,):
+            raise ValueError("dimension mismatch")
+        x = np.empty(self.n)
+        it = C.c_int64()
+        L.check(op.ctx.lib.gsi_op_lowrank_solve(op.ctx.h, op.h, bv.ctypes.data_as(L.c_dp), x.ctypes.data_as(L.c_dp),
+                                               C.byref(it)), op.ctx.lib)
+        return (x, it.value) if return_iterations else x
+
     def close(self):
         if self._op is not None:
             self._op.close()
@@ -73,30 +86,63 @@ class LowRankCovMatrix:
 
 class PCGALowRankMatrix:
     """`PCGALowRankMatrix(etas, HX, R)`  (lowrank.jl:32-36, 62-73, 83-97): the saddle-point matrix
-    [(HQH+R) HX; HX' 0] with HQH = sum eta_i eta_i' kept implicit.  nobs-sized host algebra, as in
-    the reference; it is the LSQR operator of pcgalsqr (lsqr.jl:53-54)."""
+    [(HQH+R) HX; HX' 0] with HQH = sum eta_i eta_i' kept implicit -- the LSQR operator of pcgalsqr
+    (lsqr.jl:53-54).  etas, HX and R are uploaded once (`gsi_pcgamat_create`); the product and the LSQR solve run on
+    the device (`gsi_pcgamat_mul`, `gsi_pcgamat_lsqr`)."""
 
-    def __init__(self, etas, HX, R):
-        self.E = np.asfortranarray(np.stack([np.asarray(e, dtype=np.float64) for e in etas], axis=1))
-        self.HX = np.asarray(HX, dtype=np.float64)
-        self.R = R
+    def __init__(self, etas, HX, R, ctx=None):
+        self.ctx = ctx or default_context()
+        E = np.asfortranarray(np.stack([np.asarray(e, dtype=np.float64) for e in etas], axis=1))
+        self.nobs, self.K = E.shape
+        hx = np.ascontiguousarray(HX, dtype=np.float64)
+        if hasattr(R, "diagonal") and hasattr(R, "nnz") and R.nnz == np.count_nonzero(R.diagonal()):
+            Rv, diag = np.ascontiguousarray(R.diagonal(), dtype=np.float64), 1     # sparse diagonal (the tests' R)
+        else:
+            Rd = R.toarray() if hasattr(R, "toarray") else np.asarray(R, dtype=np.float64)
+            Rv, diag = np.asfortranarray(Rd), 0
+        h = C.c_void_p()
+        lib = self.ctx.lib
+        L.check(lib.gsi_pcgamat_create(self.ctx.h, C.byref(h), L.dptr(E), self.nobs, self.K, hx.ctypes.data_as(L.c_dp),
+                                       Rv.ctypes.data_as(L.c_dp), diag), lib)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.gsi_pcgamat_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def shape(self):
-        s = self.E.shape[0] + 1
-        return (s, s)
+        return (self.nobs + 1, self.nobs + 1)
 
     def size(self, i):
         if i in (1, 2):
-            return self.E.shape[0] + 1
-        raise IndexError(f"there is no {i}-th dimension in a PCGALowRankMatrix")
+            return self.nobs + 1
+        raise IndexError(f"there is no {i}-th dimension in a PCGALowRankMatrix")      # lowrank.jl:71
 
     def matvec(self, x):
-        x = np.asarray(x, dtype=np.float64)
-        xs = x[:-1]
-        v = np.empty(len(x))
-        v[:-1] = self.R @ xs + self.E @ (self.E.T @ xs) + self.HX * x[-1]
-        v[-1] = np.dot(self.HX, xs)
-        return v
+        """`*(A::PCGALowRankMatrix, x::Vector)` / `mul!`  (lowrank.jl:83-97, 109-113)."""
+        xv = np.ascontiguousarray(x, dtype=np.float64)
+        if xv.shape != (self.nobs + 1,):
+            raise ValueError("dimension mismatch")
+        y = np.empty(self.nobs + 1)
+        L.check(self.ctx.lib.gsi_pcgamat_mul(self.ctx.h, self.h, xv.ctypes.data_as(L.c_dp), y.ctypes.data_as(L.c_dp)),
+                self.ctx.lib)
+        return y
 
     __matmul__ = matvec
+
+    def lsqr(self, b, *, return_iterations=False):
+        """`IterativeSolvers.lsqr(bigA, b)` with that package's defaults  (lsqr.jl:54)."""
+        bv = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.empty(self.nobs + 1)
+        it = C.c_int64()
+        L.check(self.ctx.lib.gsi_pcgamat_lsqr(self.ctx.h, self.h, bv.ctypes.data_as(L.c_dp), x.ctypes.data_as(L.c_dp),
+                                              C.byref(it)), self.ctx.lib)
+        return (x, it.value) if return_iterations else x

@@ -1,7 +1,8 @@
 """Host-side mirror of the consumers of the xi-basis: `pcgadirect` (src/direct.jl), `pcgalsqr`
 (src/lsqr.jl) and `rga` (src/GeostatInversion.jl:101-103).  The forward model is user code and runs
 on the host exactly as the reference's `pmap` does; the package's own n-sized algebra (the
-perturbation batch and the update s = X*beta + sum xis[i]*dot(eta_i, xi_bar)) runs on the GPU."""
+perturbation batch and the update s = X*beta + sum xis[i]*dot(eta_i, xi_bar)) and pcgalsqr's
+saddle-point LSQR (PCGALowRankMatrix products, IterativeSolvers defaults) run on the GPU."""
 import numpy as np
 
 from . import _lib as L
@@ -11,85 +12,39 @@ from .lowrank import PCGALowRankMatrix
 SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
 
 
-def _lsqr(matvec, b, maxiter=None):
-    """IterativeSolvers.jl 0.9 `lsqr` defaults (atol = btol = sqrt(eps), conlim = 1e8,
-    maxiter = max(size)) for a symmetric operator -- Paige & Saunders 1982.  nobs-sized, host."""
-    b = np.asarray(b, dtype=np.float64)
-    n = b.shape[0]
-    tol = SQRT_EPS
-    maxiter = n if maxiter is None else maxiter
-    x = np.zeros(n)
-    u = b.copy()
-    beta = np.linalg.norm(u)
-    if beta == 0:
-        return x
-    u /= beta
-    v = matvec(u)
-    alpha = np.linalg.norm(v)
-    if alpha == 0:
-        return x
-    v /= alpha
-    w = v.copy()
-    rhobar, phibar, bnorm = alpha, beta, beta
-    Anorm = ddnorm = xxnorm = z = 0.0
-    cs2, sn2 = -1.0, 0.0
-    for _ in range(maxiter):
-        u = matvec(v) - alpha * u
-        beta = np.linalg.norm(u)
-        if beta > 0:
-            u /= beta
-            Anorm = np.sqrt(Anorm ** 2 + alpha ** 2 + beta ** 2)
-            v = matvec(u) - beta * v
-            alpha = np.linalg.norm(v)
-            if alpha > 0:
-                v /= alpha
-        rho = np.hypot(rhobar, beta)
-        cs, sn = rhobar / rho, beta / rho
-        theta = sn * alpha
-        rhobar = -cs * alpha
-        phi = cs * phibar
-        phibar = sn * phibar
-        tau = sn * phi
-        ddnorm += (np.linalg.norm(w) / rho) ** 2
-        x = x + (phi / rho) * w
-        w = v - (theta / rho) * w
-        delta = sn2 * rho
-        gambar = -cs2 * rho
-        rhs = phi - delta * z
-        zbar = rhs / gambar
-        xnorm = np.sqrt(xxnorm + zbar ** 2)
-        gamma = np.hypot(gambar, theta)
-        cs2, sn2 = gambar / gamma, theta / gamma
-        z = rhs / gamma
-        xxnorm += z ** 2
-        Acond = Anorm * np.sqrt(ddnorm)
-        rnorm = phibar
-        Arnorm = alpha * abs(tau)
-        test1 = rnorm / bnorm
-        test2 = Arnorm / (Anorm * rnorm) if Anorm * rnorm > 0 else 0.0
-        test3 = 1.0 / Acond if Acond > 0 else 0.0
-        t1 = test1 / (1.0 + Anorm * xnorm / bnorm)
-        rtol = tol + tol * Anorm * xnorm / bnorm
-        if 1 + test3 <= 1 or 1 + test2 <= 1 or 1 + t1 <= 1:
-            break
-        if test3 <= 1e-8 or test2 <= tol or test1 <= rtol:
-            break
-    return x
-
-
 class DeviceBasis:
     """The xi-basis resident in HBM: the n x (K+p) matrix Z a device-side randsvd left
     there; `xis[i]` is its column i.  Pass it to `pcgadirect` / `pcgalsqr` / `rga` in place of the
     reference's `xis::Array{Array{Float64,1},1}`: the basis then crosses PCIe never (only the n x (K+3)
-    perturbation batch and the updated s do, because the forward model is host code)."""
+    perturbation batch and the updated s do, because the forward model is host code).
+    `precision=32` keeps an fp32 copy of the K columns instead (BASELINE configs[4], "fp32 mixed precision": half
+    the HBM bytes of every iteration's own algebra; all sums in fp64)."""
 
-    def __init__(self, Zmat, K):
+    def __init__(self, Zmat, K, precision=64):
+        import ctypes as C
         self.Zmat = Zmat
         self.ctx = Zmat.ctx
         self.n = Zmat.shape[0]
         self.K = int(K)
+        self.precision = int(precision)
         if not 1 <= self.K <= Zmat.shape[1]:
             raise ValueError("K out of range for this basis")
+        h = C.c_void_p()
+        L.check(self.ctx.lib.gsi_basis_create(self.ctx.h, C.byref(h), Zmat.h, self.K, self.precision), self.ctx.lib)
+        self.h = h
+        if self.precision == 32:
+            self.Zmat = None            # the fp64 matrix is no longer needed by this basis
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.gsi_basis_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __len__(self):
         return self.K
@@ -99,15 +54,15 @@ class DeviceBasis:
         if not 0 <= i < self.K:
             raise IndexError(i)
         out = np.empty(self.n)
-        L.check(self.ctx.lib.gsi_mat_download_col(self.ctx.h, self.Zmat.h, i, out.ctypes.data_as(L.c_dp)), self.ctx.lib)
+        L.check(self.ctx.lib.gsi_basis_download_col(self.ctx.h, self.h, i, out.ctypes.data_as(L.c_dp)), self.ctx.lib)
         return out
 
     def params(self, s, X, delta):
         out = np.empty((self.n, self.K + 3), order="F")
         s = np.ascontiguousarray(s, dtype=np.float64)
         X = np.ascontiguousarray(X, dtype=np.float64)
-        L.check(self.ctx.lib.gsi_pcga_params_dev(self.ctx.h, self.Zmat.h, self.K, s.ctypes.data_as(L.c_dp),
-                                                 X.ctypes.data_as(L.c_dp), float(delta), L.dptr(out)), self.ctx.lib)
+        L.check(self.ctx.lib.gsi_pcga_params_basis(self.ctx.h, self.h, s.ctypes.data_as(L.c_dp),
+                                                   X.ctypes.data_as(L.c_dp), float(delta), L.dptr(out)), self.ctx.lib)
         return out
 
     def update(self, X, beta_bar, etas, xi_bar):
@@ -115,9 +70,9 @@ class DeviceBasis:
         X = np.ascontiguousarray(X, dtype=np.float64)
         xb = np.ascontiguousarray(xi_bar, dtype=np.float64)
         out = np.empty(self.n)
-        L.check(self.ctx.lib.gsi_pcga_update_dev(self.ctx.h, self.Zmat.h, self.K, X.ctypes.data_as(L.c_dp),
-                                                 float(beta_bar), L.dptr(E), E.shape[0], xb.ctypes.data_as(L.c_dp),
-                                                 out.ctypes.data_as(L.c_dp)), self.ctx.lib)
+        L.check(self.ctx.lib.gsi_pcga_update_basis(self.ctx.h, self.h, X.ctypes.data_as(L.c_dp), float(beta_bar),
+                                                   L.dptr(E), E.shape[0], xb.ctypes.data_as(L.c_dp),
+                                                   out.ctypes.data_as(L.c_dp)), self.ctx.lib)
         return out
 
 
@@ -204,8 +159,9 @@ def pcgalsqr(forwardmodel, s0, X, xis, R, y, *, maxiters=5, delta=SQRT_EPS, xtol
         olds = s
         etas, HX, Hs, hs = _iteration_head(forwardmodel, basis, s, X, delta)
         b = np.concatenate([y - hs + Hs, np.zeros(1)])                # :52
-        bigA = PCGALowRankMatrix(etas, HX, R)                         # :53
-        x = _lsqr(bigA.matvec, b)                                     # :54
+        bigA = PCGALowRankMatrix(etas, HX, R, ctx=basis.ctx)          # :53
+        x = bigA.lsqr(b)                                              # :54  (LSQR on the device)
+        bigA.close()
         s = basis.update(X, x[-1], etas, x[:-1])                      # :55-61
         if np.linalg.norm(s - olds) < xtol:
             converged = True

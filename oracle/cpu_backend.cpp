@@ -224,6 +224,19 @@ class CpuBackend : public Backend {
         out[i + c * n] = s[i] + delta * d;
       }
   }
+  void gemv_n(int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double beta,
+              double* y) override {
+    gsio_gemm_nn(m, 1, k, alpha, A, lda, x, k > 0 ? k : 1, beta, y, m > 0 ? m : 1);
+  }
+  void gemv_t(int64_t m, int64_t k, double alpha, const double* A, int64_t lda, const double* x, double* y) override {
+    gsio_gemm_tn(k, 1, m, alpha, A, lda, x, m > 0 ? m : 1, 0.0, y, k > 0 ? k : 1);
+  }
+  void project_out(int64_t m, int64_t ncols, const double* q, double* Y, int64_t ld) override {
+    for (int64_t c = 0; c < ncols; ++c) {
+      const double d = dot(m, q, Y + c * ld);
+      axpy(m, -d, q, Y + c * ld);
+    }
+  }
   void scal(int64_t n, double a, double* x) override { for (int64_t i = 0; i < n; ++i) x[i] *= a; }
   void diag_mul_add(int64_t n, const double* d, const double* x, double* y) override { for (int64_t i = 0; i < n; ++i) y[i] += d[i] * x[i]; }
   void f64_to_f32(const double* src, void* dst32, size_t count) override {

@@ -213,3 +213,76 @@ def test_fft_powerlaw_operator_cpuref(gsi, cx, Ns, beta):
     assert rel_sv_err(S, Sr, K) < 1e-9
     assert np.abs(Z @ Z.T - Zr @ Zr.T).max() < 1e-8 * Sr[0]
     op.close()
+
+
+# ---- LSQR consumers, PCGALowRankMatrix, fp32 basis through the shipped pipeline ----------
+def _pcga_problem(rng, nobs, K):
+    etas = [rng.standard_normal(nobs) for _ in range(K)]
+    HX = rng.standard_normal(nobs)
+    import scipy.sparse as sp
+    R = 1e-2 * sp.identity(nobs, format="csc")
+    return etas, HX, R
+
+
+def test_lowrank_solve_cpuref(gsi, cx):
+    """`\\(A::LowRankCovMatrix, b)` (lowrank.jl:141-144) = lsqr with maxiter = N: same iterate as the oracle's."""
+    rng = np.random.default_rng(11)
+    fields = powerlaw_fields(rng, (7, 6), 12)
+    lr = gsi.LowRankCovMatrix(fields, ctx=cx)
+    ref = orc.LowRankCovMatrix(fields)
+    b = ref.matmul(rng.standard_normal(42))            # in range(A): a consistent system
+    x, it = lr.solve(b, return_iterations=True)
+    xr = ref.solve(b)
+    assert it <= 12
+    # the Krylov iterates of the two products (two GEMMs here, N rank-1 updates in the oracle) agree to rounding
+    # amplified by the operator's condition number; the iteration stops on maxiter, not on convergence
+    assert np.linalg.norm(x - xr) < 1e-3 * np.linalg.norm(xr)
+    assert np.linalg.norm(ref.matmul(x) - b) < 1e-3 * np.linalg.norm(b)
+    lr.close()
+
+
+def test_pcga_lowrank_matrix_cpuref(gsi, cx):
+    rng = np.random.default_rng(12)
+    nobs, K = 23, 5
+    etas, HX, R = _pcga_problem(rng, nobs, K)
+    A = gsi.PCGALowRankMatrix(etas, HX, R, ctx=cx)
+    ref = orc.PCGALowRankMatrix(etas, HX, R)
+    assert A.shape == (nobs + 1, nobs + 1) and A.size(1) == nobs + 1
+    with pytest.raises(IndexError):
+        A.size(3)
+    x = rng.standard_normal(nobs + 1)
+    assert np.abs(A.matvec(x) - ref.matvec(x)).max() < 1e-12
+    # dense R takes the other code path
+    Rd = R.toarray() + 1e-3 * np.diag(rng.random(nobs))
+    A2 = gsi.PCGALowRankMatrix(etas, HX, Rd, ctx=cx)
+    assert np.abs(A2.matvec(x) - orc.PCGALowRankMatrix(etas, HX, Rd).matvec(x)).max() < 1e-12
+    b = np.concatenate([rng.standard_normal(nobs), [0.0]])
+    sol, it = A.lsqr(b, return_iterations=True)
+    solr, itr = orc.lsqr(ref.matvec, ref.matvec, b, nobs + 1)
+    assert it == itr
+    assert np.linalg.norm(sol - solr) < 1e-7 * np.linalg.norm(solr)     # both stop at atol = btol = sqrt(eps)
+    A.close(); A2.close()
+
+
+def test_fp32_basis_cpuref(gsi, cx):
+    """fp32-stored xi-basis: params/update equal the fp64 formulas on the ROUNDED basis to fp64 accuracy, and the
+    fp64 results to fp32 accuracy."""
+    rng = np.random.default_rng(13)
+    n, K, nobs = 97, 6, 15
+    Zh = rng.standard_normal((n, K + 2))
+    Zd = gsi.DeviceMatrix.from_host(cx, Zh)
+    b64 = gsi.DeviceBasis(Zd, K)
+    b32 = gsi.DeviceBasis(Zd, K, precision=32)
+    s, X = rng.standard_normal(n), rng.standard_normal(n)
+    Z32 = Zh[:, :K].astype(np.float32).astype(np.float64)
+    P32 = b32.params(s, X, 1e-3)
+    assert np.abs(P32[:, :K] - (s[:, None] + 1e-3 * Z32)).max() < 1e-15
+    assert np.abs(P32 - b64.params(s, X, 1e-3)).max() < 1e-3 * 1e-6
+    etas = [rng.standard_normal(nobs) for _ in range(K)]
+    xb = rng.standard_normal(nobs)
+    w = np.array([e @ xb for e in etas])
+    u32 = b32.update(X, 0.7, etas, xb)
+    assert np.abs(u32 - (0.7 * X + Z32 @ w)).max() < 1e-12
+    assert np.abs(u32 - b64.update(X, 0.7, etas, xb)).max() < 1e-5
+    assert np.abs(b32[2] - Z32[:, 2]).max() == 0.0 and np.abs(b64[2] - Zh[:, 2]).max() == 0.0
+    b32.close(); b64.close(); Zd.close()
