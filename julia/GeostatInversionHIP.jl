@@ -19,6 +19,8 @@ module GeostatInversionHIP
 
 import Random
 import Libdl
+import LinearAlgebra
+import Distributed
 
 const libgsi = get(ENV, "GSI_HIP_LIB", joinpath(@__DIR__, "..", "geostatinversion.jl_amd", "libgsi_hip.so"))
 
@@ -116,8 +118,11 @@ function GridCovImplicit(nx::Int, ny::Int, ell::Float64; c::Context=ctx())
 	return op
 end
 
-"Exact, matrix-free covariance of `FFTRF.powerlaw_structuredgrid(Ns, k0, dk, beta)` fields up to the factor dk^2
-(circulant embedding, spectrum |k|^beta, unit diagonal): `gsi_op_fft_powerlaw`.  Acts on `vec(field)`."
+"Matrix-free stationary power-law covariance on a structured grid (circulant embedding on the next power of two
+>= 2N per axis, spectrum |k|^beta with k in cycles per grid spacing, unit diagonal): `gsi_op_fft_powerlaw`.  Acts on
+`vec(field)`.  It is the covariance family FFTRF.powerlaw_structuredgrid samples from; it coincides with the
+covariance of those fields (up to the per-sample normalisation) only on power-of-two grids with equal axes --
+FFTRF embeds on exactly 2N points and uses integer wavenumbers (FFTRF.jl:83-90), see DESIGN.md section 4.6."
 function FFTPowerlawCovariance(Ns::Vector{Int}, beta::Float64; c::Context=ctx())
 	r = Ref{Ptr{Cvoid}}(C_NULL)
 	N64 = Int64.(Ns)
@@ -141,6 +146,133 @@ function Base.:*(A::DeviceOperator, X::Matrix{Float64})                         
 	check(ccall((:gsi_op_mul, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
 		A.c.h, A.h, 0, X, stride(X, 2), size(X, 2), Y, A.m))
 	return Y
+end
+
+"`adjoint(A) * X`  (RandMatFact.jl:67,85)"
+struct AdjointOperator
+	parent::DeviceOperator
+end
+Base.adjoint(A::DeviceOperator) = AdjointOperator(A)
+Base.transpose(A::DeviceOperator) = AdjointOperator(A)
+Base.size(A::AdjointOperator) = (A.parent.n, A.parent.m)
+function Base.:*(At::AdjointOperator, X::Matrix{Float64})
+	A = At.parent
+	Y = Matrix{Float64}(undef, A.n, size(X, 2))
+	check(ccall((:gsi_op_mul, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
+		A.c.h, A.h, 1, X, stride(X, 2), size(X, 2), Y, A.n))
+	return Y
+end
+Base.:*(A::DeviceOperator, x::Vector{Float64}) = vec(A * reshape(x, :, 1))            # lowrank.jl:135-139
+
+"`\\(A::LowRankCovMatrix, b::Vector)`  (lowrank.jl:141-144): lsqr(A, b; maxiter=length(A.samples)) on the device."
+function Base.:\(A::DeviceOperator, b::Vector{Float64})
+	x = Vector{Float64}(undef, A.n)
+	check(ccall((:gsi_op_lowrank_solve, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}),
+		A.c.h, A.h, b, x, C_NULL))
+	return x
+end
+
+# ---- device-resident matrices and the xi-basis (SURVEY.md 8b last row / 8f f1) -----------------------------
+mutable struct DeviceMatrix
+	h::Ptr{Cvoid}
+	c::Context
+	rows::Int
+	cols::Int
+	function DeviceMatrix(rows::Int, cols::Int; c::Context=ctx())
+		r = Ref{Ptr{Cvoid}}(C_NULL)
+		check(ccall((:gsi_mat_create, libgsi), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Int64, Int64), c.h, r, rows, cols))
+		m = new(r[], c, rows, cols)
+		finalizer(m) do x
+			x.h != C_NULL && ccall((:gsi_mat_destroy, libgsi), Cint, (Ptr{Cvoid},), x.h)
+			x.h = C_NULL
+		end
+		return m
+	end
+end
+function DeviceMatrix(A::Matrix{Float64}; c::Context=ctx())
+	m = DeviceMatrix(size(A, 1), size(A, 2); c=c)
+	check(ccall((:gsi_mat_upload, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64), c.h, m.h, A, stride(A, 2)))
+	return m
+end
+
+"The xi-basis resident in HBM: what `getxis_device` returns and what `pcgadirect` / `pcgalsqr` / `rga` accept in place
+of `xis::Array{Array{Float64,1},1}`.  `precision = 32` stores the K columns in fp32 (all sums in fp64)."
+mutable struct DeviceBasis
+	h::Ptr{Cvoid}
+	Z::DeviceMatrix            # kept alive: a 64-bit basis points into it
+	n::Int
+	K::Int
+	function DeviceBasis(Z::DeviceMatrix, K::Int; precision::Int=64)
+		r = Ref{Ptr{Cvoid}}(C_NULL)
+		check(ccall((:gsi_basis_create, libgsi), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int64, Cint),
+			Z.c.h, r, Z.h, K, precision))
+		b = new(r[], Z, Z.rows, K)
+		finalizer(b) do x
+			x.h != C_NULL && ccall((:gsi_basis_destroy, libgsi), Cint, (Ptr{Cvoid},), x.h)
+			x.h = C_NULL
+		end
+		return b
+	end
+end
+Base.length(b::DeviceBasis) = b.K
+function Base.getindex(b::DeviceBasis, i::Int)                                           # xis[i] on the host
+	x = Vector{Float64}(undef, b.n)
+	check(ccall((:gsi_basis_download_col, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}), b.Z.c.h, b.h, i - 1, x))
+	return x
+end
+"paramstorun as an n x (K+3) matrix: columns s + delta*xis[i], s + delta*X, s + delta*s, s   (direct.jl:39-45)"
+function paramstorun(b::DeviceBasis, s::Vector{Float64}, X::Vector{Float64}, delta::Float64)
+	P = Matrix{Float64}(undef, b.n, b.K + 3)
+	check(ccall((:gsi_pcga_params_basis, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Float64}),
+		b.Z.c.h, b.h, s, X, delta, P))
+	return P
+end
+"s = X*beta_bar + sum_i xis[i]*dot(etas[i], xi_bar)   (direct.jl:59-65, lsqr.jl:55-61)"
+function update(b::DeviceBasis, X::Vector{Float64}, beta_bar::Float64, etas::Matrix{Float64}, xi_bar::Vector{Float64})
+	s = Vector{Float64}(undef, b.n)
+	check(ccall((:gsi_pcga_update_basis, libgsi), Cint,
+		(Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Cdouble, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}),
+		b.Z.c.h, b.h, X, beta_bar, etas, size(etas, 1), xi_bar, s))
+	return s
+end
+
+"`PCGALowRankMatrix(etas, HX, R)` (lowrank.jl:32-36) resident on the device; `A * x` and `lsqr(A, b)` run there."
+mutable struct PCGALowRankMatrix
+	h::Ptr{Cvoid}
+	c::Context
+	nobs::Int
+	function PCGALowRankMatrix(etas::Matrix{Float64}, HX::Vector{Float64}, R::AbstractMatrix; c::Context=ctx())
+		nobs, K = size(etas)
+		isdiag = R == LinearAlgebra.Diagonal(LinearAlgebra.diag(R))
+		Rv = isdiag ? collect(Float64, LinearAlgebra.diag(R)) : vec(Matrix{Float64}(R))
+		r = Ref{Ptr{Cvoid}}(C_NULL)
+		check(ccall((:gsi_pcgamat_create, libgsi), Cint,
+			(Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Cint),
+			c.h, r, etas, nobs, K, HX, Rv, isdiag ? 1 : 0))
+		A = new(r[], c, nobs)
+		finalizer(A) do x
+			x.h != C_NULL && ccall((:gsi_pcgamat_destroy, libgsi), Cint, (Ptr{Cvoid},), x.h)
+			x.h = C_NULL
+		end
+		return A
+	end
+end
+Base.size(A::PCGALowRankMatrix) = (A.nobs + 1, A.nobs + 1)
+function Base.size(A::PCGALowRankMatrix, i::Int)
+	(i == 1 || i == 2) || error("there is no $i-th dimension in a PCGALowRankMatrix")     # lowrank.jl:71
+	return A.nobs + 1
+end
+function Base.:*(A::PCGALowRankMatrix, x::Vector{Float64})                                # lowrank.jl:83-97, 109-113
+	y = Vector{Float64}(undef, A.nobs + 1)
+	check(ccall((:gsi_pcgamat_mul, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), A.c.h, A.h, x, y))
+	return y
+end
+"`IterativeSolvers.lsqr(A, b)` with that package's defaults, on the device   (lsqr.jl:54)"
+function lsqr(A::PCGALowRankMatrix, b::Vector{Float64})
+	x = Vector{Float64}(undef, A.nobs + 1)
+	check(ccall((:gsi_pcgamat_lsqr, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}),
+		A.c.h, A.h, b, x, C_NULL))
+	return x
 end
 
 # ---- RandMatFact ------------------------------------------------------------------------------------
@@ -201,29 +333,77 @@ function randsvdwithseed(Q, numxis, p, q, seed::Int)
 	return RandMatFact.randsvd(Q, numxis, p, q)
 end
 
+# columns of Z as the reference's Vector{Vector{Float64}}
+xis_from(Z::Matrix{Float64}, numxis::Int) = [Z[:, i] for i in 1:numxis]
+
 function getxis(::Type{Val{:iwantfields}}, samplefield::Function, numfields::Int, numxis::Int, p::Int, q::Int=3, seed=nothing)
-	fields = Array{Float64, 1}[samplefield() for i = 1:numfields]                    # the reference uses RobustPmap.rpmap (:30)
-	lrcm = LowRankCovMatrix(fields)
-	Z = randsvdwithseed(lrcm, numxis, p, q, seed)
-	xis = Array{Array{Float64, 1}}(undef, numxis)
-	for i = 1:numxis
-		xis[i] = Z[:, i]
-	end
-	return xis, fields
+	# sampling fans out over the workers like the reference's RobustPmap.rpmap (GeostatInversion.jl:30)
+	fields = convert(Vector{Vector{Float64}}, Distributed.pmap(i->samplefield(), 1:numfields))
+	Z = randsvdwithseed(LowRankCovMatrix(fields), numxis, p, q, seed)                 # :31-32
+	return xis_from(Z, numxis), fields
 end
 
-function getxis(samplefield::Function, numfields::Int, numxis::Int, p::Int, q::Int=3, seed=nothing)
-	xis, _ = getxis(Val{:iwantfields}, samplefield, numfields, numxis, p, q, seed)
-	return xis
+getxis(samplefield::Function, numfields::Int, numxis::Int, p::Int, q::Int=3, seed=nothing) =
+	first(getxis(Val{:iwantfields}, samplefield, numfields, numxis, p, q, seed))      # :58-61
+
+getxis(Q::Matrix, numxis::Int, p::Int, q::Int=3, seed=nothing) =
+	xis_from(randsvdwithseed(convert(Matrix{Float64}, Q), numxis, p, q, seed), numxis)   # :63-70
+
+"`getxis` whose result stays in HBM: a `DeviceBasis` for the `pcgadirect` / `pcgalsqr` methods below."
+function getxis_device(A::DeviceOperator, numxis::Int, p::Int, q::Int=3, seed=nothing; precision::Int=64)
+	seed === nothing || Random.seed!(seed)
+	Omega = DeviceMatrix(randn(A.n, numxis + p); c=A.c)
+	Z = DeviceMatrix(A.n, numxis + p; c=A.c)
+	check(ccall((:gsi_randsvd_dev, libgsi), Cint,
+		(Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+		A.c.h, A.h, Omega.h, numxis, p, q, Z.h, C_NULL))
+	return DeviceBasis(Z, numxis; precision=precision)
 end
 
-function getxis(Q::Matrix, numxis::Int, p::Int, q::Int=3, seed=nothing)
-	xis = Array{Array{Float64, 1}}(undef, numxis)
-	Z = randsvdwithseed(convert(Matrix{Float64}, Q), numxis, p, q, seed)
-	for i = 1:numxis
-		xis[i] = Z[:, i]
-	end
-	return xis
+# ---- pcgadirect / pcgalsqr with a device-resident basis (same positional / keyword shape as direct.jl:21, lsqr.jl:20) ----
+function iterationhead(forwardmodel::Function, s::Vector, X::Vector, xis::DeviceBasis, delta)
+	K = length(xis)
+	P = paramstorun(xis, s, X, delta)                                                   # direct.jl:39-45
+	results = Distributed.pmap(i->forwardmodel(P[:, i]), 1:K + 3)                       # :46
+	hs = results[K + 3]
+	etas = hcat([(results[i] - hs) / delta for i in 1:K]...)                            # :49-50
+	HX = (results[K + 1] - hs) / delta
+	Hs = (results[K + 2] - hs) / delta
+	return etas, HX, Hs, hs
 end
+
+function pcgadirect(forwardmodel::Function, s0::Vector, X::Vector, xis::DeviceBasis, R, y::Vector;
+		maxiters::Int=5, delta::Float64=sqrt(eps(Float64)), xtol::Float64=1e-6, callback=(s, obs_cal)->nothing)
+	s, converged, iters = s0, false, 0
+	while !converged && iters < maxiters
+		etas, HX, Hs, hs = iterationhead(forwardmodel, s, X, xis, delta)
+		callback(s, hs)
+		bigA = [(etas * etas' + R) HX; transpose(HX) 0.0]                               # direct.jl:57
+		x = LinearAlgebra.pinv(Matrix(bigA)) * [y - hs + Hs; 0.0]                        # :56,58
+		snew = update(xis, X, x[end], etas, x[1:end - 1])                                # :59-65
+		converged = LinearAlgebra.norm(snew - s) < xtol
+		s = snew
+		iters += 1
+	end
+	return s
+end
+
+function pcgalsqr(forwardmodel::Function, s0::Vector, X::Vector, xis::DeviceBasis, R, y::Vector;
+		maxiters::Int=5, delta::Float64=sqrt(eps(Float64)), xtol::Float64=1e-6)
+	s, converged, iters = s0, false, 0
+	while !converged && iters < maxiters
+		etas, HX, Hs, hs = iterationhead(forwardmodel, s, X, xis, delta)
+		x = lsqr(PCGALowRankMatrix(etas, HX, R; c=xis.Z.c), [y - hs + Hs; 0.0])         # lsqr.jl:52-54
+		snew = update(xis, X, x[end], etas, x[1:end - 1])                                # :55-61
+		converged = LinearAlgebra.norm(snew - s) < xtol
+		s = snew
+		iters += 1
+	end
+	return s
+end
+
+"`rga(forwardmodel, s0, X, xis, R, y, S; ...)`  (GeostatInversion.jl:101-103)"
+rga(forwardmodel::Function, s0::Vector, X::Vector, xis::DeviceBasis, R, y::Vector, S; pcgafunc=pcgadirect, kwargs...) =
+	pcgafunc(x->S * forwardmodel(x), s0, X, xis, S * R * S', S * y; kwargs...)
 
 end # module
