@@ -180,14 +180,19 @@ def gridcov_implicit_operator(ctx, nx, ny, ell):
     return Operator(ctx, h)
 
 
-def fft_powerlaw_operator(ctx, Ns, beta):
-    """Matrix-free covariance of FFTRF-style power-law fields on a structured grid (circulant embedding, spectrum
-    |k|^beta, unit diagonal): `gsi_op_fft_powerlaw`.  `Ns` = grid points per axis (1 to 3 axes); the operator acts on
-    vec(field) in Julia's (column-major) order."""
+def fft_powerlaw_operator(ctx, Ns, beta, fftrf=False):
+    """Matrix-free power-law covariance on a structured grid (circulant embedding, spectrum |k|^beta, unit diagonal).
+    `Ns` = grid points per axis (1 to 3 axes); the operator acts on vec(field) in Julia's (column-major) order.
+    `fftrf=False` (`gsi_op_fft_powerlaw`): embedding on the next power of two >= 2N, |k| in cycles per grid spacing --
+    the covariance family FFTRF samples from, for any grid.  `fftrf=True` (`gsi_op_fft_powerlaw_fftrf`): FFTRF.jl's own
+    convention (exactly 2N points per axis, integer wavenumbers, FFTRF.jl:83-90) = the covariance of
+    `powerlaw_structuredgrid(Ns, k0, dk, beta)` fields up to dk^2 and the per-sample normalisation; power-of-two grids
+    only."""
     Ns = [int(v) for v in Ns]
     arr = (C.c_int64 * len(Ns))(*Ns)
     h = C.c_void_p()
-    L.check(ctx.lib.gsi_op_fft_powerlaw(ctx.h, C.byref(h), len(Ns), arr, float(beta)), ctx.lib)
+    fn = ctx.lib.gsi_op_fft_powerlaw_fftrf if fftrf else ctx.lib.gsi_op_fft_powerlaw
+    L.check(fn(ctx.h, C.byref(h), len(Ns), arr, float(beta)), ctx.lib)
     return Operator(ctx, h)
 
 

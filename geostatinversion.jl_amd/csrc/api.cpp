@@ -232,26 +232,32 @@ int gsi_op_gridcov_implicit(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, d
   });
 }
 
+static void make_fft_powerlaw(gsi_ctx* ctx, gsi_op** op, int ndims, const int64_t* N, double beta, int fftrf) {
+  REQUIRE(ctx && op && N, "NULL argument");
+  *op = nullptr;
+  REQUIRE(ndims >= 1 && ndims <= 3, "fft covariance: 1, 2 or 3 grid dimensions");
+  REQUIRE(ctx->c.nranks() == 1, "fft covariance operator: single rank only (the transform needs whole columns)");
+  int64_t N3[3] = {1, 1, 1};
+  int64_t n = 1;
+  for (int a = 0; a < ndims; ++a) {
+    REQUIRE(N[a] >= 1, "fft covariance: grid dimensions must be >= 1");
+    N3[a] = N[a];
+    n *= N[a];
+  }
+  REQUIRE(n >= 2, "fft covariance: need at least two grid points");
+  std::unique_ptr<gsi_op> o(new gsi_op());
+  Operator& A = o->op;
+  A.ctx = &ctx->c; A.kind = OP_FFT_COV; A.m = n; A.n = n; A.row0 = 0; A.mloc = n; A.ld = 0;
+  A.plan = ctx->c.be->fftcov_create(N3, beta, fftrf);
+  *op = o.release();
+}
+
 int gsi_op_fft_powerlaw(gsi_ctx* ctx, gsi_op** op, int ndims, const int64_t* N, double beta) {
-  return guarded([&] {
-    REQUIRE(ctx && op && N, "NULL argument");
-    *op = nullptr;
-    REQUIRE(ndims >= 1 && ndims <= 3, "fft covariance: 1, 2 or 3 grid dimensions");
-    REQUIRE(ctx->c.nranks() == 1, "fft covariance operator: single rank only (the transform needs whole columns)");
-    int64_t N3[3] = {1, 1, 1};
-    int64_t n = 1;
-    for (int a = 0; a < ndims; ++a) {
-      REQUIRE(N[a] >= 1, "fft covariance: grid dimensions must be >= 1");
-      N3[a] = N[a];
-      n *= N[a];
-    }
-    REQUIRE(n >= 2, "fft covariance: need at least two grid points");
-    std::unique_ptr<gsi_op> o(new gsi_op());
-    Operator& A = o->op;
-    A.ctx = &ctx->c; A.kind = OP_FFT_COV; A.m = n; A.n = n; A.row0 = 0; A.mloc = n; A.ld = 0;
-    A.plan = ctx->c.be->fftcov_create(N3, beta);
-    *op = o.release();
-  });
+  return guarded([&] { make_fft_powerlaw(ctx, op, ndims, N, beta, 0); });
+}
+
+int gsi_op_fft_powerlaw_fftrf(gsi_ctx* ctx, gsi_op** op, int ndims, const int64_t* N, double beta) {
+  return guarded([&] { make_fft_powerlaw(ctx, op, ndims, N, beta, 1); });
 }
 
 int gsi_op_destroy(gsi_op* op) {

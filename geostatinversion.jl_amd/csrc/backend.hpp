@@ -56,7 +56,8 @@ class Backend {
 
   // Matrix-free stationary covariance on an N[0] x N[1] x N[2] grid (column-major point index) by circulant
   // embedding: A = R F^-1 diag(lambda) F R', lambda(k) = |k|^beta, unit diagonal (fft_cov.hip).  Opaque plan.
-  virtual void* fftcov_create(const int64_t N[3], double beta) = 0;
+  // fftrf != 0: FFTRF.jl's own convention -- embedding of exactly 2 N[a] points, integer wavenumbers (FFTRF.jl:83-90)
+  virtual void* fftcov_create(const int64_t N[3], double beta, int fftrf) = 0;
   virtual void fftcov_destroy(void* plan) = 0;
   // Y (n x l, ld ldy) = A X (n x l, ld ldx)
   virtual void fftcov_apply(void* plan, int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy) = 0;

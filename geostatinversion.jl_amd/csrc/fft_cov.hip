@@ -158,14 +158,16 @@ __global__ __launch_bounds__(1024) void fft_pass_kernel(double2* __restrict__ W,
   }
 }
 
-// lam[e] = (sum_i (f_i / M_i)^2)^(beta/2), f_i = min(k_i, M_i - k_i); lam[0] = 0
+// lam[e] = (sum_i nu_i^2)^(beta/2), f_i = min(k_i, M_i - k_i), lam[0] = 0.
+// fftrf == 0: nu_i = f_i / M_i (cycles per grid spacing: the correlation length does not depend on the embedding);
+// fftrf != 0: nu_i = f_i, the INTEGER wavenumbers FFTRF.jl:86-89 + computesqrtS_f (:40-72) use on its 2N embedding.
 __global__ __launch_bounds__(256) void fft_spectrum_kernel(double* __restrict__ lam, int64_t Mtot, int64_t M0, int64_t M1,
-                                                           int64_t M2, double beta) {
+                                                           int64_t M2, double beta, int fftrf) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < Mtot; e += (int64_t)gridDim.x * 256) {
     const int64_t k0 = e % M0, r = e / M0, k1 = r % M1, k2 = r / M1;
-    const double f0 = (double)((k0 <= M0 - k0) ? k0 : M0 - k0) / (double)M0;
-    const double f1 = (double)((k1 <= M1 - k1) ? k1 : M1 - k1) / (double)M1;
-    const double f2 = (double)((k2 <= M2 - k2) ? k2 : M2 - k2) / (double)M2;
+    const double f0 = (double)((k0 <= M0 - k0) ? k0 : M0 - k0) / (fftrf ? 1.0 : (double)M0);
+    const double f1 = (double)((k1 <= M1 - k1) ? k1 : M1 - k1) / (fftrf ? 1.0 : (double)M1);
+    const double f2 = (double)((k2 <= M2 - k2) ? k2 : M2 - k2) / (fftrf ? 1.0 : (double)M2);
     const double k2sum = f0 * f0 + f1 * f1 + f2 * f2;
     lam[e] = (k2sum > 0.0) ? pow(k2sum, 0.5 * beta) : 0.0;
   }
@@ -215,10 +217,10 @@ __global__ __launch_bounds__(256) void fft_twiddle_kernel(double2* __restrict__ 
 // lam layout: [Mtot spectrum | 64 scratch | FFT_TW_LEN doubles of twiddles]
 size_t fft_plan_doubles(const int64_t M[3]) { return (size_t)(M[0] * M[1] * M[2]) + 64 + FFT_TW_LEN; }
 
-void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3], double beta) {
+void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3], double beta, int fftrf) {
   const int64_t Mtot = M[0] * M[1] * M[2];
   hipLaunchKernelGGL(fft_twiddle_kernel, dim3(FFT_TW_LEN / 2 / 256), dim3(256), 0, st, reinterpret_cast<double2*>(lam + Mtot + 64));
-  hipLaunchKernelGGL(fft_spectrum_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, M[0], M[1], M[2], beta);
+  hipLaunchKernelGGL(fft_spectrum_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, M[0], M[1], M[2], beta, fftrf);
   hipLaunchKernelGGL(fft_sum_kernel, dim3(64), dim3(256), 0, st, lam, Mtot, part64);
   hipLaunchKernelGGL(fft_normalise_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, part64, 64);
 }

@@ -202,7 +202,7 @@ class HipBackend : public Backend {
 
   // ---- matrix-free FFT covariance ----
   struct FftCov { int64_t N[3], M[3]; double* lam; double* W; int nb_max; };
-  void* fftcov_create(const int64_t N[3], double beta) override {
+  void* fftcov_create(const int64_t N[3], double beta, int fftrf) override {
     bind();
     std::unique_ptr<FftCov> p(new FftCov());
     int64_t Mtot = 1;
@@ -212,6 +212,9 @@ class HipBackend : public Backend {
       if (N[a] < 1) throw Error(GSI_ERR_ARG, "fft covariance: grid dimensions must be >= 1");
       if (N[a] == 1) continue;
       p->N[d] = N[a]; p->M[d] = hipk::fft_embed_size(N[a]);
+      if (fftrf && p->M[d] != 2 * N[a])
+        throw Error(GSI_ERR_ARG, "FFTRF-convention covariance: the embedding is exactly 2 N per axis and the LDS transforms "
+                                 "are radix-2/4 -- every grid dimension must be a power of two");
       if (p->M[d] > 4096) throw Error(GSI_ERR_ARG, "fft covariance: at most 2048 grid points per axis (a line must fit LDS)");
       Mtot *= p->M[d];
       ++d;
@@ -221,7 +224,7 @@ class HipBackend : public Backend {
     p->nb_max = (int)std::max<int64_t>(1, std::min<int64_t>(nb, 64));
     p->lam = alloc(hipk::fft_plan_doubles(p->M));
     try { p->W = alloc((size_t)2 * Mtot * p->nb_max); } catch (...) { release(p->lam); throw; }
-    hipk::fft_spectrum(st_, p->lam, p->lam + Mtot, p->M, beta);
+    hipk::fft_spectrum(st_, p->lam, p->lam + Mtot, p->M, beta, fftrf);
     check_launch("fft_spectrum");
     return p.release();
   }

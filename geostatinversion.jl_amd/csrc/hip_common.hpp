@@ -35,7 +35,7 @@ void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const dou
 int64_t fft_embed_size(int64_t N);   // next power of two >= 2 N (1 for a singleton axis)
 size_t fft_plan_doubles(const int64_t M[3]);   // spectrum + scratch + twiddle table
 // lam (fft_plan_doubles) <- |k|^beta / sum, scratch part64 = lam + Mtot, twiddles behind it
-void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3], double beta);
+void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3], double beta, int fftrf);
 void fft_cov_apply(hipStream_t st, const int64_t N[3], const int64_t M[3], const double* lam, double2* W, int nb_max,
                    int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy);
 

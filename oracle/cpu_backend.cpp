@@ -107,13 +107,14 @@ class CpuBackend : public Backend {
         for (int64_t k = 0; k < Ma; ++k) w[(size_t)(i + es * k + os * o)] = out[(size_t)k];
       }
   }
-  void* fftcov_create(const int64_t N[3], double beta) override {
+  void* fftcov_create(const int64_t N[3], double beta, int fftrf) override {
     FftCov* p = new FftCov();
     int64_t Mtot = 1;
     for (int a = 0; a < 3; ++a) {
       p->N[a] = N[a];
       int64_t m = 1;
       while (m < 2 * N[a]) m <<= 1;
+      if (fftrf) m = 2 * N[a];           // FFTRF's own embedding; the naive DFT here takes any length
       p->M[a] = (N[a] == 1) ? 1 : m;
       Mtot *= p->M[a];
     }
@@ -124,7 +125,7 @@ class CpuBackend : public Backend {
       const int64_t kk[3] = {k0, k1, k2};
       double s = 0.0;
       for (int a = 0; a < 3; ++a) {
-        const double f = (double)std::min(kk[a], p->M[a] - kk[a]) / (double)p->M[a];
+        const double f = (double)std::min(kk[a], p->M[a] - kk[a]) / (fftrf ? 1.0 : (double)p->M[a]);
         s += f * f;
       }
       p->lam[(size_t)e] = s > 0.0 ? std::pow(s, 0.5 * beta) : 0.0;

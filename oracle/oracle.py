@@ -489,16 +489,21 @@ def xis_error_up_to_sign(Z1: np.ndarray, Z2: np.ndarray, K: int) -> float:
 
 
 # ---- f2: matrix-free circulant-embedding covariance (not in the reference as an operator) --------------------
-def fft_powerlaw_spectrum(Ns, beta):
-    """lambda on the power-of-two embedding grid (shape M_1 x ... x M_d, Fortran order of the flattened operator):
-    (sum_a (f_a / M_a)^2)^(beta/2), f_a = min(k_a, M_a - k_a), lambda(0) = 0; normalised to mean 1 so that
-    the circulant F^-1 diag(lambda) F has a unit diagonal.  Same power law as FFTRF.jl:58-66 (`S_f ^ (.25*beta)` is
-    the square root of it)."""
-    Ms = [1 if N == 1 else 1 << int(np.ceil(np.log2(2 * N))) for N in Ns]
+def fft_powerlaw_spectrum(Ns, beta, fftrf=False):
+    """lambda on the embedding grid (shape M_1 x ... x M_d, Fortran order of the flattened operator):
+    (sum_a nu_a^2)^(beta/2), f_a = min(k_a, M_a - k_a), lambda(0) = 0; normalised to mean 1 so that the circulant
+    F^-1 diag(lambda) F has a unit diagonal.
+    fftrf=False: M_a = next power of two >= 2 N_a, nu_a = f_a / M_a (cycles per grid spacing).
+    fftrf=True : FFTRF.jl's convention -- M_a = 2 N_a exactly, nu_a = f_a the integer wavenumbers
+    0..N_a, -(N_a-1)..-1 (FFTRF.jl:86-89); `S_f ^ (.25*beta)` at FFTRF.jl:62 is the square root of this lambda."""
+    if fftrf:
+        Ms = [1 if N == 1 else 2 * N for N in Ns]
+    else:
+        Ms = [1 if N == 1 else 1 << int(np.ceil(np.log2(2 * N))) for N in Ns]
     k2 = np.zeros(Ms)
     for a, M in enumerate(Ms):
         k = np.arange(M)
-        f = np.minimum(k, M - k) / M
+        f = np.minimum(k, M - k) / (1.0 if fftrf else M)
         shape = [1] * len(Ms)
         shape[a] = M
         k2 = k2 + (f ** 2).reshape(shape)
@@ -508,13 +513,13 @@ def fft_powerlaw_spectrum(Ns, beta):
     return lam / lam.mean(), Ms
 
 
-def fft_powerlaw_apply(X, Ns, beta):
+def fft_powerlaw_apply(X, Ns, beta, fftrf=False):
     """A X for A = R F^-1 diag(lambda) F R' (zero padding R' of the N-grid into the embedding grid), columns of X =
     vec(field) in column-major (Julia) order."""
     X = np.asarray(X, dtype=np.float64)
     if X.ndim == 1:
         X = X[:, None]
-    lam, Ms = fft_powerlaw_spectrum(Ns, beta)
+    lam, Ms = fft_powerlaw_spectrum(Ns, beta, fftrf)
     out = np.empty_like(X)
     box = tuple(slice(0, N) for N in Ns)
     for c in range(X.shape[1]):
@@ -523,3 +528,40 @@ def fft_powerlaw_apply(X, Ns, beta):
         y = np.fft.ifftn(lam * np.fft.fftn(w)).real
         out[:, c] = y[box].reshape(-1, order="F")
     return out
+
+
+# ---- FFTRF.jl:8-100 restated (TEST INFRASTRUCTURE: FFTRF stays on the Julia/CPU side, BASELINE.json north_star; this
+#      exists only so that a test can check which covariance its fields have) ------------------------------------------
+def fftrf_powerlaw_structuredgrid(Ns, k0, dk, beta, rng, raw=False):
+    """``powerlaw_structuredgrid(Ns, k0, dk, beta)``  (FFTRF.jl:83-100) for 2-D and 3-D grids.
+
+    Returns the N_1 x N_2 (x N_3) array ``finalk``; ``raw=True`` returns it before the per-sample normalisation of
+    FFTRF.jl:94-98 (the quantity whose covariance is the circulant-embedding operator).  ``rng.standard_normal``
+    stands for Julia's ``randn`` in ``mulbyphi`` (FFTRF.jl:74-81)."""
+    Ns = [int(v) for v in Ns]
+    d = len(Ns)
+    if d not in (2, 3):
+        raise ValueError(f"unsupported dimension: {d}")                     # FFTRF.jl:58
+    M = [2 * N for N in Ns]                                                   # :85
+    coords = [np.concatenate([np.arange(0, N + 1), -np.arange(N - 1, 0, -1)]).astype(float) for N in Ns]   # :86-89
+    # computesqrtS_f (:40-72): the array is (M_2, M_1[, M_3]); its FIRST axis runs over coordinate 2
+    if d == 2:
+        S = coords[1][:, None] ** 2 + coords[0][None, :] ** 2
+    else:
+        S = coords[1][:, None, None] ** 2 + coords[0][None, :, None] ** 2 + coords[2][None, None, :] ** 2
+    with np.errstate(divide="ignore"):
+        sqrtS = S ** (0.25 * beta)                                            # :62
+    sqrtS[np.isinf(sqrtS)] = 0.0                                              # :63-65
+    phi = rng.standard_normal(sqrtS.shape)                                    # mulbyphi :75
+    result = sqrtS * (np.cos(2 * np.pi * phi) + 1j * np.sin(2 * np.pi * phi))   # :78 (cospi, sinpi)
+    kcomplex = np.fft.ifftn(result)                                           # :92
+    # reducek (:8-38): keep the first half along every axis, real part, axes 1 and 2 swapped back
+    if d == 2:
+        finalk = kcomplex[:Ns[1], :Ns[0]].real.T.copy()                       # finalk[j, i] = real(k[i, j])
+    else:
+        finalk = np.transpose(kcomplex[:Ns[1], :Ns[0], :Ns[2]].real, (1, 0, 2)).copy()
+    if raw:
+        return finalk
+    std = finalk.std(ddof=1)                                                  # Statistics.std: corrected  :94
+    mean = finalk.mean()                                                      # :95
+    return dk * (finalk - mean) / std + k0                                    # :96-98

@@ -769,3 +769,24 @@ def test_pcgalsqr_c5_fp32_vs_fp64(gsi, ctx):
     assert np.linalg.norm(s32 - s64) < 1e-5 * np.linalg.norm(s64)    # stated fp32-vs-fp64 tolerance
     assert np.linalg.norm(s64 - truth) < 0.2 * np.linalg.norm(truth - X)   # and recover the observed part of the field
     b32.close(); b64.close(); Z.close()
+
+
+# ---- f2 in FFTRF's own convention (2N embedding, integer wavenumbers: the covariance of FFTRF's fields, see
+#      tests/test_fftrf_covariance.py for the statistical tie to the restated FFTRF.jl) -------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ns,beta,l", [((64,), -2.0, 5), ((32, 8), -3.5, 9), ((16, 64), -2.5, 33), ((8, 4, 16), -3.0, 6),
+                                       ((256, 128), -3.5, 16)])
+def test_fft_powerlaw_fftrf_convention(gsi, ctx, Ns, beta, l):
+    n = int(np.prod(Ns))
+    rng = np.random.default_rng(n + l)
+    X = rng.standard_normal((n, l))
+    op = gsi.fft_powerlaw_operator(ctx, Ns, beta, fftrf=True)
+    Y = op.matmul(X)
+    Yref = orc.fft_powerlaw_apply(X, list(Ns), beta, fftrf=True)
+    assert np.abs(Y - Yref).max() < 1e-11 * np.abs(Yref).max()
+    Yiso = orc.fft_powerlaw_apply(X, list(Ns), beta, fftrf=False)
+    if len(set(Ns)) > 1:
+        assert np.abs(Yiso - Yref).max() > 1e-3 * np.abs(Yref).max()       # a different operator on unequal axes
+    op.close()
+    with pytest.raises(gsi.GsiError):
+        gsi.fft_powerlaw_operator(ctx, [24, 16], beta, fftrf=True)           # 2N embedding needs power-of-two axes here
