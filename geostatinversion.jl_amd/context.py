@@ -171,12 +171,22 @@ def lowrank_synthetic_operator(ctx, n, N, seed=0, decay=0.75):
     return Operator(ctx, h)
 
 
-def gridcov_implicit_operator(ctx, nx, ny, ell):
-    """The Gaussian grid covariance of `gridcov_operator(kind=0)` as an implicit operator: entries are
-    regenerated inside the product kernel, nothing of size n^2 is stored."""
+def gridcov_implicit_operator(ctx, nx, ny, ell, kind=0, table=None):
+    """A stationary grid covariance as an implicit operator: entries are regenerated inside the product kernel, nothing of
+    size n^2 is stored.  kind 0: Gaussian exp(-d^2/(2 ell^2)) (two 1-D tables); kind 1:
+    exponential exp(-d/ell) (a 2-D table over grid offsets); `table` (nx x ny array, table[dx, dy] = k(dx, dy)): any
+    stationary kernel on the grid."""
     row0, mloc = ctx.shard(nx * ny)
     h = C.c_void_p()
-    L.check(ctx.lib.gsi_op_gridcov_implicit(ctx.h, C.byref(h), nx, ny, float(ell), row0, mloc), ctx.lib)
+    if table is not None:
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        if t.shape != (nx, ny):
+            raise ValueError("table must be nx x ny")
+        L.check(ctx.lib.gsi_op_gridcov_implicit_table(ctx.h, C.byref(h), nx, ny, t.ctypes.data_as(L.c_dp), row0, mloc),
+                ctx.lib)
+    else:
+        L.check(ctx.lib.gsi_op_gridcov_implicit_kind(ctx.h, C.byref(h), nx, ny, float(ell), int(kind), row0, mloc),
+                ctx.lib)
     return Operator(ctx, h)
 
 

@@ -210,25 +210,56 @@ int gsi_op_dense_gridcov(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, doub
   });
 }
 
-int gsi_op_gridcov_implicit(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, double ell, int64_t row0,
-                            int64_t m_local) {
+// table[dx * ny + dy] = k(dx, dy): any stationary kernel on the regular grid
+static void make_gridcov_table(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, const double* table, int64_t row0,
+                               int64_t m_local) {
+  REQUIRE(nx >= 1 && ny >= 1, "bad grid");
+  REQUIRE(nx * ny < ((int64_t)1 << 31), "implicit grid covariance: more than 2^31 points");
+  const int64_t n = nx * ny;
+  check_shard(ctx->c, n, row0, m_local);
+  std::unique_ptr<gsi_op> o(new gsi_op());
+  Operator& A = o->op;
+  A.ctx = &ctx->c; A.kind = OP_GRIDCOV_IMPLICIT; A.m = n; A.n = n; A.row0 = row0; A.mloc = m_local;
+  A.gx = nx; A.gy = ny; A.ld = 0;
+  A.data = Buf(ctx->c.be.get(), (size_t)n);
+  ctx->c.be->upload2d(A.data.p, n, table, n, n, 1);
+  *op = o.release();
+}
+
+int gsi_op_gridcov_implicit_kind(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, double ell, int kind, int64_t row0,
+                                 int64_t m_local) {
   return guarded([&] {
     REQUIRE(ctx && op, "NULL argument");
     *op = nullptr;
-    REQUIRE(nx >= 1 && ny >= 1 && ell > 0, "bad grid covariance parameters");
-    REQUIRE(nx * ny < ((int64_t)1 << 31), "implicit grid covariance: more than 2^31 points");
-    const int64_t n = nx * ny;
-    check_shard(ctx->c, n, row0, m_local);
-    std::unique_ptr<gsi_op> o(new gsi_op());
-    Operator& A = o->op;
-    A.ctx = &ctx->c; A.kind = OP_GRIDCOV_IMPLICIT; A.m = n; A.n = n; A.row0 = row0; A.mloc = m_local;
-    A.gx = nx; A.gy = ny; A.ld = 0;
-    std::vector<double> tab((size_t)(nx + ny));
-    for (int64_t d = 0; d < nx; ++d) tab[(size_t)d] = std::exp(-(double)(d * d) / (2.0 * ell * ell));
-    for (int64_t d = 0; d < ny; ++d) tab[(size_t)(nx + d)] = std::exp(-(double)(d * d) / (2.0 * ell * ell));
-    A.data = Buf(ctx->c.be.get(), tab.size());
-    ctx->c.be->upload2d(A.data.p, (int64_t)tab.size(), tab.data(), (int64_t)tab.size(), (int64_t)tab.size(), 1);
-    *op = o.release();
+    REQUIRE(nx >= 1 && ny >= 1 && ell > 0 && (kind == 0 || kind == 1),
+            "bad grid covariance parameters (kind 0: Gaussian, 1: exponential)");
+    std::vector<double> tab((size_t)(nx * ny));
+    if (kind == 0) {     // exp(-(dx^2 + dy^2) / (2 ell^2)) as the product of its two 1-D factors
+      std::vector<double> ex((size_t)nx), ey((size_t)ny);
+      for (int64_t d = 0; d < nx; ++d) ex[(size_t)d] = std::exp(-(double)(d * d) / (2.0 * ell * ell));
+      for (int64_t d = 0; d < ny; ++d) ey[(size_t)d] = std::exp(-(double)(d * d) / (2.0 * ell * ell));
+      for (int64_t dx = 0; dx < nx; ++dx)
+        for (int64_t dy = 0; dy < ny; ++dy) tab[(size_t)(dx * ny + dy)] = ex[(size_t)dx] * ey[(size_t)dy];
+    } else {
+      for (int64_t dx = 0; dx < nx; ++dx)
+        for (int64_t dy = 0; dy < ny; ++dy)
+          tab[(size_t)(dx * ny + dy)] = std::exp(-std::sqrt((double)(dx * dx + dy * dy)) / ell);
+    }
+    make_gridcov_table(ctx, op, nx, ny, tab.data(), row0, m_local);
+  });
+}
+
+int gsi_op_gridcov_implicit(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, double ell, int64_t row0,
+                            int64_t m_local) {
+  return gsi_op_gridcov_implicit_kind(ctx, op, nx, ny, ell, 0, row0, m_local);
+}
+
+int gsi_op_gridcov_implicit_table(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, const double* table, int64_t row0,
+                                  int64_t m_local) {
+  return guarded([&] {
+    REQUIRE(ctx && op && table, "NULL argument");
+    *op = nullptr;
+    make_gridcov_table(ctx, op, nx, ny, table, row0, m_local);
   });
 }
 

@@ -47,9 +47,9 @@ class Backend {
   virtual void gemm_tn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc) = 0;
 
-  // C(m x l) = G * B(k x l) for the separable grid covariance G(i, j) = ex[|x_i - x_j|] * ey[|y_i - y_j|],
-  // grid point i = (i / ny, i % ny), rows roff.., reduction indices koff..; tab = [ex (nx) | ey (ny)].
-  // G is generated, never stored (the "implicit" operator).
+  // C(m x l) = G * B(k x l) for a stationary grid covariance G(i, j) = tab[|x_i - x_j| * ny + |y_i - y_j|],
+  // grid point i = (i / ny, i % ny), rows roff.., reduction indices koff..; tab = the nx * ny table of the kernel over
+  // grid offsets.  G is generated, never stored (the "implicit" operator).
   virtual void gemm_nn_gridcov(int64_t m, int64_t l, int64_t k, const double* tab, int64_t nx, int64_t ny,
                                int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
                                int64_t ldc) = 0;

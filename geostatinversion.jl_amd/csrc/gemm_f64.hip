@@ -62,13 +62,15 @@ constexpr int KSTEP_NN = 2 * NTHREADS / BMT;          // NN A tile: k advance pe
 constexpr int RSTEP = 2 * NTHREADS / BK;              // TN A tile / B tile: row (column) advance per pair slot
 static_assert(A_PAIRS * 2 * NTHREADS == BMT * BK, "tile does not divide over the threads");
 
-// GEN: the big operand is never stored.  A(i, j) = ex[|x_i - x_j|] * ey[|y_i - y_j|] for grid points
-// i = (i / ny, i % ny) (a separable stationary covariance, SURVEY.md 8d "implicit" configuration); the
-// staging registers are filled from the two L1-resident tables instead of from HBM, everything after
-// that (LDS images, fragments, MFMAs) is the stored-operand kernel unchanged.
+// GEN: the big operand is never stored.  A(i, j) = t2[|x_i - x_j| * ny + |y_i - y_j|] for grid points
+// i = (i / ny, i % ny): any stationary covariance on a regular grid (SURVEY.md 8d "implicit" configuration), given as
+// the nx * ny table of the kernel over grid offsets.  The staging registers are filled from the table instead of from
+// HBM, everything after that (LDS images, fragments, MFMAs) is the stored-operand kernel unchanged.  Consecutive rows
+// and consecutive reduction indices are consecutive y, so a tile touches one or two contiguous runs of a table row:
+// the lookups are L1 hits.  (A first version kept separable kernels as two 1-D tables and multiplied; one 2-D lookup
+// covers the non-separable kernels too -- exponential, Matern -- and costs one load instead of two and a multiply.)
 struct GenA {
-  const double* ex;   // nx entries
-  const double* ey;   // ny entries
+  const double* t2;   // nx * ny entries
   int32_t ny;
   int32_t pad_;
   int64_t roff;       // global index of row 0 of the product
@@ -182,11 +184,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
         g_ky += KSTEP_NN;
         while (g_ky >= gen.ny) { g_ky -= gen.ny; ++g_kx; }
       };
+      auto entry = [&](int gx, int gy) -> double { return gen.t2[abs(gx - g_kx) * gen.ny + abs(gy - g_ky)]; };
       if (r0 + BMT <= M && k0 + BK <= kend) {      // interior: no predicates (workgroup-uniform branch)
 #pragma unroll
         for (int it = 0; it < A_PAIRS; ++it) {
-          a_reg[set][it].x = gen.ex[abs(g_x0 - g_kx)] * gen.ey[abs(g_y0 - g_ky)];
-          a_reg[set][it].y = gen.ex[abs(g_x1 - g_kx)] * gen.ey[abs(g_y1 - g_ky)];
+          a_reg[set][it].x = entry(g_x0, g_y0);
+          a_reg[set][it].y = entry(g_x1, g_y1);
           advance();
         }
       } else {
@@ -194,8 +197,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 #pragma unroll
         for (int it = 0; it < A_PAIRS; ++it) {
           const bool okk = kfirst + KSTEP_NN * it < kend;   // uniform
-          a_reg[set][it].x = (okk && ok_r0) ? gen.ex[abs(g_x0 - g_kx)] * gen.ey[abs(g_y0 - g_ky)] : 0.0;
-          a_reg[set][it].y = (okk && ok_r1) ? gen.ex[abs(g_x1 - g_kx)] * gen.ey[abs(g_y1 - g_ky)] : 0.0;
+          a_reg[set][it].x = (okk && ok_r0) ? entry(g_x0, g_y0) : 0.0;
+          a_reg[set][it].y = (okk && ok_r1) ? entry(g_x1, g_y1) : 0.0;
           advance();
         }
       }
@@ -523,7 +526,7 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   const bool irregular_x = a_ok && (!b_ok || L % ((int64_t)nt * 16) != 0);
   const int wide = a_ok ? 1 : 0;
   const int xmode = big ? 2 : (irregular_x ? 1 : 0);
-  const GenA none = {nullptr, nullptr, 1, 0, 0, 0};
+  const GenA none = {nullptr, 1, 0, 0, 0};
   if (gen != nullptr)
     launch_dispatch<false, true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, *gen);
   else if (transA)
@@ -558,11 +561,12 @@ void gemm_f64_trmm_upper(hipStream_t st, int64_t M, int64_t L, int64_t K, const 
   gemm_launch(st, false, nullptr, M, L, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, ws, 2);
 }
 
-// C (M x L) = G * B with G(i, k) = ex[|x_i - x_k|] ey[|y_i - y_k|], i = roff + row, k = koff + reduction index;
-// tab = [ex (nx) | ey (ny)] in device memory.  The operand G is generated in registers, never stored.
+// C (M x L) = G * B with G(i, k) = tab[|x_i - x_k| * ny + |y_i - y_k|], i = roff + row, k = koff + reduction index;
+// tab = the nx * ny kernel table in device memory.  The operand G is generated in registers, never stored.
 void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* tab, int64_t nx, int64_t ny,
                       int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws) {
-  GenA g = {tab, tab + nx, (int32_t)ny, 0, roff, koff};
+  (void)nx;
+  GenA g = {tab, (int32_t)ny, 0, roff, koff};
   // A / lda only feed the 16-byte-load test for the stored operand: pass aligned dummies
   gemm_launch(st, false, &g, M, L, K, 1.0, nullptr, 2, B, ldb, 0.0, C, ldc, ws);
 }

@@ -27,7 +27,7 @@ void gemm_f64_syrk_upper(hipStream_t st, int64_t l, int64_t m, const double* A, 
                          double* ws);
 void gemm_f64_trmm_upper(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A, int64_t lda, const double* B,
                          int64_t ldb, double* C, int64_t ldc, double* ws);
-// C = G * B, G(i,k) = ex[|x_i-x_k|] ey[|y_i-y_k|] generated in registers (tab = [ex(nx) | ey(ny)])
+// C = G * B, G(i,k) = tab[|x_i-x_k| * ny + |y_i-y_k|] generated in registers (tab: nx * ny kernel table)
 void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* tab, int64_t nx, int64_t ny,
                       int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws);
 

@@ -44,7 +44,7 @@ struct Operator {
   Buf data;        // dense: mloc x n (ld mloc).  lowrank: samples shard mloc x N (ld mloc)
   int64_t ld = 0;
   int64_t N = 0;   // lowrank: number of samples
-  int64_t gx = 0, gy = 0;   // implicit grid covariance: data = [ex (gx) | ey (gy)], the operator is never stored
+  int64_t gx = 0, gy = 0;   // implicit grid covariance: data = the gx * gy table of the kernel over grid offsets; never stored
   void* plan = nullptr;     // OP_FFT_COV: the backend's circulant-embedding plan (owned; single rank)
   Operator() = default;
   Operator(const Operator&) = delete;

@@ -74,14 +74,14 @@ class CpuBackend : public Backend {
   }
   void gemm_nn_gridcov(int64_t m, int64_t l, int64_t k, const double* tab, int64_t nx, int64_t ny, int64_t roff,
                        int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc) override {
-    const double* ex = tab; const double* ey = tab + nx;
+    (void)nx;
     for (int64_t c = 0; c < l; ++c)
       for (int64_t r = 0; r < m; ++r) {
         const int64_t gi = roff + r;
         double s = 0.0;
         for (int64_t kk = 0; kk < k; ++kk) {
           const int64_t gj = koff + kk;
-          s += ex[std::llabs(gi / ny - gj / ny)] * ey[std::llabs(gi % ny - gj % ny)] * B[kk + c * ldb];
+          s += tab[std::llabs(gi / ny - gj / ny) * ny + std::llabs(gi % ny - gj % ny)] * B[kk + c * ldb];
         }
         C[r + c * ldc] = s;
       }

@@ -286,3 +286,33 @@ def test_fp32_basis_cpuref(gsi, cx):
     assert np.abs(u32 - b64.update(X, 0.7, etas, xb)).max() < 1e-5
     assert np.abs(b32[2] - Z32[:, 2]).max() == 0.0 and np.abs(b64[2] - Zh[:, 2]).max() == 0.0
     b32.close(); b64.close(); Zd.close()
+
+
+def test_implicit_exponential_and_table_operator(gsi, cx):
+    """gsi_op_gridcov_implicit_kind(kind=1) / _table: the generated operator equals the stored exponential covariance
+     and an arbitrary stationary kernel given as a table over grid offsets."""
+    from helpers import exponential_cov, grid_points
+    nx, ny, ell = 9, 7, 3.0
+    G = exponential_cov(nx, ny, ell)
+    op = gsi.gridcov_implicit_operator(cx, nx, ny, ell, kind=1)
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((nx * ny, 5))
+    assert np.abs(op.matmul(X) - G @ X).max() < 1e-12
+    assert np.abs(op.rmatmul_t(X) - G @ X).max() < 1e-12
+    op.close()
+    # anisotropic Matern-3/2-like table
+    dx = np.arange(nx)[:, None]; dy = np.arange(ny)[None, :]
+    r = np.sqrt((dx / 2.0) ** 2 + (dy / 5.0) ** 2)
+    T = (1.0 + np.sqrt(3.0) * r) * np.exp(-np.sqrt(3.0) * r)
+    P = grid_points(nx, ny)
+    D = np.abs(P[:, None, :] - P[None, :, :]).astype(int)
+    Gt = T[D[:, :, 0], D[:, :, 1]]
+    op = gsi.gridcov_implicit_operator(cx, nx, ny, 1.0, table=T)
+    assert np.abs(op.matmul(X) - Gt @ X).max() < 1e-12
+    Om = rng.standard_normal((nx * ny, 10))
+    Z, S = gsi.randsvd(op, 7, 3, 2, Omega=Om, return_S=True)
+    Zr, Sr, _ = orc.randsvd_full(Gt, 7, 3, 2, Om)
+    assert rel_sv_err(S, Sr, 7) < 1e-9
+    op.close()
+    with pytest.raises(gsi.GsiError):
+        gsi.gridcov_implicit_operator(cx, 4, 4, 1.0, kind=2)

@@ -790,3 +790,42 @@ def test_fft_powerlaw_fftrf_convention(gsi, ctx, Ns, beta, l):
     op.close()
     with pytest.raises(gsi.GsiError):
         gsi.fft_powerlaw_operator(ctx, [24, 16], beta, fftrf=True)           # 2N embedding needs power-of-two axes here
+
+
+# ---- implicit operator, exponential kernel and a caller-supplied stationary kernel table, against the
+#      STORED gsi_op_dense_gridcov(kind=1) on the same grid ------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,l", [(40, 33, 5), (64, 50, 160), (130, 7, 48)])
+def test_implicit_exponential_vs_stored(gsi, ctx, nx, ny, l):
+    n = nx * ny
+    rng = np.random.default_rng(n + l)
+    X = rng.standard_normal((n, l))
+    stored = gsi.gridcov_operator(ctx, nx, ny, 6.0, 1)               # exp(-d / ell), materialised in HBM
+    implicit = gsi.gridcov_implicit_operator(ctx, nx, ny, 6.0, kind=1)
+    Ys, Yi = stored.matmul(X), implicit.matmul(X)
+    assert np.abs(Yi - Ys).max() < 1e-11 * np.abs(Ys).max()
+    assert np.abs(implicit.rmatmul_t(X) - Ys).max() < 1e-11 * np.abs(Ys).max()
+    if l <= 48:
+        Om = rng.standard_normal((n, l))
+        K, p = l - 3, 3
+        Zi, Si = gsi.randsvd(implicit, K, p, 2, Omega=Om, return_S=True)
+        Zs, Ss = gsi.randsvd(stored, K, p, 2, Omega=Om, return_S=True)
+        assert rel_sv_err(Si, Ss, K) < 1e-9
+    stored.close(); implicit.close()
+
+
+@pytest.mark.gpu
+def test_implicit_table_operator_gpu(gsi, ctx):
+    from helpers import grid_points
+    nx, ny = 37, 21
+    dx = np.arange(nx)[:, None]; dy = np.arange(ny)[None, :]
+    r = np.sqrt((dx / 4.0) ** 2 + (dy / 9.0) ** 2)
+    T = (1.0 + np.sqrt(3.0) * r) * np.exp(-np.sqrt(3.0) * r)        # anisotropic Matern 3/2
+    P = grid_points(nx, ny)
+    D = np.abs(P[:, None, :] - P[None, :, :]).astype(int)
+    G = T[D[:, :, 0], D[:, :, 1]]
+    op = gsi.gridcov_implicit_operator(ctx, nx, ny, 1.0, table=T)
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((nx * ny, 40))
+    assert np.abs(op.matmul(X) - G @ X).max() < 1e-11 * np.abs(G @ X).max()
+    op.close()
