@@ -106,12 +106,36 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   constexpr int NTW = (NT + 1) / 2;
   const int jl = lane & 15;   // MFMA "column" index -> C row within a 16-row tile
   const int kk = lane >> 4;   // MFMA k index within a k4 step
-  int64_t r0 = (int64_t)(blockIdx.x / nchunks_x) * BMT;   // column chunk folded into x: chunk-mates are dispatched together
-  int64_t c0 = (int64_t)(blockIdx.x % nchunks_x) * (NT * 16);
+  // ---- workgroup -> (tile, K split), XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs in dispatch order
+  // (linear id % 8), each XCD has its own L2.  Two cases re-read a streamed operand from the fabric once per XCD
+  // unless the workgroups that share it sit on the SAME XCD (counters at n = 1e6, N_s = 1024, l = 320: S'X moved 29.7
+  // GB for 10.75 GB of operands, S T 19.6 GB):
+  //   split-K (S'X: 16 tiles x 16 splits): the tiles of one K range share both operand slabs -> split s on XCD s % 8;
+  //   column chunks of one row block (S T: 2 chunks): both read the same rows of the operator -> same XCD, 8 apart.
+  int64_t tile_lin = blockIdx.x;
+  int split = (int)blockIdx.y;
+  {
+    const int T = (int)gridDim.x, S = (int)gridDim.y;
+    if (S > 1 && (S & 7) == 0) {
+      const int lin = (int)blockIdx.x + T * (int)blockIdx.y;
+      const int xcd = lin & 7, j = lin >> 3;
+      split = xcd + 8 * (j / T);
+      tile_lin = j % T;
+    } else if (S == 1 && tri != 1 && nchunks_x > 1) {
+      const int C8 = 8 * nchunks_x;
+      const int nrb = (int)((M + BMT - 1) / BMT);
+      const int grp = (int)(blockIdx.x / C8), r = (int)(blockIdx.x % C8);
+      const int rows_here = (grp * 8 + 8 <= nrb) ? 8 : (nrb - grp * 8);      // the last group may be short
+      const int rb = grp * 8 + r % rows_here, chunk = r / rows_here;
+      tile_lin = (int64_t)rb * nchunks_x + chunk;
+    }
+  }
+  int64_t r0 = (int64_t)(tile_lin / nchunks_x) * BMT;
+  int64_t c0 = (int64_t)(tile_lin % nchunks_x) * (NT * 16);
   if (tri == 1) {
-    // symmetric product: blockIdx.x counts only the tiles that touch the upper triangle (tiles entirely below the
+    // symmetric product: the tile index counts only the tiles that touch the upper triangle (tiles entirely below the
     // diagonal are not part of the grid -- as idle workgroups they pushed the grid past one round of 256)
-    int left = (int)blockIdx.x;
+    int left = (int)tile_lin;
     const int nrb = (int)((M + BMT - 1) / BMT);
     for (int rb = 0; rb < nrb; ++rb) {
       const int first = (rb * BMT) / (NT * 16);           // first chunk with a column at or right of the block's first row
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   // tri == 1 (TN, C = A'A symmetric): tiles entirely below the diagonal are not computed (the caller mirrors the
   //   upper triangle); tri == 2 (NN, B upper triangular): rows of B below the chunk's last column are zero, so the
   //   reduction stops there.  CholeskyQR spends 4 n l^2 flop instead of 8 n l^2 this way.
-  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
+  const int64_t kbeg = (int64_t)split * kchunk;
   int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
   if (tri == 2 && kend > c0 + NT * 16) kend = c0 + NT * 16;
   const int64_t ntiles = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
@@ -371,7 +395,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   for (int h = 0; h < MT; ++h) {
     const int64_t row = r0 + 16 * MT * rg + 16 * h + jl;
     if (row < M) {
-      double* W = (slabs != nullptr) ? slabs + (int64_t)blockIdx.y * M * L : nullptr;
+      double* W = (slabs != nullptr) ? slabs + (int64_t)split * M * L : nullptr;
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         if ((NT % 2 == 0) || t < ntw) {

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch / per factorization from the two rocprofv3 --pmc passes of tools/pmc_bench_traffic.sh over
+`bench.py` (n = 1e6 LowRankCovMatrix, N_s = 1024, l = 320):  bytes = 2 * FETCH_SIZE(KB) * 1024 + WRITE_SIZE(KB) * 1024
+(FETCH_SIZE doubled per MI355X_MICROARCH.md, HBM section: gfx950 tallies 128-B requests at 64 B).
+    python tools/pmc_bench_summary.py <gpurun_out dir> <out.json>"""
+import collections, csv, glob, json, os, sys
+root, out_path = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+def load(counter):
+    fs = glob.glob(f"{root}/pmc_bench_{counter}/*/*counter_collection.csv")
+    rows = [r for r in csv.DictReader(open(fs[0])) if r["Counter_Name"] == counter]
+    out = collections.defaultdict(list)
+    for r in rows:
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3      # us
+        out[name].append((dur, float(r["Counter_Value"])))
+    return out
+
+F, W = load("FETCH_SIZE"), load("WRITE_SIZE")
+n, Ns, l = 1000000, 1024, 320
+res = {"kernel_source_hash": bench.kernel_source_hash(), "n": n, "samples": Ns, "l": l,
+       "note": "bytes = 2*FETCH_SIZE(KB)*1024 + WRITE_SIZE(KB)*1024, two separate --pmc passes of bench.py; FETCH_SIZE doubled "
+               "per MI355X_MICROARCH.md HBM section (gfx950 tallies 128-B requests at 64 B)"}
+# operator contractions: the long (>= 2 ms) dispatches of the big contraction kernel, S'X (TN) and S T (NN, K = N_s)
+per = {}
+for name in F:
+    if "gemm_f64_kernel<10" not in name:
+        continue
+    fl = [v for d, v in F[name] if d >= 8000.0]      # the two operator products (~10.8 ms); Y R^-1 (~4 ms) is a panel product
+    wl = [v for d, v in W.get(name, []) if d >= 8000.0]
+    if fl and wl:
+        per[name] = {"launches": len(fl), "fetch_KB_avg": sum(fl) / len(fl), "write_KB_avg": sum(wl) / len(wl),
+                     "hbm_bytes_per_launch": 2.0 * 1024.0 * sum(fl) / len(fl) + 1024.0 * sum(wl) / len(wl)}
+res["operator_contractions"] = per
+if per:
+    tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in per.values())
+    cnt = sum(v["launches"] for v in per.values())
+    res["hbm_bytes_per_launch"] = tot / cnt
+    res["algorithmic_bytes_per_launch"] = 8.0 * n * (Ns + l)
+    res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+
+def phase(prefixes, count_name, per_unit):
+    fb = sum(2.0 * 1024.0 * v for name in F if any(p in name for p in prefixes) for d, v in F[name])
+    wb = sum(1024.0 * v for name in W if any(p in name for p in prefixes) for d, v in W[name])
+    units = sum(len(F[name]) for name in F if count_name in name) / per_unit
+    return {"hbm_bytes_per_factorization": (fb + wb) / units if units else None, "factorizations": units,
+            "algorithmic_bytes": 16.0 * n * l,
+            "traffic_over_one_read_plus_write": ((fb + wb) / units / (16.0 * n * l)) if units else None}
+
+res["lu"] = phase(["lu_leaf_kernel", "lu_rankk_kernel", "lu_u12_kernel", "lu2_extract"], "lu_leaf_kernel", l // 8)
+json.dump(res, open(out_path, "w"), indent=1)
+print(json.dumps(res, indent=1))
