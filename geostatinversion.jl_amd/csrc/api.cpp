@@ -504,6 +504,30 @@ int gsi_lu_L(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double* L_out,
   });
 }
 
+int gsi_lu_L_sharded(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double* L_out, int32_t* ipiv_out) {
+  return guarded([&] {
+    REQUIRE(ctx && Y && L_out, "NULL argument");
+    REQUIRE(m >= 1 && l >= 1 && l <= m, "lu_L: need 1 <= l <= m (tall panel)");
+    Context& c = ctx->c;
+    Backend* be = c.be.get();
+    int64_t r0, ml;
+    default_shard(m, c.nranks(), c.rank(), &r0, &ml);
+    int64_t r00, ml0;
+    default_shard(m, c.nranks(), 0, &r00, &ml0);
+    REQUIRE(l <= ml0, "sharded lu: the first rank must hold the first l rows (l <= ceil(m / nranks))");
+    Buf P(be, (size_t)std::max<int64_t>(ml, 1) * l);
+    if (ml > 0) be->upload2d(P.p, ml, Y + r0, m, ml, l);
+    lu_panel_sharded(c, P.p, m, r0, ml, l);
+    Buf Full(be, (size_t)m * l);
+    Operator shape;
+    shape.m = m; shape.row0 = r0; shape.mloc = ml;
+    gather_rows(c, shape, P.p, std::max<int64_t>(ml, 1), l, Full.p);
+    be->download2d(L_out, m, Full.p, m, m, l);
+    if (ipiv_out) be->lus_pivots(ipiv_out, l);
+    check_async_errors(c);
+  });
+}
+
 int gsi_qr_thinQ(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double* Q_out, double* R_out) {
   return guarded([&] {
     REQUIRE(ctx && Y && Q_out, "NULL argument");

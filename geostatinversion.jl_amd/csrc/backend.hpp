@@ -66,6 +66,25 @@ class Backend {
   // Y (m x l, ld) <- L of lu(Y) in pivoted row order; ipiv (device int32[l]) may be null.
   // Sets *singular_flag (backend int, see flags()) to j+1 on an exactly zero pivot.
   virtual void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv_host_or_null) = 0;
+  // ---- the same factorization ROW-SHARDED (SURVEY.md 8e "sharded alternative"): primitives on this rank's rows
+  //      [row0, row0 + mloc) of the m x l panel, ld = leading dimension of the local block; the exchange between ranks is
+  //      pipeline.cpp:lu_panel_sharded.  Blocks of `lus_block()` columns, leaves of 8; per element the arithmetic of lu_L.
+  //      Record (4 + 2 l doubles): [0] max |value| (-1: none), [1] global row, [2] 1 if this rank holds row j,
+  //      [4, 4+l) that row, [4+l, 4+2l) row j.
+  virtual int lus_block() const = 0;
+  virtual void lus_u12_leaf(const double* Yloc, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w, double* U12) = 0;
+  virtual void lus_pending(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w,
+                           const double* U12) = 0;
+  virtual void lus_candidate(const double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l, int64_t j,
+                             double* rec) = 0;
+  virtual void lus_apply(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t m, int64_t l, int64_t j0, int s,
+                         int w, const double* recs, int nranks) = 0;
+  virtual void lus_u12_block(const double* Yloc, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t c1,
+                             double* U12) = 0;
+  virtual void lus_rankk(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t t,
+                         const double* U12) = 0;
+  virtual void lus_finish(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l) = 0;
+  virtual void lus_pivots(int32_t* host, int64_t l) = 0;      // the pivot rows of the last sharded factorization
   // Y (m x l) <- thin Q; R (l x l, ld l) <- upper triangular factor if R != null.
   // replicated: the same panel is factored by every rank and the results must be bit-identical everywhere
   // (stacked R factors of the TSQR, gathered panels): the backend must then not let anything rank-local

@@ -57,7 +57,7 @@ class HipBackend : public Backend {
   ~HipBackend() override {
     hipSetDevice(device_);
     hipStreamSynchronize(st_);
-    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_}) if (b->p) hipFree(b->p);
+    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_}) if (b->p) hipFree(b->p);
     for (auto& b : pool_) hipFree(b.p);
     for (auto& ev : ev_pool_) hipEventDestroy(ev);
     for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -291,6 +291,66 @@ class HipBackend : public Backend {
       HIP_CHECK(hipMemcpyAsync(ipiv_host, w.ipiv, sizeof(int32_t) * l, hipMemcpyDeviceToHost, st_));
       HIP_CHECK(hipStreamSynchronize(st_));
     }
+  }
+  // ---- row-sharded LU primitives ----
+  int lus_block() const override { return hipk::LU2_NB; }
+  struct LusWs { double* pval; int64_t* pidx; int32_t* ipiv; };
+  LusWs lus_ws(int64_t, int64_t l) {
+    // fixed layout: pivots (l <= 8188), then the per-workgroup partial arg-maxes (<= 1024 workgroups)
+    if (l > 8188) throw Error(GSI_ERR_ARG, "sharded lu: sketch width too large");
+    grow(ws_lus_, 32768 + 2 * 8 * 1024 + 64);
+    char* base = (char*)ws_lus_.p;
+    LusWs w;
+    w.ipiv = (int32_t*)base;
+    w.pval = (double*)(base + 32768);
+    w.pidx = (int64_t*)(base + 32768 + 8 * 1024);
+    return w;
+  }
+  void lus_u12_leaf(const double* Yloc, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w, double* U12) override {
+    bind();
+    hipk::lus_u12_leaf(st_, Yloc, ld, row0, jb, j0, w, U12);
+    check_launch("lus_u12_leaf");
+  }
+  void lus_pending(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w,
+                   const double* U12) override {
+    bind();
+    if (mloc > 0) hipk::lus_pending(st_, Yloc, ld, mloc, row0, jb, j0, w, U12);
+    check_launch("lus_pending");
+  }
+  void lus_candidate(const double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l, int64_t j, double* rec) override {
+    bind();
+    LusWs w = lus_ws(mloc, l);
+    hipk::lus_candidate(st_, Yloc, ld, mloc, row0, l, j, rec, w.pval, w.pidx);
+    check_launch("lus_candidate");
+  }
+  void lus_apply(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t m, int64_t l, int64_t j0, int s, int w,
+                 const double* recs, int nranks) override {
+    bind();
+    LusWs ws = lus_ws(mloc, l);
+    hipk::lus_apply(st_, Yloc, ld, mloc, row0, m, l, j0, s, w, recs, nranks, ws.ipiv, flags_ + 0);
+    check_launch("lus_apply");
+  }
+  void lus_u12_block(const double* Yloc, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t c1,
+                     double* U12) override {
+    bind();
+    hipk::lus_u12_block(st_, Yloc, ld, row0, jb, b, c0, c1, U12);
+    check_launch("lus_u12_block");
+  }
+  void lus_rankk(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t t,
+                 const double* U12) override {
+    bind();
+    hipk::lus_rankk(st_, Yloc, ld, mloc, row0, jb, b, c0, t, U12);
+    check_launch("lus_rankk");
+  }
+  void lus_finish(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l) override {
+    bind();
+    hipk::lus_finish(st_, Yloc, ld, mloc, row0, l);
+  }
+  void lus_pivots(int32_t* host, int64_t l) override {
+    bind();
+    LusWs w = lus_ws(1, l);
+    HIP_CHECK(hipMemcpyAsync(host, w.ipiv, sizeof(int32_t) * l, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
   }
   void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R, bool replicated) override {
     bind();
@@ -584,7 +644,7 @@ class HipBackend : public Backend {
   hipStream_t st_ = nullptr;
   int32_t* flags_ = nullptr;  // [0] lu info, [1] chol info, [8] jacobi rotation counter
   double* scal_ = nullptr;
-  DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_, ws_blas2_;
+  DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_, ws_blas2_, ws_lus_;
   std::mutex mu_;
   std::vector<DevBuf> sizes_;
   std::vector<DevBuf> pool_;

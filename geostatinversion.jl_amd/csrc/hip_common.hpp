@@ -71,6 +71,21 @@ struct Lu2Work {
 bool lu2_config(int64_t m, int ncus, int* bs, int* rpt, int* grid);
 void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu2Work& w);
 
+// row-sharded form (the exchange between ranks is pipeline.cpp's): primitives on this rank's rows [row0, row0 + mloc)
+int lus_grid(int64_t mloc);
+void lus_candidate(hipStream_t st, const double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j, double* rec,
+                   double* pval, int64_t* pidx);
+void lus_apply(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l, int64_t j0, int s, int w,
+               const double* recs, int nranks, int32_t* ipiv, int32_t* info);
+void lus_u12_leaf(hipStream_t st, const double* Y, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w, double* U12);
+void lus_pending(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t jb, int64_t j0, int w,
+                 const double* U12);
+void lus_u12_block(hipStream_t st, const double* Y, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t c1,
+                   double* U12);
+void lus_rankk(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t jb, int b, int64_t c0, int64_t t,
+               const double* U12);
+void lus_finish(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l);
+
 // ---- panel_qr.hip ----
 constexpr int QR_NB = 16;
 struct QrWork {

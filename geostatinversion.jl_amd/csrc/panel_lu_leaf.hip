@@ -681,4 +681,250 @@ void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu
 #endif
 }
 
+// =====================================================================================================================
+// Row-sharded form of the same factorization ("sharded alternative"): every rank keeps only its rows
+// [row0, row0 + mloc) of the panel; per pivot step the ranks exchange one record each {local max |value|, its global
+// row, that row, row j} (pipeline.cpp:lu_panel_sharded runs the collectives), everything else is row-local.  The
+// arithmetic per element is the register-resident kernel's, operation for operation (same blocks of 64, leaves of 8,
+// the same forward substitution for U12, fma(-l, u, a) in the same order, the same rank-64 MFMA update), so the
+// result is bit-identical to the single-rank factorization -- tests/test_gpu_parity.py compares them on the GPU.
+// Leaf columns live in HBM between the steps here (a step is host-sequenced around a collective, not a persistent launch).
+// Record (doubles): [0] max |value| (-1: none), [1] global row (as a double), [2] 1.0 if this rank holds row j,
+//                   [4, 4 + l) the candidate row, [4 + l, 4 + 2 l) row j.
+// =====================================================================================================================
+namespace {
+constexpr int LUS_HDR = 4;
+
+__global__ __launch_bounds__(256) void lus_cand_partial_kernel(const double* __restrict__ Y, int64_t ld, int64_t mloc,
+                                                               int64_t row0, int64_t j, double* __restrict__ pval,
+                                                               int64_t* __restrict__ pidx) {
+  __shared__ double s_v[4];
+  __shared__ int32_t s_i[4];
+  double best = -1.0;
+  int32_t besti = -1;
+  for (int64_t li = (int64_t)blockIdx.x * 256 + threadIdx.x; li < mloc; li += (int64_t)gridDim.x * 256) {
+    const int64_t gi = row0 + li;
+    if (gi >= j) {
+      const double av = fabs(Y[li + j * ld]);
+      if (av > best) { best = av; besti = (int32_t)gi; }     // ascending rows per thread: the first maximum stays
+    }
+  }
+  wave_argmax(best, besti);
+  if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = besti; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double v = (threadIdx.x < 4) ? s_v[threadIdx.x] : -1.0;
+    int32_t i = (threadIdx.x < 4) ? s_i[threadIdx.x] : -1;
+    wave_argmax8(v, i);
+    if (threadIdx.x == 0) { pval[blockIdx.x] = v; pidx[blockIdx.x] = i; }
+  }
+}
+__global__ __launch_bounds__(256) void lus_cand_final_kernel(const double* __restrict__ Y, int64_t ld, int64_t mloc,
+                                                             int64_t row0, int64_t l, int64_t j, int nparts,
+                                                             const double* __restrict__ pval, const int64_t* __restrict__ pidx,
+                                                             double* __restrict__ rec) {
+  __shared__ double s_v[4];
+  __shared__ int32_t s_i[4];
+  __shared__ int32_t s_win;
+  double best = -1.0;
+  int32_t besti = -1;
+  for (int p = threadIdx.x; p < nparts; p += 256) {
+    const double v = pval[p];
+    const int32_t i = (int32_t)pidx[p];
+    if (v > best || (v == best && (uint32_t)i < (uint32_t)besti)) { best = v; besti = i; }
+  }
+  wave_argmax(best, besti);
+  if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = besti; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double v = (threadIdx.x < 4) ? s_v[threadIdx.x] : -1.0;
+    int32_t i = (threadIdx.x < 4) ? s_i[threadIdx.x] : -1;
+    wave_argmax8(v, i);
+    if (threadIdx.x == 0) {
+      s_win = i;
+      rec[0] = v;
+      rec[1] = (double)i;
+      rec[2] = (j >= row0 && j < row0 + mloc) ? 1.0 : 0.0;
+      rec[3] = 0.0;
+    }
+  }
+  __syncthreads();
+  const int64_t wi = s_win;
+  const bool has_j = (j >= row0 && j < row0 + mloc);
+  for (int64_t c = threadIdx.x; c < l; c += 256) {
+    rec[LUS_HDR + c] = (wi >= 0) ? Y[(wi - row0) + c * ld] : 0.0;
+    rec[LUS_HDR + l + c] = has_j ? Y[(j - row0) + c * ld] : 0.0;
+  }
+}
+
+// every workgroup reduces the ranks' records in rank order (same result everywhere), then: the rank that holds row j
+// receives the pivot row there, the rank that holds row r the old row j, rows below j take the rank-1 update of the leaf
+__global__ __launch_bounds__(256) void lus_apply_kernel(double* __restrict__ Y, int64_t ld, int64_t mloc, int64_t row0,
+                                                        int64_t m, int64_t l, int64_t j0, int s, int w,
+                                                        const double* __restrict__ recs, int nranks,
+                                                        int32_t* __restrict__ ipiv, int32_t* __restrict__ info) {
+  __shared__ double s_u[LW], s_old[LW];
+  __shared__ int32_t s_r;
+  __shared__ int s_gw, s_go;
+  __shared__ double s_bestv;
+  const int64_t j = j0 + s;
+  const int64_t reclen = LUS_HDR + 2 * l;
+  if (threadIdx.x == 0) {
+    double best = -1.0;
+    int32_t besti = -1;
+    int gw = -1, go = -1;
+    for (int g = 0; g < nranks; ++g) {
+      const double v = recs[g * reclen + 0];
+      const int32_t i = (int32_t)recs[g * reclen + 1];
+      if (i >= 0 && (v > best || (v == best && (uint32_t)i < (uint32_t)besti))) { best = v; besti = i; gw = g; }
+      if (recs[g * reclen + 2] != 0.0) go = g;
+    }
+    const bool valid = (besti >= j && besti < m && gw >= 0);
+    s_r = valid ? besti : (int32_t)j;
+    s_gw = valid ? gw : go;
+    s_go = go;
+    s_bestv = best;
+  }
+  __syncthreads();
+  const int32_t r = s_r;
+  const double* prow = recs + (int64_t)s_gw * reclen + ((s_gw == s_go && r == j) ? LUS_HDR + l : LUS_HDR);   // the pivot row
+  const double* orow = recs + (int64_t)s_go * reclen + LUS_HDR + l;                                          // the old row j
+  if (threadIdx.x < LW) {
+    s_u[threadIdx.x] = (threadIdx.x < w) ? prow[j0 + threadIdx.x] : 0.0;
+    s_old[threadIdx.x] = (threadIdx.x < w) ? orow[j0 + threadIdx.x] : 0.0;
+  }
+  __syncthreads();
+  const double piv = s_u[s];
+  const double rpiv = (piv != 0.0) ? 1.0 / piv : 0.0;
+  const bool has_j = (j >= row0 && j < row0 + mloc), has_r = (r >= row0 && r < row0 + mloc);
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {                      // every rank keeps the whole pivot sequence
+      if (ipiv != nullptr) ipiv[j] = r;
+      if (!(s_bestv > 0.0)) atomicCAS(info, 0, (int32_t)(j + 1));
+    }
+    if (r != j) {
+      for (int64_t c = threadIdx.x; c < l; c += 256) {
+        const bool leafcol = (c >= j0 && c < j0 + w);
+        if (has_j) Y[(j - row0) + c * ld] = prow[c];                 // the pivot row moves up (all columns)
+        if (has_r && !leafcol) Y[(r - row0) + c * ld] = orow[c];     // the old row j moves down (its leaf part below)
+      }
+    }
+  }
+  for (int64_t li = (int64_t)blockIdx.x * 256 + threadIdx.x; li < mloc; li += (int64_t)gridDim.x * 256) {
+    const int64_t gi = row0 + li;
+    if (gi <= j) continue;
+    double* row = Y + li + j0 * ld;
+    const bool moved = (gi == r);
+    double x[LW];
+#pragma unroll
+    for (int k = 0; k < LW; ++k) x[k] = moved ? s_old[k] : ((k >= s && k < w) ? row[k * ld] : 0.0);
+    const double x0 = x[s];
+    const double lij = (rpiv != 0.0) ? x0 * rpiv : x0;
+    x[s] = lij;
+#pragma unroll
+    for (int k = 0; k < LW; ++k)
+      if (k > s) x[k] -= lij * s_u[k];
+#pragma unroll
+    for (int k = 0; k < LW; ++k)
+      if (k < w && (k >= s || moved)) row[k * ld] = x[k];
+  }
+}
+
+// rows [jb, j0) of the leaf columns -> U12 = L11^-1 A12 (kp x 8, [c * 8 + v]); the rank that holds those rows
+__global__ __launch_bounds__(512) void lus_u12_leaf_kernel(const double* __restrict__ Y, int64_t ld, int64_t jb_local,
+                                                           int kp, int64_t j0, int w, double* __restrict__ U12) {
+  __shared__ double Ls[KPMAX * LSP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < kp * kp; e += 512) {
+    const int r = e % kp, c = e / kp;
+    Ls[r * LSP + c] = Y[(jb_local + r) + (int64_t)(j0 - kp + c) * ld];     // rows local, columns global jb .. j0
+  }
+  __syncthreads();
+  for (int v = wave; v < LW; v += 8) {
+    double x = (lane < kp && v < w) ? Y[(jb_local + lane) + (int64_t)(j0 + v) * ld] : 0.0;
+    for (int cp = 0; cp < kp; ++cp) {
+      const double xc = readlane_d(x, __builtin_amdgcn_readfirstlane(cp));
+      if (lane > cp && lane < kp) x -= Ls[lane * LSP + cp] * xc;
+    }
+    if (lane < kp) U12[lane * LW + v] = x;
+  }
+}
+__global__ __launch_bounds__(256) void lus_pending_kernel(double* __restrict__ Y, int64_t ld, int64_t mloc, int64_t row0,
+                                                          int64_t jb, int64_t j0, int w, const double* __restrict__ U12) {
+  __shared__ double Us[KPMAX * LW];
+  const int kp = (int)(j0 - jb);
+  for (int e = threadIdx.x; e < kp * LW; e += 256) Us[e] = U12[e];
+  __syncthreads();
+  for (int64_t li = (int64_t)blockIdx.x * 256 + threadIdx.x; li < mloc; li += (int64_t)gridDim.x * 256) {
+    if (row0 + li < j0) continue;
+    double a[LW];
+#pragma unroll
+    for (int k = 0; k < LW; ++k) a[k] = (k < w) ? Y[li + (j0 + k) * ld] : 0.0;
+    for (int c = 0; c < kp; ++c) {
+      const double lv = Y[li + (jb + c) * ld];
+#pragma unroll
+      for (int k = 0; k < LW; ++k) a[k] -= lv * Us[c * LW + k];
+    }
+#pragma unroll
+    for (int k = 0; k < LW; ++k)
+      if (k < w) Y[li + (j0 + k) * ld] = a[k];
+  }
+}
+__global__ void lus_finish_kernel(double* __restrict__ Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l) {
+  const int64_t total = l * l;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e % l, c = e / l;
+    if (r < row0 || r >= row0 + mloc) continue;
+    if (r == c) Y[(r - row0) + c * ld] = 1.0;
+    else if (r < c) Y[(r - row0) + c * ld] = 0.0;
+  }
+}
+}  // namespace
+
+int lus_grid(int64_t mloc) {
+  int64_t g = (mloc + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 1024) g = 1024;
+  return (int)g;
+}
+void lus_candidate(hipStream_t st, const double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j, double* rec,
+                   double* pval, int64_t* pidx) {
+  const int g = lus_grid(mloc);
+  hipLaunchKernelGGL(lus_cand_partial_kernel, dim3(g), dim3(256), 0, st, Y, ld, mloc, row0, j, pval, pidx);
+  hipLaunchKernelGGL(lus_cand_final_kernel, dim3(1), dim3(256), 0, st, Y, ld, mloc, row0, l, j, g, pval, pidx, rec);
+}
+void lus_apply(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l, int64_t j0, int s, int w,
+               const double* recs, int nranks, int32_t* ipiv, int32_t* info) {
+  hipLaunchKernelGGL(lus_apply_kernel, dim3(lus_grid(mloc)), dim3(256), 0, st, Y, ld, mloc, row0, m, l, j0, s, w, recs, nranks,
+                     ipiv, info);
+}
+void lus_u12_leaf(hipStream_t st, const double* Y, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w, double* U12) {
+  hipLaunchKernelGGL(lus_u12_leaf_kernel, dim3(1), dim3(512), 0, st, Y, ld, jb - row0, (int)(j0 - jb), j0, w, U12);
+}
+void lus_pending(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t jb, int64_t j0, int w,
+                 const double* U12) {
+  hipLaunchKernelGGL(lus_pending_kernel, dim3(lus_grid(mloc)), dim3(256), 0, st, Y, ld, mloc, row0, jb, j0, w, U12);
+}
+void lus_u12_block(hipStream_t st, const double* Y, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t c1,
+                   double* U12) {
+  const unsigned gu = (unsigned)((c1 - c0 + 63) / 64);
+  if (b == 64) hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(64), 0, st, Y, ld, jb - row0, c0, c1, U12);
+  else hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(64), 0, st, Y, ld, jb - row0, c0, c1, U12);
+}
+void lus_rankk(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t jb, int b, int64_t c0, int64_t t,
+               const double* U12) {
+  int64_t rbeg = c0 - row0;             // first local row below the block
+  if (rbeg < 0) rbeg = 0;
+  const int64_t mr = mloc - rbeg;
+  if (mr <= 0) return;
+  const unsigned gr = (unsigned)((mr + 127) / 128);
+  if (b == 64) launch_rankk<64>(st, gr, Y, ld, mloc, rbeg, jb, c0, t, U12);
+  else launch_rankk<32>(st, gr, Y, ld, mloc, rbeg, jb, c0, t, U12);
+}
+void lus_finish(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l) {
+  int eb = (int)((l * l + 255) / 256);
+  if (eb > 1024) eb = 1024;
+  hipLaunchKernelGGL(lus_finish_kernel, dim3(eb), dim3(256), 0, st, Y, ld, mloc, row0, l);
+}
+
 }}  // namespace gsi::hipk

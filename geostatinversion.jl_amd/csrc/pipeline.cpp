@@ -13,6 +13,7 @@
 #include "pipeline.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include "../../include/gsi_hip.h"
 
@@ -218,6 +219,62 @@ static void lu_panel(Context& c, double* Y, int64_t rows, int64_t l) {
   c.be->lu_L(Y, rows, l, rows, nullptr);   // F = lu(Y); Q = F.L   RandMatFact.jl:60-61,68-69,72-73
 }
 
+static bool all_shards_tall(int64_t m, int G, int64_t l);
+
+// Partial-pivot LU of a row-sharded panel ("sharded alternative": local arg-max -> exchange -> pivot row
+// to everyone).  Per pivot step ONE all-gather of a (4 + 2 l)-double record per rank {local max, its row, row j};
+// every rank then picks the same winner (largest value, lowest global row: LAPACK's idamax).  Left-looking leaves of 8
+// inside blocks of lus_block() columns, exactly like the single-rank kernels; the U12 rows (rank 0 holds the first l
+// rows) reach the other ranks by an all-reduce with zeros.
+void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l) {
+  Backend* be = c.be.get();
+  const int G = c.nranks(), rank = c.rank();
+  if (G > 1 && l > (m + G - 1) / G)
+    throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: the first rank must hold the first l rows");
+  ScopedPhase ph(be, PH_LU);
+  const int64_t reclen = 4 + 2 * l, ld = std::max<int64_t>(mloc, 1);
+  const int nb = be->lus_block();
+  Buf rec(be, (size_t)reclen), recs(be, (size_t)reclen * G), u12leaf(be, (size_t)nb * 8), u12blk(be, (size_t)nb * l);
+  for (int64_t jb = 0; jb < l; jb += nb) {
+    const int b = (int)std::min<int64_t>(nb, l - jb);
+    for (int64_t j0 = jb; j0 < jb + b; j0 += 8) {
+      const int w = (int)std::min<int64_t>(8, jb + b - j0);
+      const int64_t kp = j0 - jb;
+      if (kp > 0) {
+        if (rank == 0) be->lus_u12_leaf(Yloc, ld, row0, jb, j0, w, u12leaf.p);
+        else be->fill_zero(u12leaf.p, (size_t)kp * 8);
+        if (c.comm) c.comm->allreduce_sum(u12leaf.p, (size_t)kp * 8);
+        be->lus_pending(Yloc, mloc, ld, row0, jb, j0, w, u12leaf.p);
+      }
+      for (int s = 0; s < w; ++s) {
+        be->lus_candidate(Yloc, mloc, ld, row0, l, j0 + s, rec.p);
+        if (c.comm) c.comm->allgather(rec.p, recs.p, (size_t)reclen);
+        else be->copy2d(recs.p, reclen, rec.p, reclen, reclen, 1);
+        be->lus_apply(Yloc, mloc, ld, row0, m, l, j0, s, w, recs.p, G);
+      }
+    }
+    const int64_t c0 = jb + b, t = l - c0;
+    if (t > 0) {
+      if (rank == 0) be->lus_u12_block(Yloc, ld, row0, jb, b, c0, l, u12blk.p);
+      else be->fill_zero(u12blk.p, (size_t)b * t);
+      if (c.comm) c.comm->allreduce_sum(u12blk.p, (size_t)b * t);
+      be->lus_rankk(Yloc, mloc, ld, row0, jb, b, c0, t, u12blk.p);
+    }
+  }
+  be->lus_finish(Yloc, mloc, ld, row0, l);
+}
+
+// When is the sharded form used?  It trades the all-gather of the m x l panel plus a replicated factorization for ~l
+// latency-bound collectives (DESIGN.md section 6 has the numbers).  A LowRankCovMatrix never needs the panel whole
+// (its products take and give row shards), so with the sharded LU its range finder moves nothing of size n x l at
+// all; for the other operators the replicated form stays the default.  GSI_LU_SHARDED=1 / =0 forces either.
+bool use_sharded_lu(Context& c, const Operator& A, int64_t rows, int64_t l) {
+  if (!c.comm || !all_shards_tall(rows, c.nranks(), l)) return false;
+  static const char* env = getenv("GSI_LU_SHARDED");
+  if (env != nullptr) return env[0] == '1';
+  return A.kind == OP_LOWRANK && c.nranks() > 1;
+}
+
 static bool all_shards_tall(int64_t m, int G, int64_t l) {
   for (int g = 0; g < G; ++g) {
     int64_t r0, ml;
@@ -289,23 +346,46 @@ Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
     tsqr(c, A, Yloc, l);                                    //                        :57-58
     return Yloc;
   }
+  if (!single && A.kind == OP_LOWRANK && A.m == A.n && use_sharded_lu(c, A, m, l)) {
+    // LowRankCovMatrix with the row-sharded LU: every panel stays a row shard from the sketch to the TSQR -- products
+    // take and give local rows (S (S'X): only the N x l sums cross ranks), adjoint(A) === A (lowrank.jl:38-40)
+    Buf Yloc(be, (size_t)std::max<int64_t>(A.mloc, 1) * l), Zloc(be, (size_t)std::max<int64_t>(A.mloc, 1) * l);
+    auto mul_local = [&](const double* Xloc, int64_t ldx, double* Out) {
+      op_mul(A, Xloc - A.row0, ldx, l, Out, A.mloc);       // op_mul reads rows [row0, row0 + mloc) of its X argument only
+    };
+    mul_local(Omega + A.row0, n, Yloc.p);                   // Y = A*Omega            :55
+    lu_panel_sharded(c, Yloc.p, m, A.row0, A.mloc, l);      // Q = lu(Y).L            :60-61
+    for (int64_t i = 1; i <= q; ++i) {
+      mul_local(Yloc.p, A.mloc, Zloc.p);                    // Q = A'*Q               :67
+      lu_panel_sharded(c, Zloc.p, m, A.row0, A.mloc, l);    //                        :68-69
+      mul_local(Zloc.p, A.mloc, Yloc.p);                    // Q = A*Q                :70
+      if (i < q) lu_panel_sharded(c, Yloc.p, m, A.row0, A.mloc, l);   //              :72-73
+    }
+    tsqr(c, A, Yloc, l);                                    //                        :75-76
+    return Yloc;
+  }
   Buf Yfull(be, (size_t)m * l);                              // replicated m x l
   Buf Z(be, (size_t)n * l);                                  // replicated n x l
   Buf Yloc;                                                  // this rank's rows (multi-rank only)
   if (!single) Yloc = Buf(be, (size_t)std::max<int64_t>(A.mloc, 1) * l);
   double* yl = single ? Yfull.p : Yloc.p;
   const int64_t ldyl = single ? m : A.mloc;
+  // a sketch panel comes out of A*X as row shards: factor it where it lies when the sharded LU is on (the all-gather
+  // of the panel and the replicated factorization go away; A'*L only reads the local rows anyway)
+  const bool shard_y = !single && use_sharded_lu(c, A, m, l);
+  auto lu_y = [&]() {
+    if (shard_y) { lu_panel_sharded(c, yl, m, A.row0, A.mloc, l); return; }
+    gather_rows(c, A, yl, ldyl, l, Yfull.p);
+    lu_panel(c, Yfull.p, m, l);
+  };
   op_mul(A, Omega, n, l, yl, ldyl);                         // Y = A*Omega            :55
-  gather_rows(c, A, yl, ldyl, l, Yfull.p);
-  lu_panel(c, Yfull.p, m, l);                               // Q = lu(Y).L            :60-61
+  lu_y();                                                   // Q = lu(Y).L            :60-61
   for (int64_t i = 1; i <= q; ++i) {                        //                        :66
-    op_mul_t(A, Yfull.p + A.row0, m, l, Z.p, n);            // Q = A'*Q               :67
-    lu_panel(c, Z.p, n, l);                                 // Q = lu(Q).L            :68-69
+    if (shard_y) op_mul_t(A, yl, ldyl, l, Z.p, n);          // Q = A'*Q               :67
+    else op_mul_t(A, Yfull.p + A.row0, m, l, Z.p, n);
+    lu_panel(c, Z.p, n, l);                                 // Q = lu(Q).L            :68-69 (Z is replicated by the all-reduce)
     op_mul(A, Z.p, n, l, yl, ldyl);                         // Q = A*Q                :70
-    if (i < q) {
-      gather_rows(c, A, yl, ldyl, l, Yfull.p);
-      lu_panel(c, Yfull.p, m, l);                           //                        :72-73
-    }
+    if (i < q) lu_y();                                      //                        :72-73
   }
   if (single) {
     tsqr(c, A, Yfull, l);                                   // pivoted-QR range       :75-76

@@ -62,6 +62,11 @@ void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, dou
 // Y (m x l, ld m, replicated) <- all ranks' row shards
 void gather_rows(Context& c, const Operator& A, const double* Yloc, int64_t ldy, int64_t l, double* Yfull);
 
+// lu(Y).L of a ROW-SHARDED m x l panel (this rank: rows [row0, row0 + mloc), block layout of default_shard(m)), in
+// place; bit-identical to the single-rank factorization.  One small all-gather per pivot step, one all-reduce per
+// leaf / block for the U12 rows of rank 0; nothing of size m x l is communicated.  Needs l <= rows of rank 0.
+void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l);
+bool use_sharded_lu(Context& c, const Operator& A, int64_t rows, int64_t l);
 // rangefinder(A, l, numiterations)  RandMatFact.jl:50-80.  Omega replicated n x l (ld n).
 // Returns this rank's rows of Q (mloc x l, ld mloc).
 Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q);

@@ -144,6 +144,19 @@ def lu_L(Y, *, return_pivots=False, ctx=None):
     return (out, piv) if return_pivots else out
 
 
+def lu_L_sharded(Y, *, return_pivots=False, ctx=None):
+    """`lu(Y).L` with the panel row-sharded over the ranks of `ctx`'s communicator (collective; every rank passes the
+    whole panel and receives the whole L): bit-identical to `lu_L`."""
+    ctx = ctx or default_context()
+    Yf = L.fmat(Y, "Y")
+    m, l = Yf.shape
+    out = np.empty((m, l), order="F")
+    piv = np.empty(l, dtype=np.int32)
+    L.check(ctx.lib.gsi_lu_L_sharded(ctx.h, L.dptr(Yf), m, l, L.dptr(out), piv.ctypes.data_as(C.POINTER(C.c_int32))),
+            ctx.lib)
+    return (out, piv) if return_pivots else out
+
+
 def qr_thinQ(Y, *, return_R=False, ctx=None):
     """`Matrix(qr(Y, Val(true)).Q)` up to an orthogonal change of basis  (RandMatFact.jl:57-58)."""
     ctx = ctx or default_context()

@@ -159,6 +159,116 @@ class CpuBackend : public Backend {
     const int info = gsio_lu_L(Y, m, l, ld, ipiv);
     if (info && !lu_info_) lu_info_ = info;
   }
+  // ---- row-sharded LU primitives: the arithmetic of gsio_lu_L (unblocked right-looking, multiplier = a * (1/pivot),
+  //      a -= l * u in ascending column order), regrouped by leaves and blocks -- per element the same operations in the
+  //      same order, so the sharded factorization equals the single-rank one bit for bit ----
+  int lus_block() const override { return 32; }
+  void lus_u12_leaf(const double* Y, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w, double* U12) override {
+    const int64_t kp = j0 - jb;
+    for (int v = 0; v < 8; ++v)
+      for (int64_t c = 0; c < kp; ++c) {
+        double x = (v < w) ? Y[(jb - row0 + c) + (j0 + v) * ld] : 0.0;
+        for (int64_t cp = 0; cp < c; ++cp) x -= Y[(jb - row0 + c) + (jb + cp) * ld] * U12[cp * 8 + v];
+        U12[c * 8 + v] = x;
+      }
+  }
+  void lus_pending(double* Y, int64_t mloc, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w,
+                   const double* U12) override {
+    const int64_t kp = j0 - jb;
+    for (int64_t li = 0; li < mloc; ++li) {
+      if (row0 + li < j0) continue;
+      for (int k = 0; k < w; ++k) {
+        double a = Y[li + (j0 + k) * ld];
+        for (int64_t c = 0; c < kp; ++c) a -= Y[li + (jb + c) * ld] * U12[c * 8 + k];
+        Y[li + (j0 + k) * ld] = a;
+      }
+    }
+  }
+  void lus_candidate(const double* Y, int64_t mloc, int64_t ld, int64_t row0, int64_t l, int64_t j, double* rec) override {
+    double best = -1.0;
+    int64_t bi = -1;
+    for (int64_t li = 0; li < mloc; ++li)
+      if (row0 + li >= j) {
+        const double av = std::fabs(Y[li + j * ld]);
+        if (av > best) { best = av; bi = row0 + li; }
+      }
+    const bool has_j = (j >= row0 && j < row0 + mloc);
+    rec[0] = best; rec[1] = (double)bi; rec[2] = has_j ? 1.0 : 0.0; rec[3] = 0.0;
+    for (int64_t c = 0; c < l; ++c) {
+      rec[4 + c] = (bi >= 0) ? Y[(bi - row0) + c * ld] : 0.0;
+      rec[4 + l + c] = has_j ? Y[(j - row0) + c * ld] : 0.0;
+    }
+  }
+  void lus_apply(double* Y, int64_t mloc, int64_t ld, int64_t row0, int64_t m, int64_t l, int64_t j0, int s, int w,
+                 const double* recs, int nranks) override {
+    const int64_t j = j0 + s, reclen = 4 + 2 * l;
+    double best = -1.0;
+    int64_t bi = -1;
+    int gw = -1, go = -1;
+    for (int g = 0; g < nranks; ++g) {
+      const double v = recs[g * reclen];
+      const int64_t i = (int64_t)recs[g * reclen + 1];
+      if (i >= 0 && (v > best || (v == best && i < bi))) { best = v; bi = i; gw = g; }
+      if (recs[g * reclen + 2] != 0.0) go = g;
+    }
+    const bool valid = (bi >= j && bi < m && gw >= 0);
+    const int64_t r = valid ? bi : j;
+    const double* prow = valid ? recs + gw * reclen + 4 : recs + go * reclen + 4 + l;
+    const double* orow = recs + go * reclen + 4 + l;
+    if ((int64_t)lus_ipiv_.size() < l) lus_ipiv_.resize((size_t)l);
+    lus_ipiv_[(size_t)j] = (int32_t)r;
+    if (best == 0.0 || !(best > 0.0)) { if (!lu_info_) lu_info_ = (int)(j + 1); }
+    const double piv = prow[j];
+    const bool singular = !(best > 0.0);                  // gsio_lu_L skips the column on an exactly zero pivot
+    const bool has_j = (j >= row0 && j < row0 + mloc), has_r = (r >= row0 && r < row0 + mloc);
+    if (!singular && r != j) {
+      std::vector<double> pr(prow, prow + l), orw(orow, orow + l);
+      if (has_j) for (int64_t c = 0; c < l; ++c) Y[(j - row0) + c * ld] = pr[(size_t)c];
+      if (has_r) for (int64_t c = 0; c < l; ++c) Y[(r - row0) + c * ld] = orw[(size_t)c];
+    }
+    if (singular) return;
+    const double rp = 1.0 / piv;
+    for (int64_t li = 0; li < mloc; ++li) {
+      if (row0 + li <= j) continue;
+      Y[li + j * ld] *= rp;
+      const double lij = Y[li + j * ld];
+      for (int k = s + 1; k < w; ++k) {
+        const double u = prow[j0 + k];
+        if (u != 0.0) Y[li + (j0 + k) * ld] -= lij * u;
+      }
+    }
+  }
+  void lus_u12_block(const double* Y, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t c1,
+                     double* U12) override {
+    for (int64_t c = c0; c < c1; ++c)
+      for (int r = 0; r < b; ++r) {
+        double x = Y[(jb - row0 + r) + c * ld];
+        for (int p = 0; p < r; ++p) x -= Y[(jb - row0 + r) + (jb + p) * ld] * U12[p + (c - c0) * b];
+        U12[r + (c - c0) * b] = x;
+      }
+  }
+  void lus_rankk(double* Y, int64_t mloc, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t t,
+                 const double* U12) override {
+    for (int64_t li = 0; li < mloc; ++li) {
+      if (row0 + li < c0) continue;
+      for (int64_t c = 0; c < t; ++c) {
+        double a = Y[li + (c0 + c) * ld];
+        for (int p = 0; p < b; ++p) {
+          const double u = U12[p + c * b];
+          if (u != 0.0) a -= Y[li + (jb + p) * ld] * u;
+        }
+        Y[li + (c0 + c) * ld] = a;
+      }
+    }
+  }
+  void lus_finish(double* Y, int64_t mloc, int64_t ld, int64_t row0, int64_t l) override {
+    for (int64_t c = 0; c < l; ++c)
+      for (int64_t r = 0; r <= c; ++r)
+        if (r >= row0 && r < row0 + mloc) Y[(r - row0) + c * ld] = (r == c) ? 1.0 : 0.0;
+  }
+  void lus_pivots(int32_t* host, int64_t l) override {
+    for (int64_t i = 0; i < l; ++i) host[i] = (i < (int64_t)lus_ipiv_.size()) ? lus_ipiv_[(size_t)i] : 0;
+  }
   void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R, bool /*replicated*/) override {
     gsio_qr_thinQ(Y, m, l, ld, 0, R, nullptr);   // unpivoted, like the HIP backend (same range)
   }
@@ -285,6 +395,7 @@ class CpuBackend : public Backend {
   std::vector<std::pair<double*, size_t>> sizes_;
   int64_t in_use_ = 0;
   int lu_info_ = 0, chol_info_ = 0;
+  std::vector<int32_t> lus_ipiv_;
   int64_t counts_[PH_COUNT] = {0};
 };
 

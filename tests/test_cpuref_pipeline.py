@@ -316,3 +316,17 @@ def test_implicit_exponential_and_table_operator(gsi, cx):
     op.close()
     with pytest.raises(gsi.GsiError):
         gsi.gridcov_implicit_operator(cx, 4, 4, 1.0, kind=2)
+
+
+@pytest.mark.parametrize("m,l", [(10, 2), (40, 7), (100, 25), (625, 50), (300, 70), (97, 33)])
+def test_lu_sharded_single_rank_equals_lu(gsi, cx, m, l):
+    """The row-sharded LU (pipeline.cpp:lu_panel_sharded) on one rank: same pivots as dgetrf, L equal to the single-rank
+    factorization bit for bit."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(m * l)
+    Y = rng.standard_normal((m, l))
+    Ls, ps = gsi.lu_L_sharded(Y, return_pivots=True, ctx=cx)
+    L1, p1 = gsi.lu_L(Y, return_pivots=True, ctx=cx)
+    assert np.array_equal(ps, p1)
+    assert np.array_equal(ps, orc.lu_pivots(Y))
+    assert np.array_equal(Ls, L1)

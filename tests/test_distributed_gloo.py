@@ -106,6 +106,18 @@ def _worker(rank, world, port, q):
         x4, _ = orc.getxis_fields(small, 2, 1, 1, Om4)
         results["lowrank_empty_rank_xis"] = orc.xis_error_up_to_sign(Z4, np.array(x4).T, 2)
         lr4.close()
+        # row-sharded partial-pivot LU (SURVEY 8e "sharded alternative"): dgetrf's pivots, L equal to the single-rank
+        # factorization EXACTLY, on every rank; ties (duplicate rows across the shard boundary) included
+        ctx1 = gsi.Context(0, lib=lib)                               # a second context without a communicator
+        for (mm, ll) in [(143, 16), (90, 30), (64, 21)]:
+            Yp = rng.standard_normal((mm, ll))
+            if mm == 90:
+                Yp[60:75] = Yp[5:20]                                # exact ties between rows of different ranks
+            Ls, ps = gsi.lu_L_sharded(Yp, return_pivots=True, ctx=ctx)
+            L1, p1 = gsi.lu_L(Yp, return_pivots=True, ctx=ctx1)
+            results[f"lu_sharded_{mm}_pivots_equal"] = 0.0 if (np.array_equal(ps, p1) and np.array_equal(ps, orc.lu_pivots(Yp))) else 1.0
+            results[f"lu_sharded_{mm}_L_exact"] = 0.0 if np.array_equal(Ls, L1) else 1.0
+        ctx1.close()
         # operator products gathered to every rank
         op = gsi.dense_operator(ctx, B)
         X = rng.standard_normal((60, 3))

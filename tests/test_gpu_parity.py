@@ -829,3 +829,60 @@ def test_implicit_table_operator_gpu(gsi, ctx):
     X = rng.standard_normal((nx * ny, 40))
     assert np.abs(op.matmul(X) - G @ X).max() < 1e-11 * np.abs(G @ X).max()
     op.close()
+
+
+# ---- row-sharded LU on the GPU (one rank: no collective, every kernel of the sharded path): bit-identical to the
+#      register-resident single-rank factorization, dgetrf's pivots ---------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,l", [(10, 2), (100, 25), (625, 50), (5000, 160), (3000, 33), (70001, 72), (300000, 96)])
+def test_lu_sharded_bit_identical(gsi, ctx, m, l):
+    rng = np.random.default_rng(m + l)
+    Y = rng.standard_normal((m, l))
+    if m == 3000:
+        Y[1500:1600] = Y[100:200]                                    # exact ties
+    Ls, ps = gsi.lu_L_sharded(Y, return_pivots=True, ctx=ctx)
+    L1, p1 = gsi.lu_L(Y, return_pivots=True, ctx=ctx)
+    assert np.array_equal(ps, p1)
+    assert np.array_equal(Ls, L1)
+    if m <= 5000:
+        assert np.array_equal(ps, orc.lu_pivots(Y))
+
+
+@pytest.mark.gpu
+def test_lu_sharded_through_rccl_single_rank(gsi):
+    """The row-sharded LU with its collectives going through librccl (1-rank communicator, GSI_FORCE_COMM=1) and forced
+    on for every operator (GSI_LU_SHARDED=1): pivots and L equal to the plain single-rank factorization exactly; a
+    randsvd through the sharded range finder equals the replicated one to rounding."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import gsi_amd as gsi
+from helpers import gaussian_cov, powerlaw_fields
+os.environ["GSI_FORCE_COMM"] = "1"; os.environ["GSI_LU_SHARDED"] = "1"
+ctx = gsi.Context(0)
+ctx.comm_init(1, 0, ctx.unique_id())
+rng = np.random.default_rng(4)
+Y = rng.standard_normal((20000, 72))
+Ls, ps = gsi.lu_L_sharded(Y, return_pivots=True, ctx=ctx)
+A = gaussian_cov(20, 15, 3.0); Om = rng.standard_normal((300, 20))
+Z1, S1 = gsi.randsvd(A, 14, 6, 2, Omega=Om, return_S=True, ctx=ctx)
+fields = powerlaw_fields(rng, (12, 12), 30); Om2 = rng.standard_normal((144, 12))
+lr = gsi.LowRankCovMatrix(fields, ctx=ctx); Z3 = gsi.randsvd(lr, 8, 4, 3, Omega=Om2)
+del os.environ["GSI_FORCE_COMM"]
+ctx2 = gsi.Context(0)
+L1, p1 = gsi.lu_L(Y, return_pivots=True, ctx=ctx2)
+assert np.array_equal(ps, p1) and np.array_equal(Ls, L1)
+Z2, S2 = gsi.randsvd(A, 14, 6, 2, Omega=Om, return_S=True, ctx=ctx2)
+lr2 = gsi.LowRankCovMatrix(fields, ctx=ctx2); Z4 = gsi.randsvd(lr2, 8, 4, 3, Omega=Om2)
+assert np.abs(S1 - S2).max() < 1e-12 * S2[0]
+assert np.abs(Z1 - Z2).max() < 1e-9 and np.abs(Z3 - Z4).max() < 1e-9
+print("rccl-sharded-lu-ok")
+'''
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "rccl-sharded-lu-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
