@@ -34,6 +34,24 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// roctx ranges around the phases of the hot path: bound lazily, so the library has no hard
+// dependency on the profiler's marker library; visible with `rocprofv3 --marker-trace`.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) { push = nullptr; pop = nullptr; }
+  }
+};
+static RoctxApi& roctx() { static RoctxApi api; return api; }
+static const char* const kPhaseNames[PH_COUNT] = {"gsi:A*X", "gsi:A'*X", "gsi:lu(Y).L", "gsi:thin QR", "gsi:svd(l x l)",
+                                                 "gsi:panel x (l x l)", "gsi:collective", "gsi:other"};
+
 class HipBackend : public Backend {
  public:
   explicit HipBackend(int device) : device_(device) {
@@ -575,6 +593,7 @@ class HipBackend : public Backend {
   void phase_begin(Phase p) override {
     if (!prof_) return;
     bind();
+    if (roctx().push) roctx().push(kPhaseNames[p]);
     cur_.phase = p;
     cur_.a = get_event();
     cur_.b = get_event();
@@ -582,6 +601,7 @@ class HipBackend : public Backend {
   }
   void phase_end(Phase) override {
     if (!prof_) return;
+    if (roctx().pop) roctx().pop();
     hipEventRecord(cur_.b, st_);
     records_.push_back(cur_);
   }

@@ -13,6 +13,7 @@
 // inner products by wavefront shuffles -- then writes the block back.  l <= 2*SVD_W needs
 // a single workgroup and no inter-workgroup traffic at all.
 #include "hip_common.hpp"
+#include <cstdlib>
 #include <cfloat>
 
 namespace gsi { namespace hipk {
@@ -185,6 +186,10 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
 // (LDS: columns x (l padded) x 8 B <= 160 KB); l <= SVD_MAX_L = 5000.
 int svd_small(hipStream_t st, double* G, int64_t l64, double* U, double* S, const SvdWork& w) {
   const int l = (int)l64;
+  static const int forced = getenv("GSI_SVD_W") ? atoi(getenv("GSI_SVD_W")) : 0;      // A/B knob
+  if (forced == 16 && l <= 600) return svd_small_impl<16>(st, G, l, U, S, w);
+  if (forced == 8 && l <= 1200) return svd_small_impl<8>(st, G, l, U, S, w);
+  if (forced == 4 && l <= 2500) return svd_small_impl<4>(st, G, l, U, S, w);
   if (l <= 600) return svd_small_impl<16>(st, G, l, U, S, w);
   if (l <= 1200) return svd_small_impl<8>(st, G, l, U, S, w);
   if (l <= 2500) return svd_small_impl<4>(st, G, l, U, S, w);
