@@ -90,6 +90,11 @@ class Backend {
   // (stacked R factors of the TSQR, gathered panels): the backend must then not let anything rank-local
   // (e.g. which algorithm tier an earlier rank-local panel needed) steer the choice of algorithm.
   virtual void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R, bool replicated = false) = 0;
+  // thin SVD of a tall W (n x l, ld) in one go, W untouched: V (n x l, ldv) = left singular vectors (scaled by sqrt(S_i)
+  // for i < K_scale, zero beyond, when K_scale >= 0), S (l).  A backend may decline (false): the caller then runs
+  // qr_thinQ + svd_small + the l x l product itself.  The HIP backend fuses the last product of CholeskyQR2 with the
+  // product by the small factor: Z = T (R2^-1 U sqrt(S)) -- one tall product instead of two.
+  virtual bool svd_tall_fused(const double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, double*) { return false; }
   // G (l x l, ld l), columns orthogonalised in place by one-sided Jacobi; on return
   // U (l x l) = left singular vectors sorted by descending S, S (l) singular values.
   virtual void svd_small(double* G, int64_t l, double* U, double* S) = 0;

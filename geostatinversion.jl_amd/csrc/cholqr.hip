@@ -273,6 +273,15 @@ void cholqr2_apply(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld
     hipLaunchKernelGGL(cq_triprod_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, b.R2, b.R1, l, R);
 }
 
+// after cholqr2_factor: R (l x l) <- R2 R1, and where R2^-1 lives in the small workspace (svd(B) without the thin Q:
+// hip_backend.hip:svd_tall_fused)
+void cholqr2_R(hipStream_t st, int64_t l64, double* small, double* R) {
+  const int l = (int)l64;
+  const CqBufs b = cq_bufs(small, l);
+  hipLaunchKernelGGL(cq_triprod_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, b.R2, b.R1, l, R);
+}
+const double* cholqr2_X2(const double* small, int64_t l) { return small + 5 * (size_t)l * (size_t)l; }
+
 // Shifted CholeskyQR3, the tier between CholeskyQR2 and Householder: panels with cond up to ~1e15 (sketches of
 // fast-decaying covariance spectra after the power iterations).  Y -> T (shifted round) -> S (plain round); third
 // Gram matrix, its orthogonality check, R3 and R3^-1.  Y is NOT modified.  Afterwards flag != 0 means "not trusted".

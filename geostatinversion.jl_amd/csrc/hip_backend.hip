@@ -75,7 +75,7 @@ class HipBackend : public Backend {
   ~HipBackend() override {
     hipSetDevice(device_);
     hipStreamSynchronize(st_);
-    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_}) if (b->p) hipFree(b->p);
+    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_, &ws_svdf_}) if (b->p) hipFree(b->p);
     for (auto& b : pool_) hipFree(b.p);
     for (auto& ev : ev_pool_) hipEventDestroy(ev);
     for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -164,7 +164,7 @@ class HipBackend : public Backend {
     }
   }
   int64_t bytes_in_use() const override {
-    return in_use_ + pooled_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes + ws_blas2_.bytes);
+    return in_use_ + pooled_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes + ws_blas2_.bytes + ws_svdf_.bytes);
   }
   void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) override {
     if (rows <= 0 || cols <= 0) return;
@@ -450,6 +450,55 @@ class HipBackend : public Backend {
     hipk::qr_thinQ(st_, Y, m, l, ld, R, w, ws);
     check_launch("qr_thinQ");
   }
+  // svd(B) for B = W' (RandMatFact.jl:86-88) without forming the thin Q of W: CholeskyQR2's first round leaves
+  // T = W R1^-1 and R2, R2^-1; R = R2 R1 goes to the Jacobi SVD, and Z = T (R2^-1 (U sqrt(S))) is ONE tall product
+  // (the generic path runs Y = T R2^-1 and Z = Y (U sqrt(S)): two).  Declines when CholeskyQR2 does not apply.
+  bool svd_tall_fused(const double* W, int64_t m, int64_t l, int64_t ld, int64_t K_scale, double* V, int64_t ldv,
+                      double* S) override {
+    bind();
+    static const bool off = (getenv("GSI_NO_CHOLQR") != nullptr) || (getenv("GSI_NO_SVD_FUSION") != nullptr);
+    if (off || l > 1024 || m < 2 * l) return false;
+    int& skip_tier1 = skip_tier1_by_height_[std::make_pair(m, false)];
+    if (skip_tier1 > 0) return false;                       // this kind of panel needs the shifted tier: generic path
+    const int64_t ldt = (m + 1) & ~(int64_t)1;
+    size_t cnt = 0;
+    auto take = [&](size_t c) { size_t o = cnt; cnt += (c + 7) & ~(size_t)7; return o; };
+    const size_t o_small = take(hipk::cholqr_small_doubles(l)), o_R = take((size_t)l * l), o_U = take((size_t)l * l),
+                 o_M = take((size_t)l * l), o_T = take((size_t)ldt * l);
+    grow(ws_svdf_, cnt * sizeof(double));
+    double* base = (double*)ws_svdf_.p;
+    size_t gmax = hipk::gemm_workspace_doubles(l, l, m);
+    gmax = std::max(gmax, hipk::gemm_syrk_workspace_doubles(l, m));
+    gmax = std::max(gmax, hipk::gemm_workspace_doubles(m, l, l));
+    gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, 32, l));
+    gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, l, l));
+    double* ws = gemm_ws(gmax + 64);
+    int32_t f = 0;
+    phase_begin(PH_QR);
+    HIP_CHECK(hipMemsetAsync(flags_ + 9, 0, sizeof(int32_t), st_));
+    hipk::cholqr2_factor(st_, W, m, l, ld, base + o_T, ldt, base + o_small, flags_ + 9, ws);
+    check_launch("cholqr2_factor");
+    HIP_CHECK(hipMemcpyAsync(&f, flags_ + 9, sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    if (f != 0) {
+      phase_end(PH_QR);
+      skip_tier1 = 8;
+      return false;                                         // W is untouched: the caller's generic path takes over
+    }
+    hipk::cholqr2_R(st_, l, base + o_small, base + o_R);    // R = R2 R1
+    phase_end(PH_QR);
+    ++n_cholqr_;
+    phase_begin(PH_SVD);
+    svd_small(base + o_R, l, base + o_U, S);
+    if (K_scale >= 0) hipk::scale_cols_sqrt(st_, base + o_U, l, S, K_scale);
+    phase_end(PH_SVD);
+    phase_begin(PH_SMALL_GEMM);
+    hipk::gemm_f64(st_, false, l, l, l, 1.0, hipk::cholqr2_X2(base + o_small, l), l, base + o_U, l, 0.0, base + o_M, l, ws);
+    hipk::gemm_f64(st_, false, m, l, l, 1.0, base + o_T, ldt, base + o_M, l, 0.0, V, ldv, ws);
+    check_launch("svd_tall_fused");
+    phase_end(PH_SMALL_GEMM);
+    return true;
+  }
   void svd_small(double* G, int64_t l, double* U, double* S) override {
     bind();
     if (l > 5000) throw Error(GSI_ERR_ARG, "sketch width l = K+p > 5000 is not supported by the LDS-resident block Jacobi SVD");
@@ -664,7 +713,7 @@ class HipBackend : public Backend {
   hipStream_t st_ = nullptr;
   int32_t* flags_ = nullptr;  // [0] lu info, [1] chol info, [8] jacobi rotation counter
   double* scal_ = nullptr;
-  DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_, ws_blas2_, ws_lus_;
+  DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_, ws_blas2_, ws_lus_, ws_svdf_;
   std::mutex mu_;
   std::vector<DevBuf> sizes_;
   std::vector<DevBuf> pool_;

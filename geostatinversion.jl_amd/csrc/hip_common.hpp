@@ -110,6 +110,8 @@ void cholqr2_factor(hipStream_t st, const double* Y, int64_t m, int64_t l, int64
                     double* small_ws, int32_t* flag, double* gemm_ws);
 void cholqr2_apply(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const double* T, int64_t ldt,
                    double* R, double* small_ws, double* gemm_ws);
+void cholqr2_R(hipStream_t st, int64_t l, double* small_ws, double* R);         // R = R2 R1 after cholqr2_factor
+const double* cholqr2_X2(const double* small_ws, int64_t l);                    // R2^-1 (l x l) after cholqr2_factor
 void scholqr3_factor(hipStream_t st, const double* Y, int64_t m, int64_t l, int64_t ld, double* T, int64_t ldt,
                      double* S, int64_t lds, double* small_ws, int32_t* flag, double* gemm_ws);
 void scholqr3_apply(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const double* S, int64_t lds,

@@ -397,6 +397,7 @@ Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
 
 void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, double* V, double* S) {
   Backend* be = c.be.get();
+  if (!c.comm && V != W && be->svd_tall_fused(W, n, l, n, K_scale, V, n, S)) return;   // :86-88 in one pass (single rank)
   Buf R(be, (size_t)l * l), U(be, (size_t)l * l);
   {
     ScopedPhase ph(be, PH_QR);
