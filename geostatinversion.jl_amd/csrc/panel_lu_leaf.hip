@@ -139,7 +139,7 @@ template <int BS, int R>
 __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int64_t ld, int32_t m, int32_t l,
                                                      int32_t jb, int32_t j0, int w, unsigned long long* __restrict__ recs,
                                                      uint32_t epoch_base, int32_t* __restrict__ ipiv,
-                                                     int32_t* __restrict__ info) {
+                                                     int32_t* __restrict__ info, int onehop) {
   constexpr int NW = BS / 64;
   constexpr int LPR = BS / 256;               // leader: consumer lanes per record (G <= 256 records)
   constexpr int GPL = (2 * (2 + LW)) / LPR;   // leader: granules per consumer lane
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
   __shared__ int32_t c_idx[NW];
   __shared__ uint32_t c_rowbits[NW][2 * LW];  // the wave-local winner's 8 row values as 16 halves
   __shared__ uint32_t c_oldbits[2 * LW];
+  __shared__ int32_t c_slot[NW];
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x, G = gridDim.x;
@@ -299,11 +300,84 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    // (c) leader: sweep all records, reduce, publish the result; everyone else: poll the result
-    const bool leader = (g == G - 1);
+    // (c) the exchange.  Two protocols (GSI_LU_ONEHOP selects):
+    //  one hop (default): every workgroup reads the (value, row) head of every record itself (3 granules each: 6 KB per
+    //            workgroup and round), reduces, then fetches the winner's row values (landed long before) and row j;
+    //            measured 5.6-6.5 us per step, LU 7.35 ms at n = 1e6, l = 320;
+    //  two hops: a leader sweeps all WHOLE records, reduces, publishes the result; everyone else polls the result:
+    //            6.5-7.5 us per step (7.7 ms).  (Every workgroup sweeping all whole records -- 40 KB each -- 14.7 us.)
+    const bool leader = (g == G - 1) && !onehop;
     // the result is published in LU2_RES_COPIES copies on lines of their own; workgroup g polls copy g % LU2_RES_COPIES
     // (255 workgroups polling the same three lines serialise on one memory channel)
     unsigned long long* res = recs + (size_t)2 * (size_t)G * REC + (size_t)(epoch & 1u) * (size_t)LU2_RES_COPIES * REC;
+    if (onehop) {
+      const int ncw1 = (G + 63) / 64;                                      // one lane per record
+      if (wave < ncw1) {
+        const bool mine = tid < G;
+        const unsigned long long* src = rec_set + (size_t)(mine ? tid : 0) * REC;
+        const bool extra = tid < 2 * LW;                                    // workgroup 0's copy of row j
+        const unsigned long long* xsrc = rec_set + 2 * (2 + LW) + (extra ? tid : 0);
+        unsigned long long g0 = 0, g1 = 0, g2 = 0, gx = 0;
+        int tries = s_abort ? POLL_LIMIT : 0;
+        bool ok;
+        for (;;) {
+          if (mine) {
+            g0 = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (extra) gx = __hip_atomic_load(xsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = !mine || ((uint32_t)(g0 >> 32) == epoch && (uint32_t)(g1 >> 32) == epoch && (uint32_t)(g2 >> 32) == epoch);
+          if (extra) ok = ok && ((uint32_t)(gx >> 32) == epoch);
+          if (__all(ok)) break;
+          if (++tries > POLL_LIMIT) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!__all(ok)) s_abort = 1;
+        LU_STAMP(2);
+        if (extra) c_oldbits[tid] = (uint32_t)gx;
+        double cv = -1.0;
+        int32_t ci = -1;
+        if (mine) {
+          cv = __longlong_as_double((long long)(((unsigned long long)(uint32_t)g1 << 32) | (uint32_t)g0));
+          ci = (int32_t)(uint32_t)g2;
+        }
+        double rv = cv;
+        int32_t ri = ci;
+        wave_argmax(rv, ri);
+        if (mine && ri >= 0 && ci == ri) c_slot[wave] = tid;              // the record that holds the wave's winner
+        if (lane == 0) { c_val[wave] = rv; c_idx[wave] = ri; }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        double fv = (lane < ncw1) ? c_val[lane] : -1.0;
+        int32_t fi = (lane < ncw1) ? c_idx[lane] : -1;
+        const int32_t myfi = fi;
+        wave_argmax8(fv, fi);
+        const unsigned long long own = __ballot(lane < ncw1 && fi >= 0 && myfi == fi);
+        const int fw = own ? (__ffsll((long long)own) - 1) : 0;
+        const int gw = (fi >= 0) ? c_slot[fw] : 0;
+        // the winner's 8 row values: granules 4 .. 20 of its record, one per lane (they were stored with the head)
+        const bool mine = lane < 2 * LW;
+        const unsigned long long* rsrc = rec_set + (size_t)gw * REC + 4 + (mine ? lane : 0);
+        unsigned long long gv = 0;
+        int tries = s_abort ? POLL_LIMIT : 0;
+        bool ok;
+        for (;;) {
+          if (mine) gv = __hip_atomic_load(rsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = !mine || ((uint32_t)(gv >> 32) == epoch);
+          if (__all(ok)) break;
+          if (++tries > POLL_LIMIT) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!__all(ok)) s_abort = 1;
+        LU_STAMP(3);
+        if (mine) c_rowbits[0][lane] = (uint32_t)gv;
+        if (lane == 0) { c_val[0] = fv; c_idx[0] = fi; }
+      }
+      __syncthreads();
+    } else
+    {
     const int ncw = leader ? (G * LPR + 63) / 64 : 1;                     // waves that hold entries of the reduction
     if (leader) {
       const int slot = tid / LPR, part = tid % LPR;
@@ -402,6 +476,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
         else if (lane >= 4 + 2 * LW && lane < 4 + 4 * LW) c_oldbits[lane - 4 - 2 * LW] = (uint32_t)gv;
       }
       __syncthreads();
+    }
     }
     LU_STAMP(4);
     // (d) the result: slot 0 of the LDS image
@@ -626,8 +701,9 @@ bool lu2_config(int64_t m, int ncus, int* bs, int* rpt, int* grid) {
 template <int BS, int R>
 static void launch_leaf(hipStream_t st, int grid, double* Y, int64_t ld, int64_t m, int64_t l, int64_t jb, int64_t j0,
                         int w, unsigned long long* recs, uint32_t epoch_base, int32_t* ipiv, int32_t* info) {
+  static const int onehop = getenv("GSI_LU_ONEHOP") ? atoi(getenv("GSI_LU_ONEHOP")) : 1;   // A/B knob; 0 = two hops via a leader
   hipLaunchKernelGGL((lu_leaf_kernel<BS, R>), dim3(grid), dim3(BS), 0, st, Y, ld, (int32_t)m, (int32_t)l, (int32_t)jb,
-                     (int32_t)j0, w, recs, epoch_base, ipiv, info);
+                     (int32_t)j0, w, recs, epoch_base, ipiv, info, onehop);
 }
 
 void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu2Work& w) {
