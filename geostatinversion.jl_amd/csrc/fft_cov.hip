@@ -22,154 +22,365 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <stdexcept>
 #include "hip_common.hpp"
 
 namespace gsi { namespace hipk {
 
-__device__ inline double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ inline double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ inline double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 csqr(double2 a) { return make_double2(a.x * a.x - a.y * a.y, (a.x + a.x) * a.y); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 
-// One pass: batched in-place 1-D transforms of length Ma (power of two) along one axis of the embedded grid.
+// One pass: batched 1-D transforms of length Ma (power of two) along one axis of the embedded grid.
 //   element k of line (inner, o):  W[inner + estride * k + off(o)],  inner < estride (all earlier axes, full length),
 //   o < R1 * R2 enumerates the LATER axes restricted to the original grid (i_b < N_b): off(o) = (o % R1) S1 + (o / R1) S2.
 // MODE bits: AXIS0 lines are contiguous (else a workgroup takes T neighbouring `inner`); LOADX the first forward
-// pass reads the two real columns of X; SCALE the last forward pass multiplies by the spectrum as it stores; STOREY
-// the last inverse pass writes the two real columns of Y.  sign = -1 forward, +1 inverse (unnormalised).
-enum { FFT_AXIS0 = 1, FFT_LOADX = 2, FFT_SCALE = 4, FFT_STOREY = 8 };
-constexpr int FFT_TW_LEN = 4096;     // longest supported line; the plan stores exp(-2 pi i k / 4096), k < 2048
+// pass reads the two real columns of X; STOREY the last inverse pass writes the two real columns of Y; INVERSE the sign
+// of a plain pass (+1, unnormalised); FUSED the LAST axis: forward transform, multiply by the spectrum, inverse
+// transform, all on the lines while they sit in LDS / registers -- the fully transformed array never exists in HBM.
+enum { FFT_AXIS0 = 1, FFT_LOADX = 2, FFT_FUSED = 4, FFT_STOREY = 8, FFT_INVERSE = 16 };
+constexpr int FFT_TW_LEN = 8192;     // longest supported line; the plan stores exp(-2 pi i k / 8192), k < 4096
+constexpr int FFT_MAX_TILE = 8192;   // points of a tile (T lines): 16 per thread, 512 threads, 128 KB of LDS
 struct FftPass {
-  int Ma, log2Ma, nin, nout, T;
+  int Ma, log2Ma, nin, nout, T, log2T, lstride;
   int64_t estride, R1, S1, R2, S2;
-  double sign;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(1024) void fft_pass_kernel(double2* __restrict__ W, int64_t Mtot, FftPass ps,
-                                                       const double* __restrict__ lam, const double* __restrict__ X,
-                                                       int64_t ldx, double* __restrict__ Y, int64_t ldy, int64_t N0,
-                                                       int64_t col0, int64_t l) {
-  constexpr bool AXIS0 = (MODE & FFT_AXIS0) != 0;
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt -- every global load and store in
+// flight -- which is exactly what the persistent pass must not do: the next item's loads and the previous item's
+// stores are meant to stay in flight across the butterflies.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// ---- the transform of one line: Stockham autosort, radix 16 in registers -------------------------------------------
+// A thread owns 16 points of its line: slot s <-> position jt + s * Ma/16 (jt = the thread's index within the line).
+// Every stage of a Stockham decimation-in-time transform reads exactly those positions whatever its radix R (the
+// inputs of butterfly jb = jt + c Ma/16, c < 16/R, are jb + r Ma/R = jt + (c + r 16/R) Ma/16), so a stage is
+//     load 16 slots | twiddle, 16/R R-point DFTs in registers | barrier | scatter to (jb - k) R + k + m Ns | barrier
+// with k = jb mod Ns, Ns = the product of the earlier radices.  Ma = 16^a * {1, 2, 4, 8}: a radix-16 stages and at
+// most one smaller one LAST, so a 2048-point line is three LDS round trips (the radix-2/4 butterflies this replaces
+// took six, and 60 % of their LDS cycles were bank conflicts).  Natural order in and out: no bit reversal anywhere,
+// and the last stage of a forward transform leaves the thread holding the very slots the first stage of the inverse
+// wants -- the fused pass multiplies by the spectrum in registers in between.
+// LDS banking: element i of a line lives at i ^ ((i >> 4) & 15) (16-byte elements, 16 to a 256-byte bank row).  The
+// loads are aligned runs of 16 consecutive elements per 16 lanes (a permutation within the row: conflict-free); the
+// scatter of the first stage (lane stride 16 elements) lands in 16 different rows at 16 different columns; later
+// stages scatter aligned runs again.
+__device__ __forceinline__ int swz(int i) { return i ^ ((i >> 4) & 15); }
+
+// W_16^(sgn * i) for i < 8, folded at compile time once the caller's loops are unrolled
+__device__ __forceinline__ double2 mul_w16(double2 v, int i, int sgn) {
+  if (i == 0) return v;
+  if (i == 4) return sgn > 0 ? make_double2(-v.y, v.x) : make_double2(v.y, -v.x);
+  const double C1 = 0.92387953251128673848, S1 = 0.38268343236508977173, H = 0.70710678118654752440;
+  const double c = (i == 1) ? C1 : (i == 2) ? H : (i == 3) ? S1 : (i == 5) ? -S1 : (i == 6) ? -H : -C1;
+  const double sa = (i == 1 || i == 7) ? S1 : (i == 2 || i == 6) ? H : C1;
+  const double s = sgn > 0 ? sa : -sa;
+  return make_double2(v.x * c - v.y * s, v.x * s + v.y * c);
+}
+
+// R-point DFT of a[0..R), natural order in and out: decimation in frequency, then the even/odd halves interleaved
+// (register renaming once everything is unrolled)
+template <int R, int SGN>
+__device__ __forceinline__ void dft_regs(double2* a) {
+  if constexpr (R > 1) {
+    constexpr int H = R / 2;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const double2 t = csub(a[i], a[i + H]);
+      a[i] = cadd(a[i], a[i + H]);
+      a[i + H] = mul_w16(t, i * (16 / R), SGN);
+    }
+    dft_regs<H, SGN>(a);
+    dft_regs<H, SGN>(a + H);
+    double2 t[R];
+#pragma unroll
+    for (int i = 0; i < H; ++i) { t[2 * i] = a[i]; t[2 * i + 1] = a[i + H]; }
+#pragma unroll
+    for (int i = 0; i < R; ++i) a[i] = t[i];
+  }
+}
+
+struct FftLine {            // what a thread knows about its line
+  double2* x;               // the line in LDS
+  const double2* tabA;      // W_Ma^a, a < 64 (forward sign)
+  const double2* tabB;      // W_Ma^(64 b)
+  int jt, tpl, L;           // index within the line, threads per line (Ma / points per thread), log2 Ma
+  bool act;                 // writes anything at all (a thread past the tile's lines only keeps the barriers company)
+};
+
+// twiddle and NB R-point DFTs over the slots c + r NB.  Ns = 1 << lNs.
+template <int R, int NB, int SGN>
+__device__ __forceinline__ void stage_compute(double2 (&v)[R * NB], const FftLine& f, int lNs) {
+  constexpr int LR = (R == 16) ? 4 : (R == 8) ? 3 : (R == 4) ? 2 : 1;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    double2 a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = v[c + r * NB];
+    if (lNs > 0) {
+      const int jb = f.jt + c * f.tpl;
+      const int k = jb & ((1 << lNs) - 1);
+      const int t = k << (f.L - lNs - LR);                // W_{Ns R}^k = W_Ma^t
+      double2 w1 = cmul(f.tabA[t & 63], f.tabB[t >> 6]);
+      if (SGN > 0) w1.y = -w1.y;
+      // W^r from the binary powers W, W^2, W^4, W^8 as it is needed: few live registers, short dependency chains
+      double2 pw[4];
+      pw[0] = w1;
+#pragma unroll
+      for (int b = 1; b < LR; ++b) pw[b] = csqr(pw[b - 1]);
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        double2 wr = make_double2(1.0, 0.0);
+        bool have = false;
+#pragma unroll
+        for (int b = 0; b < LR; ++b)
+          if (r & (1 << b)) { wr = have ? cmul(wr, pw[b]) : pw[b]; have = true; }
+        a[r] = cmul(a[r], wr);
+      }
+    }
+    dft_regs<R, SGN>(a);
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[c + m * NB] = a[m];
+  }
+}
+template <int R, int NB>
+__device__ __forceinline__ void stage_scatter(const double2 (&v)[R * NB], const FftLine& f, int lNs) {
+  constexpr int LR = (R == 16) ? 4 : (R == 8) ? 3 : (R == 4) ? 2 : 1;
+  if (!f.act) return;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    const int jb = f.jt + c * f.tpl;
+    const int k = jb & ((1 << lNs) - 1);
+    const int base = ((jb - k) << LR) + k;
+#pragma unroll
+    for (int m = 0; m < R; ++m) f.x[swz(base + (m << lNs))] = v[c + m * NB];
+  }
+}
+// positions >= nin are zero padding that was never written (zpad: the first stage of a forward transform)
+template <int P>
+__device__ __forceinline__ void stage_gather(double2 (&v)[P], const FftLine& f, bool zpad, int nin) {
+#pragma unroll
+  for (int s = 0; s < P; ++s) {
+    const int pos = f.jt + s * f.tpl;
+    const double2 t = f.x[swz(pos)];
+    v[s] = (zpad && pos >= nin) ? make_double2(0.0, 0.0) : t;
+  }
+}
+// The whole line transform: n16 radix-16 stages, then (LR > 0) one of radix 2^LR.  A thread holds P = 16 points, or the
+// whole line when it is shorter (SHORT: n16 = 0, P = 2^LR).  IN_REGS: the slots are already in v; OUT_REGS: leave the
+// result in the slots (else the line ends up in LDS, behind a barrier).
+template <int SGN, int LR, bool SHORT, bool IN_REGS, bool OUT_REGS>
+__device__ __forceinline__ void fft_line(double2 (&v)[SHORT ? (1 << LR) : 16], const FftLine& f, int n16, bool zpad, int nin) {
+  constexpr int P = SHORT ? (1 << LR) : 16;
+  constexpr int RF = (LR == 0) ? 16 : (1 << LR);           // the final stage
+  const int nfull = (LR == 0) ? n16 - 1 : n16;            // radix-16 stages that go back to LDS
+  int lNs = 0;
+  if constexpr (!SHORT) {
+    for (int s = 0; s < nfull; ++s) {
+      if (!(IN_REGS && s == 0)) stage_gather<16>(v, f, zpad && s == 0, nin);
+      stage_compute<16, 1, SGN>(v, f, lNs);
+      lds_barrier();            // every thread has gathered: the line may be overwritten
+      stage_scatter<16, 1>(v, f, lNs);
+      lds_barrier();
+      lNs += 4;
+    }
+  }
+  if (!(IN_REGS && nfull == 0)) stage_gather<P>(v, f, zpad && nfull == 0, nin);
+  stage_compute<RF, P / RF, SGN>(v, f, lNs);
+  if (!OUT_REGS) {
+    lds_barrier();
+    stage_scatter<RF, P / RF>(v, f, lNs);
+    lds_barrier();
+  }
+}
+
+// The workgroup is PERSISTENT over (column pair, tile) work items: while item t's butterflies run, item t+1's input
+// is on its way into registers and item t's results leave through stores nobody waits for (a one-shot kernel with
+// one 130 KB workgroup per CU serialised HBM load / butterflies / HBM store).  Workgroups of one XCD (blockIdx % 8)
+// take NEIGHBOURING tiles, so the 64-byte segments of a strided pass with 4 lines per tile complete each other's
+// 128-byte lines in the same L2.
+template <int MODE, int LR, bool SHORT>
+__global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, int64_t Mtot, FftPass ps,
+                                                      const double* __restrict__ lam, const double2* __restrict__ twg,
+                                                      const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
+                                                      int64_t ldy, int64_t N0, int64_t col0, int64_t l, int tiles, int nitems) {
+  constexpr bool AXIS0 = (MODE & FFT_AXIS0) != 0, LOADX = (MODE & FFT_LOADX) != 0, FUSED = (MODE & FFT_FUSED) != 0;
+  constexpr bool STOREY = (MODE & FFT_STOREY) != 0, INV = (MODE & FFT_INVERSE) != 0;
+  constexpr int SGN1 = INV ? 1 : -1;
+  constexpr int P = SHORT ? (1 << LR) : 16;             // points (slots) per thread: slot s <-> position jt + s tpl
+  constexpr int NPRE = INV ? P : P / 2;                 // a forward line is at most half full (Ma >= 2 N)
+  constexpr int NOUT = (INV || FUSED) ? P / 2 : P;      // and only the first N <= Ma/2 entries of an inverse survive
   extern __shared__ double2 fsm[];
-  const int Ma = ps.Ma, log2Ma = ps.log2Ma, T = ps.T;
-  double2* tw = fsm;                 // [Ma/2]
-  double2* buf = fsm + Ma / 2;       // [T][Ma + 1]   (+1: neighbouring lines start in different banks)
+  const int Ma = ps.Ma, L = ps.log2Ma, T = ps.T;
   const int tid = threadIdx.x, nth = blockDim.x;
-  const int lstride = Ma + 1;
-  double2* Wb = W + (int64_t)blockIdx.y * Mtot;
-  const int64_t ca = col0 + 2 * (int64_t)blockIdx.y, cb = ca + 1;
-  // twiddles exp(sign 2 pi i k / Ma) from the plan's table for the longest line (FFT_TW_LEN points): an L2 read
-  // instead of Ma/2 sincospi evaluations per workgroup
+  const int n16 = SHORT ? 0 : (L >> 2);
+  const int ltpl = SHORT ? 0 : L - 4;
+  FftLine f;
+  f.L = L;
+  f.tpl = 1 << ltpl;
+  f.tabA = fsm;
+  f.tabB = fsm + 64;
+  const int ntabB = Ma >= 128 ? (Ma >> 7) : 1;
+  double2* buf = fsm + 64 + ntabB;
+  const int jl = tid >> ltpl;                      // line of the tile
+  f.jt = tid & (f.tpl - 1);
+  f.x = buf + (jl < T ? jl : 0) * ps.lstride;
   {
-    const double2* twg = reinterpret_cast<const double2*>(lam + Mtot + 64);
     const int tstep = FFT_TW_LEN / Ma;
-    for (int k = tid; k < Ma / 2; k += nth) {
-      const double2 w = twg[k * tstep];
-      tw[k] = make_double2(w.x, -ps.sign * w.y);      // table holds the forward sign
-    }
+    const int half = Ma >= 2 ? Ma / 2 : 1;
+    if (tid < 64) fsm[tid] = twg[(tid < half ? tid : 0) * tstep];
+    for (int b = tid; b < ntabB; b += nth) fsm[64 + b] = twg[(b * 64 < half ? b * 64 : 0) * tstep];
   }
-  // tile -> first line; line j of the tile: AXIS0: outer o0 + j, else inner i0 + j of outer o0
-  const int64_t nouter = ps.R1 * ps.R2;
-  int64_t o0, i0 = 0;
-  int nlines;
-  if (AXIS0) {
-    o0 = (int64_t)blockIdx.x * T;
-    nlines = (int)((nouter - o0 < T) ? (nouter - o0) : T);
-  } else {
-    const int64_t tiles_per_outer = (ps.estride + T - 1) / T;
-    o0 = blockIdx.x / tiles_per_outer;
-    i0 = (blockIdx.x % tiles_per_outer) * T;
-    nlines = (int)((ps.estride - i0 < T) ? (ps.estride - i0) : T);
-  }
+  lds_barrier();
+  const int nouter = (int)(ps.R1 * ps.R2);
+  const int tiles_per_outer = AXIS0 ? 1 : (int)(ps.estride >> ps.log2T);
   auto off = [&](int64_t o) -> int64_t { return (o % ps.R1) * ps.S1 + (o / ps.R1) * ps.S2; };
-  const int64_t off0 = AXIS0 ? 0 : off(o0);
-  const unsigned shift = 32u - (unsigned)log2Ma;
-  if (ps.nin < Ma) {      // the padded part of the lines
-    for (int e = tid; e < nlines * lstride; e += nth) buf[e] = make_double2(0.0, 0.0);
-    __syncthreads();
-  }
-  // load k < nin, bit-reversed
-  for (int e = tid; e < nlines * ps.nin; e += nth) {
-    int j, k;
-    if (AXIS0) { k = e % ps.nin; j = e / ps.nin; } else { j = e % nlines; k = e / nlines; }
-    double2 v;
-    if (MODE & FFT_LOADX) {
-      const int64_t o = o0 + j;                          // (i1, i2) of the original grid
-      const int64_t i = k + N0 * ((o % ps.R1) + ps.R1 * (o / ps.R1));
-      v.x = X[i + ca * ldx];
-      v.y = (cb < l) ? X[i + cb * ldx] : 0.0;
+
+  struct Item { int64_t off0, lamoff; int pair, o0, i0, nlines; };
+  // item w of this workgroup's sequence; workgroups of one XCD walk neighbouring tiles
+  const int G = gridDim.x;
+  const int bperm = ((G & 7) == 0) ? ((int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
+  auto item_of = [&](int w) -> Item {
+    Item it;
+    it.pair = w / tiles;
+    const int tile = w - it.pair * tiles;
+    if (AXIS0) {
+      it.o0 = tile * T; it.i0 = 0; it.off0 = 0;
+      it.nlines = (nouter - it.o0 < T) ? (nouter - it.o0) : T;
+      it.lamoff = 0;
     } else {
-      const int64_t g = AXIS0 ? ((int64_t)k + off(o0 + j)) : (i0 + j + ps.estride * (int64_t)k + off0);
-      v = Wb[g];
+      it.o0 = tile / tiles_per_outer;
+      it.i0 = (tile - it.o0 * tiles_per_outer) << ps.log2T;
+      it.off0 = off(it.o0);
+      it.nlines = T;
+      it.lamoff = (int64_t)it.i0 * Ma;           // the spectrum of the last axis is stored line by line (transposed)
     }
-    buf[j * lstride + (int)(__brev((unsigned)k) >> shift)] = v;
-  }
-  __syncthreads();
-  // decimation in time on the bit-reversed lines.  Two radix-2 stages at a time (radix 4 in registers: 4 reads,
-  // 3 twiddles, 4 writes per 4 points instead of 8 + 4 + 8) -- the pass is as much LDS- as HBM-bound; one radix-2
-  // stage first when log2(Ma) is odd.
-  int st = 0;
-  if (log2Ma & 1) {
-    const int nbf = nlines * (Ma / 2);
-    for (int e = tid; e < nbf; e += nth) {
-      const int j = e / (Ma / 2), p = e % (Ma / 2);
-      double2* x = buf + j * lstride + 2 * p;
-      const double2 a = x[0], b = x[1];
-      x[0] = cadd(a, b);
-      x[1] = csub(a, b);
-    }
-    __syncthreads();
-    st = 1;
-  }
-  const int nq = nlines * (Ma / 4);
-  for (; st < log2Ma; st += 2) {
-    const int h = 1 << st;
-    const int tw1 = Ma >> (st + 1);      // twiddle stride of stage st   (block 2h)
-    const int tw2 = Ma >> (st + 2);      //                    stage st+1 (block 4h)
-    for (int e = tid; e < nq; e += nth) {
-      const int j = e / (Ma / 4), p = e % (Ma / 4);
-      const int q = p & (h - 1);
-      double2* x = buf + j * lstride + ((p >> st) << (st + 2)) + q;
-      const double2 w1 = tw[q * tw1], w2 = tw[q * tw2], w3 = tw[(q + h) * tw2];
-      const double2 a0 = x[0], a1 = cmul(w1, x[h]), a2 = x[2 * h], a3 = cmul(w1, x[3 * h]);
-      const double2 b0 = cadd(a0, a1), b1 = csub(a0, a1);
-      const double2 b2 = cmul(w2, cadd(a2, a3)), b3 = cmul(w3, csub(a2, a3));
-      x[0] = cadd(b0, b2);
-      x[2 * h] = csub(b0, b2);
-      x[h] = cadd(b1, b3);
-      x[3 * h] = csub(b1, b3);
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < nlines * ps.nout; e += nth) {
-    int j, k;
-    if (AXIS0) { k = e % ps.nout; j = e / ps.nout; } else { j = e % nlines; k = e / nlines; }
-    double2 v = buf[j * lstride + k];
-    if (MODE & FFT_STOREY) {
-      const int64_t o = o0 + j;
-      const int64_t i = k + N0 * ((o % ps.R1) + ps.R1 * (o / ps.R1));
-      Y[i + ca * ldy] = v.x;
-      if (cb < l) Y[i + cb * ldy] = v.y;
+    return it;
+  };
+  // the input a thread brings in for an item.  No predicate on the loads (an element past the end re-reads the last
+  // valid one and is dropped later): a conditional load is its own basic block, and the compiler then drains vmcnt
+  // between them -- serial HBM round trips.
+  auto fetch = [&](const Item& it, double2 (&pre)[NPRE]) {
+    if (AXIS0) {
+      const int64_t o = it.o0 + (jl < it.nlines ? jl : it.nlines - 1);
+      const int64_t lo = LOADX ? N0 * o : off(o);
+      const int64_t ca = col0 + 2 * it.pair, cb = (ca + 1 < l) ? ca + 1 : ca;
+      const double2* Wb = W + (int64_t)it.pair * Mtot;
+#pragma unroll
+      for (int r = 0; r < NPRE; ++r) {
+        const int pos = f.jt + r * f.tpl;
+        const int64_t i = lo + (pos < ps.nin ? pos : ps.nin - 1);
+        if (LOADX) pre[r] = make_double2(X[i + ca * ldx], X[i + cb * ldx]);
+        else pre[r] = Wb[i];
+      }
     } else {
-      const int64_t g = AXIS0 ? ((int64_t)k + off(o0 + j)) : (i0 + j + ps.estride * (int64_t)k + off0);
-      if (MODE & FFT_SCALE) { const double sc = lam[g]; v.x *= sc; v.y *= sc; }
-      Wb[g] = v;
+      const double2* Wb = W + (int64_t)it.pair * Mtot + it.off0 + it.i0;
+#pragma unroll
+      for (int i = 0; i < NPRE; ++i) {
+        const int e = tid + i * nth;
+        const int j = e & (T - 1), k = e >> ps.log2T;
+        pre[i] = Wb[j + ps.estride * (int64_t)(k < ps.nin ? k : ps.nin - 1)];
+      }
+    }
+  };
+
+  double2 pre[NPRE];
+  int w = bperm;
+  if (w < nitems) { const Item it = item_of(w); fetch(it, pre); }
+  for (; w < nitems; w += G) {
+    const Item it = item_of(w);
+    f.act = (jl < it.nlines);
+    double2 v[P];
+    // ---- this item's input: into the slots (contiguous lines) or into LDS (strided lines, line index fastest)
+    if (AXIS0) {
+      const int64_t ca = col0 + 2 * it.pair;
+#pragma unroll
+      for (int s = 0; s < P; ++s) {
+        if (s < NPRE) {
+          v[s] = (f.jt + s * f.tpl < ps.nin) ? pre[s] : make_double2(0.0, 0.0);
+          if (LOADX && ca + 1 >= l) v[s].y = 0.0;
+        } else {
+          v[s] = make_double2(0.0, 0.0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPRE; ++i) {
+        const int e = tid + i * nth;
+        const int j = e & (T - 1), k = e >> ps.log2T;
+        if (k < ps.nin) buf[j * ps.lstride + swz(k)] = pre[i];
+      }
+      lds_barrier();
+    }
+    // ---- the spectrum of this item's lines (P per thread, coalesced), then the NEXT item's input: both land
+    //      behind the butterflies
+    double lamv[FUSED ? P : 1];
+    if (FUSED) {
+      const double* lp = lam + it.lamoff + (int64_t)(f.act ? jl : 0) * Ma;
+#pragma unroll
+      for (int s = 0; s < P; ++s) lamv[s] = lp[f.jt + s * f.tpl];
+    }
+    if (w + G < nitems) { const Item nx = item_of(w + G); fetch(nx, pre); }
+    // ---- transforms
+    fft_line<SGN1, LR, SHORT, AXIS0, AXIS0 || FUSED>(v, f, n16, !INV, ps.nin);
+    if (FUSED) {
+#pragma unroll
+      for (int s = 0; s < P; ++s) { v[s].x *= lamv[s]; v[s].y *= lamv[s]; }
+      fft_line<1, LR, SHORT, true, AXIS0>(v, f, n16, false, 0);
+    }
+    // ---- results
+    if (AXIS0) {
+      if (f.act) {
+        const int64_t o = it.o0 + jl;
+        const int64_t ca = col0 + 2 * it.pair, cb = ca + 1;
+        double2* Wb = W + (int64_t)it.pair * Mtot + off(o);
+#pragma unroll
+        for (int s = 0; s < NOUT; ++s) {
+          const int pos = f.jt + s * f.tpl;
+          if (pos < ps.nout) {
+            if (STOREY) {
+              const int64_t i = pos + N0 * o;
+              Y[i + ca * ldy] = v[s].x;
+              if (cb < l) Y[i + cb * ldy] = v[s].y;
+            } else {
+              Wb[pos] = v[s];
+            }
+          }
+        }
+      }
+    } else {
+      double2* Wb = W + (int64_t)it.pair * Mtot + it.off0 + it.i0;
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        const int e = tid + i * nth;
+        const int j = e & (T - 1), k = e >> ps.log2T;
+        if (k < ps.nout) Wb[j + ps.estride * (int64_t)k] = buf[j * ps.lstride + swz(k)];
+      }
+      lds_barrier();      // the lines are free for the next item (the stores above are not waited for)
     }
   }
 }
 
-// lam[e] = (sum_i nu_i^2)^(beta/2), f_i = min(k_i, M_i - k_i), lam[0] = 0.
+// lam = (sum_i nu_i^2)^(beta/2), f_i = min(k_i, M_i - k_i), 0 at k = 0.
 // fftrf == 0: nu_i = f_i / M_i (cycles per grid spacing: the correlation length does not depend on the embedding);
 // fftrf != 0: nu_i = f_i, the INTEGER wavenumbers FFTRF.jl:86-89 + computesqrtS_f (:40-72) use on its 2N embedding.
+// Layout: the fused pass over the LAST axis reads the spectrum of a whole line at a time, so for d >= 2 it is stored
+// line by line -- lam[inner * M_last + k_last], inner = the linear index over the earlier axes (a plain transpose of
+// the natural order; lines = Mtot / M_last, mlast = M_last; lines = 1 keeps the natural order).
 __global__ __launch_bounds__(256) void fft_spectrum_kernel(double* __restrict__ lam, int64_t Mtot, int64_t M0, int64_t M1,
-                                                           int64_t M2, double beta, int fftrf) {
+                                                           int64_t M2, double beta, int fftrf, int64_t lines, int64_t mlast) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < Mtot; e += (int64_t)gridDim.x * 256) {
     const int64_t k0 = e % M0, r = e / M0, k1 = r % M1, k2 = r / M1;
     const double f0 = (double)((k0 <= M0 - k0) ? k0 : M0 - k0) / (fftrf ? 1.0 : (double)M0);
     const double f1 = (double)((k1 <= M1 - k1) ? k1 : M1 - k1) / (fftrf ? 1.0 : (double)M1);
     const double f2 = (double)((k2 <= M2 - k2) ? k2 : M2 - k2) / (fftrf ? 1.0 : (double)M2);
     const double k2sum = f0 * f0 + f1 * f1 + f2 * f2;
-    lam[e] = (k2sum > 0.0) ? pow(k2sum, 0.5 * beta) : 0.0;
+    lam[(e % lines) * mlast + e / lines] = (k2sum > 0.0) ? pow(k2sum, 0.5 * beta) : 0.0;
   }
 }
 
@@ -220,69 +431,107 @@ size_t fft_plan_doubles(const int64_t M[3]) { return (size_t)(M[0] * M[1] * M[2]
 void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3], double beta, int fftrf) {
   const int64_t Mtot = M[0] * M[1] * M[2];
   hipLaunchKernelGGL(fft_twiddle_kernel, dim3(FFT_TW_LEN / 2 / 256), dim3(256), 0, st, reinterpret_cast<double2*>(lam + Mtot + 64));
-  hipLaunchKernelGGL(fft_spectrum_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, M[0], M[1], M[2], beta, fftrf);
+  const int64_t mlast = (M[2] > 1) ? M[2] : ((M[1] > 1) ? M[1] : Mtot);      // d = 1: one line, natural order
+  hipLaunchKernelGGL(fft_spectrum_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, M[0], M[1], M[2], beta, fftrf,
+                     Mtot / mlast, mlast);
   hipLaunchKernelGGL(fft_sum_kernel, dim3(64), dim3(256), 0, st, lam, Mtot, part64);
   hipLaunchKernelGGL(fft_normalise_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, part64, 64);
 }
 
-template <int MODE>
-static void launch_pass(hipStream_t st, dim3 grid, int threads, size_t shmem, double2* W, int64_t Mtot, const FftPass& ps,
+template <int MODE, int LR, bool SHORT>
+static void launch_pass_k(hipStream_t st, int ncus, int threads, size_t shmem, double2* W, int64_t Mtot, const FftPass& ps,
                         const double* lam, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t N0, int64_t col0,
-                        int64_t l) {
+                        int64_t l, int64_t tiles, int64_t nitems) {
   static std::atomic<uint64_t> attr_mask{0};
   if (first_use_on_this_device(attr_mask))
-    (void)hipFuncSetAttribute((const void*)fft_pass_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-  hipLaunchKernelGGL((fft_pass_kernel<MODE>), grid, dim3(threads), shmem, st, W, Mtot, ps, lam, X, ldx, Y, ldy, N0, col0, l);
+    (void)hipFuncSetAttribute((const void*)fft_pass_kernel<MODE, LR, SHORT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+  // persistent workgroups over the (column pair, tile) items: as many as the chip holds at once
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fft_pass_kernel<MODE, LR, SHORT>, threads, shmem) != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  int64_t gx = (int64_t)ncus * per_cu;
+  if (gx > nitems) gx = nitems;
+  const double2* twg = reinterpret_cast<const double2*>(lam + Mtot + 64);
+  hipLaunchKernelGGL((fft_pass_kernel<MODE, LR, SHORT>), dim3((unsigned)gx), dim3(threads), shmem, st, W, Mtot, ps, lam, twg, X, ldx,
+                     Y, ldy, N0, col0, l, (int)tiles, (int)nitems);
+}
+// the kernel is specialised on the last radix (log2 Ma mod 4) and on lines shorter than 16 points
+template <int MODE>
+static void launch_pass(hipStream_t st, int ncus, int threads, size_t shmem, double2* W, int64_t Mtot, const FftPass& ps,
+                        const double* lam, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t N0, int64_t col0,
+                        int64_t l, int64_t tiles, int64_t nitems) {
+#define GSI_FFT_K(LR, SH) launch_pass_k<MODE, LR, SH>(st, ncus, threads, shmem, W, Mtot, ps, lam, X, ldx, Y, ldy, N0, col0, l, tiles, nitems)
+  const int lr = ps.log2Ma & 3;
+  if (ps.Ma < 16) {
+    if (lr == 1) GSI_FFT_K(1, true); else if (lr == 2) GSI_FFT_K(2, true); else GSI_FFT_K(3, true);
+  } else {
+    if (lr == 0) GSI_FFT_K(0, false); else if (lr == 1) GSI_FFT_K(1, false); else if (lr == 2) GSI_FFT_K(2, false); else GSI_FFT_K(3, false);
+  }
+#undef GSI_FFT_K
 }
 
-// one pass along `axis` (N, M: squeezed grid, axis 0 is never a singleton)
+// one pass along `axis` (N, M: squeezed grid, axis 0 is never a singleton); fused = forward, spectrum, inverse
 static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], const int64_t M[3], int axis, bool inverse,
-                     bool first_fwd, bool last_fwd, bool last_inv, const double* lam, const double* X, int64_t ldx,
+                     bool fused, bool loadx, bool storey, const double* lam, const double* X, int64_t ldx,
                      double* Y, int64_t ldy, int64_t col0, int64_t l) {
   const int64_t Mtot = M[0] * M[1] * M[2];
   FftPass ps;
   ps.Ma = (int)M[axis];
   ps.log2Ma = ilog2(ps.Ma);
   ps.nin = inverse ? ps.Ma : (int)N[axis];
-  ps.nout = inverse ? (int)N[axis] : ps.Ma;
-  ps.sign = inverse ? 1.0 : -1.0;
+  ps.nout = (inverse || fused) ? (int)N[axis] : ps.Ma;
   const int64_t stride[3] = {1, M[0], M[0] * M[1]};
   ps.estride = stride[axis];
   ps.R1 = 1; ps.S1 = 0; ps.R2 = 1; ps.S2 = 0;
   if (axis == 0) { ps.R1 = N[1]; ps.S1 = stride[1]; ps.R2 = N[2]; ps.S2 = stride[2]; }
   else if (axis == 1) { ps.R1 = N[2]; ps.S1 = stride[2]; }
-  // lines per workgroup (measured, tools/fft_budget_sweep.sh): contiguous lines need no neighbours -- <= 32 KB of
-  // LDS so that several workgroups per CU overlap their load / butterfly / store phases; strided lines want long
-  // segments (T up to 16 = 256 bytes) but still two workgroups per CU (<= 76 KB) -- except that fewer than 4 lines
-  // (64-byte segments) is worse than one workgroup per CU, so 2048-point lines (32 KB each) take 152 KB for T = 4.
-  const size_t line_bytes = (size_t)(ps.Ma + 1) * sizeof(double2);
-  static const int b0 = getenv("GSI_FFT_B0") ? atoi(getenv("GSI_FFT_B0")) : 32;
-  static const int b1 = getenv("GSI_FFT_B1") ? atoi(getenv("GSI_FFT_B1")) : 76;
-  const size_t twb = (size_t)ps.Ma / 2 * sizeof(double2);
-  auto lines_in = [&](size_t kb) -> int { return (kb * 1024 > twb + line_bytes) ? (int)((kb * 1024 - twb) / line_bytes) : 1; };
-  int T = lines_in((size_t)(axis == 0 ? b0 : b1));
-  if (axis != 0 && T < 4) { const int t2 = lines_in(152); T = t2 < 4 ? t2 : 4; }
-  if (T > 16) T = 16;
-  if (T < 1) T = 1;
-  ps.T = T;
-  const size_t shmem = twb + (size_t)T * line_bytes;
-  const int threads = ((int64_t)T * ps.Ma >= 4096) ? 1024 : (((int64_t)T * ps.Ma >= 2048) ? 512 : 256);
   const int64_t nouter = ps.R1 * ps.R2;
-  const int64_t tiles = (axis == 0) ? (nouter + T - 1) / T : ((ps.estride + T - 1) / T) * nouter;
-  dim3 grid((unsigned)tiles, (unsigned)nb);
-  const int64_t N0 = N[0];
-#define GSI_FFT_LAUNCH(MODE) launch_pass<MODE>(st, grid, threads, shmem, W, Mtot, ps, lam, X, ldx, Y, ldy, N0, col0, l)
+  // lines per workgroup, within 8192 points (16 per thread, 512 threads, 128 KB).  Contiguous lines need no neighbours:
+  // GSI_FFT_B0 KB of LDS so that several workgroups share a CU.  Strided lines want long segments: a power of two of
+  // neighbouring lines, up to 16 (256 bytes) within GSI_FFT_B1 KB, but at least 4 (64 bytes) whatever that costs.
+  static const int b0 = getenv("GSI_FFT_B0") ? atoi(getenv("GSI_FFT_B0")) : 64;
+  static const int b1 = getenv("GSI_FFT_B1") ? atoi(getenv("GSI_FFT_B1")) : 76;
+  const int64_t line_bytes = (int64_t)ps.Ma * (int64_t)sizeof(double2);
+  const int tmax = FFT_MAX_TILE / ps.Ma;            // >= 1: Ma <= 8192
+  int T;
   if (axis == 0) {
-    if (!inverse) {
-      if (first_fwd && last_fwd) GSI_FFT_LAUNCH(FFT_AXIS0 | FFT_LOADX | FFT_SCALE);
-      else if (first_fwd) GSI_FFT_LAUNCH(FFT_AXIS0 | FFT_LOADX);
-      else GSI_FFT_LAUNCH(FFT_AXIS0);
-    } else {
-      if (last_inv) GSI_FFT_LAUNCH(FFT_AXIS0 | FFT_STOREY);
-      else GSI_FFT_LAUNCH(FFT_AXIS0);
-    }
+    T = (int)((int64_t)b0 * 1024 / line_bytes);
+    if (T > tmax) T = tmax;
+    if (T > 32) T = 32;
+    if (T > nouter) T = (int)nouter;
+    if (T < 1) T = 1;
+    ps.log2T = 0;
+    ps.lstride = ps.Ma;
   } else {
-    if (!inverse && last_fwd) GSI_FFT_LAUNCH(FFT_SCALE);
+    int want = (int)((int64_t)b1 * 1024 / line_bytes);
+    if (want < 4) want = 4;
+    if (want > 16) want = 16;
+    if (want > tmax) want = tmax;
+    if (want > ps.estride) want = (int)ps.estride;   // estride is a power of two >= 4
+    T = 1; ps.log2T = 0;
+    while (2 * T <= want) { T *= 2; ++ps.log2T; }
+    ps.lstride = ps.Ma + (T >= 2 ? 16 / T : 0);      // line-fastest fills and drains: T lines x 16/T neighbours = 16 banks rows apart
+  }
+  ps.T = T;
+  const int tpl = ps.Ma >= 16 ? ps.Ma / 16 : 1;
+  const int threads = (T * tpl + 63) / 64 * 64;
+  if (threads > 512) throw std::runtime_error("fft_pass: tile exceeds 16 points per thread");
+  const int ntabB = ps.Ma >= 128 ? ps.Ma / 128 : 1;
+  const size_t shmem = ((size_t)64 + ntabB + (size_t)T * ps.lstride) * sizeof(double2);
+  const int64_t tiles = (axis == 0) ? (nouter + T - 1) / T : (ps.estride / T) * nouter;
+  const int64_t nitems = tiles * nb;
+  if (nitems >= ((int64_t)1 << 31)) throw std::runtime_error("fft_pass: too many work items");
+  static const int ncus = [] { int dev = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+  const int64_t N0 = N[0];
+#define GSI_FFT_LAUNCH(MODE) launch_pass<MODE>(st, ncus, threads, shmem, W, Mtot, ps, lam, X, ldx, Y, ldy, N0, col0, l, tiles, nitems)
+  if (axis == 0) {
+    if (fused) GSI_FFT_LAUNCH(FFT_AXIS0 | FFT_LOADX | FFT_FUSED | FFT_STOREY);     // d = 1
+    else if (!inverse && loadx) GSI_FFT_LAUNCH(FFT_AXIS0 | FFT_LOADX);
+    else if (inverse && storey) GSI_FFT_LAUNCH(FFT_AXIS0 | FFT_STOREY | FFT_INVERSE);
+    else throw std::runtime_error("fft_pass: axis 0 is always the first forward and the last inverse pass");
+  } else {
+    if (fused) GSI_FFT_LAUNCH(FFT_FUSED);
+    else if (inverse) GSI_FFT_LAUNCH(FFT_INVERSE);
     else GSI_FFT_LAUNCH(0);
   }
 #undef GSI_FFT_LAUNCH
@@ -290,6 +539,7 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
 
 // Y (n x l, ld ldy) = A X for the embedded-circulant covariance; W holds nb_max * Mtot complex doubles.
 // N, M are the SQUEEZED dimensions (singleton axes removed, trailing ones = 1): axis 0 is a real axis.
+// d passes forward, the last one fused with the spectrum and the first inverse pass, d - 1 passes back.
 void fft_cov_apply(hipStream_t st, const int64_t N[3], const int64_t M[3], const double* lam, double2* W, int nb_max,
                    int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy) {
   int d = 1;
@@ -299,9 +549,10 @@ void fft_cov_apply(hipStream_t st, const int64_t N[3], const int64_t M[3], const
   for (int64_t p0 = 0; p0 < npairs; p0 += nb_max) {
     const int nb = (int)((npairs - p0 < nb_max) ? (npairs - p0) : nb_max);
     const int64_t col0 = 2 * p0;
-    for (int a = 0; a < d; ++a)
-      fft_pass(st, W, nb, N, M, a, false, a == 0, a == d - 1, false, lam, X, ldx, Y, ldy, col0, l);
-    for (int a = d - 1; a >= 0; --a)
+    for (int a = 0; a < d - 1; ++a)
+      fft_pass(st, W, nb, N, M, a, false, false, a == 0, false, lam, X, ldx, Y, ldy, col0, l);
+    fft_pass(st, W, nb, N, M, d - 1, false, true, d == 1, d == 1, lam, X, ldx, Y, ldy, col0, l);
+    for (int a = d - 2; a >= 0; --a)
       fft_pass(st, W, nb, N, M, a, true, false, false, a == 0, lam, X, ldx, Y, ldy, col0, l);
   }
 }

@@ -231,9 +231,9 @@ class HipBackend : public Backend {
       if (N[a] == 1) continue;
       p->N[d] = N[a]; p->M[d] = hipk::fft_embed_size(N[a]);
       if (fftrf && p->M[d] != 2 * N[a])
-        throw Error(GSI_ERR_ARG, "FFTRF-convention covariance: the embedding is exactly 2 N per axis and the LDS transforms "
-                                 "are radix-2/4 -- every grid dimension must be a power of two");
-      if (p->M[d] > 4096) throw Error(GSI_ERR_ARG, "fft covariance: at most 2048 grid points per axis (a line must fit LDS)");
+        throw Error(GSI_ERR_ARG, "FFTRF-convention covariance: the embedding is exactly 2 N per axis and the line "
+                                 "transforms are power-of-two Stockham -- every grid dimension must be a power of two");
+      if (p->M[d] > 8192) throw Error(GSI_ERR_ARG, "fft covariance: at most 4096 grid points per axis (a line must fit LDS)");
       Mtot *= p->M[d];
       ++d;
     }
