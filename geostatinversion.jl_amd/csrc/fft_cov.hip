@@ -31,6 +31,10 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_doub
 __device__ __forceinline__ double2 csqr(double2 a) { return make_double2(a.x * a.x - a.y * a.y, (a.x + a.x) * a.y); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// Loads and stores by component: an assignment of the double2 STRUCT between address spaces becomes an llvm.memcpy,
+// and an array that is the source or target of one stays in scratch memory instead of registers.
+__device__ __forceinline__ double2 ld2(const double2* p) { return make_double2(p->x, p->y); }
+__device__ __forceinline__ void st2(double2* p, double2 v) { p->x = v.x; p->y = v.y; }
 
 // One pass: batched 1-D transforms of length Ma (power of two) along one axis of the embedded grid.
 //   element k of line (inner, o):  W[inner + estride * k + off(o)],  inner < estride (all earlier axes, full length),
@@ -43,7 +47,7 @@ enum { FFT_AXIS0 = 1, FFT_LOADX = 2, FFT_FUSED = 4, FFT_STOREY = 8, FFT_INVERSE 
 constexpr int FFT_TW_LEN = 8192;     // longest supported line; the plan stores exp(-2 pi i k / 8192), k < 4096
 constexpr int FFT_MAX_TILE = 8192;   // points of a tile (T lines): 16 per thread, 512 threads, 128 KB of LDS
 struct FftPass {
-  int Ma, log2Ma, nin, nout, T, log2T, lstride;
+  int Ma, log2Ma, nin, nout, T, log2T, lstride, log2es;
   int64_t estride, R1, S1, R2, S2;
 };
 
@@ -71,6 +75,9 @@ __device__ __forceinline__ void lds_barrier() {
 // scatter of the first stage (lane stride 16 elements) lands in 16 different rows at 16 different columns; later
 // stages scatter aligned runs again.
 __device__ __forceinline__ int swz(int i) { return i ^ ((i >> 4) & 15); }
+// A value the optimiser may not treat as loop-invariant: the per-element offsets and masks of an item's fill and drain
+// are cheap to recompute, and hoisted out of the persistent loop they occupied (and spilled) ~100 registers.
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
 // W_16^(sgn * i) for i < 8, folded at compile time once the caller's loops are unrolled
 __device__ __forceinline__ double2 mul_w16(double2 v, int i, int sgn) {
@@ -126,7 +133,7 @@ __device__ __forceinline__ void stage_compute(double2 (&v)[R * NB], const FftLin
       const int jb = f.jt + c * f.tpl;
       const int k = jb & ((1 << lNs) - 1);
       const int t = k << (f.L - lNs - LR);                // W_{Ns R}^k = W_Ma^t
-      double2 w1 = cmul(f.tabA[t & 63], f.tabB[t >> 6]);
+      double2 w1 = cmul(ld2(&f.tabA[t & 63]), ld2(&f.tabB[t >> 6]));
       if (SGN > 0) w1.y = -w1.y;
       // W^r from the binary powers W, W^2, W^4, W^8 as it is needed: few live registers, short dependency chains
       double2 pw[4];
@@ -158,7 +165,7 @@ __device__ __forceinline__ void stage_scatter(const double2 (&v)[R * NB], const 
     const int k = jb & ((1 << lNs) - 1);
     const int base = ((jb - k) << LR) + k;
 #pragma unroll
-    for (int m = 0; m < R; ++m) f.x[swz(base + (m << lNs))] = v[c + m * NB];
+    for (int m = 0; m < R; ++m) st2(&f.x[swz(base + (m << lNs))], v[c + m * NB]);
   }
 }
 // positions >= nin are zero padding that was never written (zpad: the first stage of a forward transform)
@@ -167,15 +174,18 @@ __device__ __forceinline__ void stage_gather(double2 (&v)[P], const FftLine& f, 
 #pragma unroll
   for (int s = 0; s < P; ++s) {
     const int pos = f.jt + s * f.tpl;
-    const double2 t = f.x[swz(pos)];
+    const double2 t = ld2(&f.x[swz(pos)]);
     v[s] = (zpad && pos >= nin) ? make_double2(0.0, 0.0) : t;
   }
 }
 // The whole line transform: n16 radix-16 stages, then (LR > 0) one of radix 2^LR.  A thread holds P = 16 points, or the
 // whole line when it is shorter (SHORT: n16 = 0, P = 2^LR).  IN_REGS: the slots are already in v; OUT_REGS: leave the
 // result in the slots (else the line ends up in LDS, behind a barrier).
-template <int SGN, int LR, bool SHORT, bool IN_REGS, bool OUT_REGS>
-__device__ __forceinline__ void fft_line(double2 (&v)[SHORT ? (1 << LR) : 16], const FftLine& f, int n16, bool zpad, int nin) {
+// `late` runs once, just before the final stage's butterflies (the pass issues the next item's loads there when it
+// cannot afford to hold them through the whole transform).
+template <int SGN, int LR, bool SHORT, bool IN_REGS, bool OUT_REGS, class Late>
+__device__ __forceinline__ void fft_line(double2 (&v)[SHORT ? (1 << LR) : 16], const FftLine& f, int n16, bool zpad, int nin,
+                                         Late late) {
   constexpr int P = SHORT ? (1 << LR) : 16;
   constexpr int RF = (LR == 0) ? 16 : (1 << LR);           // the final stage
   const int nfull = (LR == 0) ? n16 - 1 : n16;            // radix-16 stages that go back to LDS
@@ -191,6 +201,7 @@ __device__ __forceinline__ void fft_line(double2 (&v)[SHORT ? (1 << LR) : 16], c
     }
   }
   if (!(IN_REGS && nfull == 0)) stage_gather<P>(v, f, zpad && nfull == 0, nin);
+  late();
   stage_compute<RF, P / RF, SGN>(v, f, lNs);
   if (!OUT_REGS) {
     lds_barrier();
@@ -233,8 +244,8 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
   {
     const int tstep = FFT_TW_LEN / Ma;
     const int half = Ma >= 2 ? Ma / 2 : 1;
-    if (tid < 64) fsm[tid] = twg[(tid < half ? tid : 0) * tstep];
-    for (int b = tid; b < ntabB; b += nth) fsm[64 + b] = twg[(b * 64 < half ? b * 64 : 0) * tstep];
+    if (tid < 64) st2(&fsm[tid], ld2(&twg[(tid < half ? tid : 0) * tstep]));
+    for (int b = tid; b < ntabB; b += nth) st2(&fsm[64 + b], ld2(&twg[(b * 64 < half ? b * 64 : 0) * tstep]));
   }
   lds_barrier();
   const int nouter = (int)(ps.R1 * ps.R2);
@@ -276,15 +287,16 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
         const int pos = f.jt + r * f.tpl;
         const int64_t i = lo + (pos < ps.nin ? pos : ps.nin - 1);
         if (LOADX) pre[r] = make_double2(X[i + ca * ldx], X[i + cb * ldx]);
-        else pre[r] = Wb[i];
+        else pre[r] = ld2(&Wb[i]);
       }
     } else {
       const double2* Wb = W + (int64_t)it.pair * Mtot + it.off0 + it.i0;
+      const int t0 = opaque(tid);
 #pragma unroll
       for (int i = 0; i < NPRE; ++i) {
-        const int e = tid + i * nth;
+        const int e = t0 + i * nth;
         const int j = e & (T - 1), k = e >> ps.log2T;
-        pre[i] = Wb[j + ps.estride * (int64_t)(k < ps.nin ? k : ps.nin - 1)];
+        pre[i] = ld2(&Wb[j + ((int64_t)(k < ps.nin ? k : ps.nin - 1) << ps.log2es)]);
       }
     }
   };
@@ -309,11 +321,14 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
         }
       }
     } else {
+      const int t0 = opaque(tid);
 #pragma unroll
       for (int i = 0; i < NPRE; ++i) {
-        const int e = tid + i * nth;
+        const int e = t0 + i * nth;
         const int j = e & (T - 1), k = e >> ps.log2T;
-        if (k < ps.nin) buf[j * ps.lstride + swz(k)] = pre[i];
+        // unconditional: an element past nin lands in the padding of its line, which the first gather never reads
+        // (predicated, the compiler kept pre[] in scratch memory and reloaded it element by element)
+        st2(&buf[j * ps.lstride + swz(k < Ma ? k : Ma - 1)], pre[i]);
       }
       lds_barrier();
     }
@@ -325,13 +340,21 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
 #pragma unroll
       for (int s = 0; s < P; ++s) lamv[s] = lp[f.jt + s * f.tpl];
     }
-    if (w + G < nitems) { const Item nx = item_of(w + G); fetch(nx, pre); }
+    // Where the next item's loads are issued: as early as possible, unless the registers they occupy are what spills
+    // the transform -- a fused pass holds the spectrum through its forward half and the prefetch through its inverse
+    // half; a strided inverse pass (16 elements per thread) issues them before its final stage.
+    constexpr bool PRE_LATE = !AXIS0 && INV && !FUSED;
+    auto prefetch = [&]() { if (w + G < nitems) { const Item nx = item_of(w + G); fetch(nx, pre); } };
+    auto nothing = []() {};
+    if (!FUSED && !PRE_LATE) prefetch();
     // ---- transforms
-    fft_line<SGN1, LR, SHORT, AXIS0, AXIS0 || FUSED>(v, f, n16, !INV, ps.nin);
+    if (PRE_LATE) fft_line<SGN1, LR, SHORT, AXIS0, AXIS0 || FUSED>(v, f, n16, !INV, ps.nin, prefetch);
+    else fft_line<SGN1, LR, SHORT, AXIS0, AXIS0 || FUSED>(v, f, n16, !INV, ps.nin, nothing);
     if (FUSED) {
 #pragma unroll
       for (int s = 0; s < P; ++s) { v[s].x *= lamv[s]; v[s].y *= lamv[s]; }
-      fft_line<1, LR, SHORT, true, AXIS0>(v, f, n16, false, 0);
+      prefetch();
+      fft_line<1, LR, SHORT, true, AXIS0>(v, f, n16, false, 0, nothing);
     }
     // ---- results
     if (AXIS0) {
@@ -348,18 +371,19 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
               Y[i + ca * ldy] = v[s].x;
               if (cb < l) Y[i + cb * ldy] = v[s].y;
             } else {
-              Wb[pos] = v[s];
+              st2(&Wb[pos], v[s]);
             }
           }
         }
       }
     } else {
       double2* Wb = W + (int64_t)it.pair * Mtot + it.off0 + it.i0;
+      const int t0 = opaque(tid);
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
-        const int e = tid + i * nth;
+        const int e = t0 + i * nth;
         const int j = e & (T - 1), k = e >> ps.log2T;
-        if (k < ps.nout) Wb[j + ps.estride * (int64_t)k] = buf[j * ps.lstride + swz(k)];
+        if (k < ps.nout) st2(&Wb[j + ((int64_t)k << ps.log2es)], ld2(&buf[j * ps.lstride + swz(k)]));
       }
       lds_barrier();      // the lines are free for the next item (the stores above are not waited for)
     }
@@ -482,6 +506,7 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
   ps.nout = (inverse || fused) ? (int)N[axis] : ps.Ma;
   const int64_t stride[3] = {1, M[0], M[0] * M[1]};
   ps.estride = stride[axis];
+  ps.log2es = ilog2(ps.estride);
   ps.R1 = 1; ps.S1 = 0; ps.R2 = 1; ps.S2 = 0;
   if (axis == 0) { ps.R1 = N[1]; ps.S1 = stride[1]; ps.R2 = N[2]; ps.S2 = stride[2]; }
   else if (axis == 1) { ps.R1 = N[2]; ps.S1 = stride[2]; }

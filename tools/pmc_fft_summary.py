@@ -8,7 +8,7 @@ for d in sorted(glob.glob(f"{root}/pmc_fft_{tag}_*/")):
         continue
     seen = set()
     for r in csv.DictReader(open(fs[0])):
-        m = re.search(r"fft_pass_kernel<(\d+)>", r["Kernel_Name"])
+        m = re.search(r"fft_pass_kernel<(\d+)[,>]", r["Kernel_Name"])
         if not m:
             continue
         k = "pass<%s>" % m.group(1)
