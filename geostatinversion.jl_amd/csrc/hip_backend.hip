@@ -75,7 +75,7 @@ class HipBackend : public Backend {
   ~HipBackend() override {
     hipSetDevice(device_);
     hipStreamSynchronize(st_);
-    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_, &ws_svdf_}) if (b->p) hipFree(b->p);
+    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_, &ws_svdf_, &ws_qr_hh_}) if (b->p) hipFree(b->p);
     for (auto& b : pool_) hipFree(b.p);
     for (auto& ev : ev_pool_) hipEventDestroy(ev);
     for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -164,7 +164,7 @@ class HipBackend : public Backend {
     }
   }
   int64_t bytes_in_use() const override {
-    return in_use_ + pooled_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes + ws_blas2_.bytes + ws_svdf_.bytes);
+    return in_use_ + pooled_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes + ws_blas2_.bytes + ws_svdf_.bytes + ws_qr_hh_.bytes);
   }
   void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) override {
     if (rows <= 0 || cols <= 0) return;
@@ -378,14 +378,15 @@ class HipBackend : public Backend {
     size_t cnt = 0;
     auto take = [&](size_t c) { size_t o = cnt; cnt += (c + 7) & ~(size_t)7; return o; };
     const size_t o_coef = take(2 + NB + 2), o_part = take((size_t)nb * NB), o_tau = take(l),
-                 o_T = take((size_t)npan * NB * NB), o_G = take(NB * NB), o_V = take((size_t)m * NB),
+                 o_T = take((size_t)npan * NB * NB), o_G = take(NB * NB),
                  o_Wt = take((size_t)l * NB), o_W2 = take((size_t)l * NB), o_small = take(hipk::cholqr_small_doubles(l)),
                  o_Q = take((size_t)(m + 1) * l);
     grow(ws_qr_, cnt * sizeof(double));
+    TrimGuard trim_qr{this, &ws_qr_}, trim_hh{this, &ws_qr_hh_};
     double* base = (double*)ws_qr_.p;
     hipk::QrWork w;
     w.coef = base + o_coef; w.part = base + o_part; w.tau = base + o_tau; w.T = base + o_T; w.G = base + o_G;
-    w.Vbuf = base + o_V; w.Wt = base + o_Wt; w.W2 = base + o_W2; w.Qo = base + o_Q; w.maxblocks = nb;
+    w.Vbuf = nullptr; w.Wt = base + o_Wt; w.W2 = base + o_W2; w.Qo = base + o_Q; w.maxblocks = nb;
     // gemm shapes inside: (t x NB, K = m), (NB x NB, K = m), (m x t, K = NB), (l x l, K = m), (m x 32, K <= l)
     size_t gmax = hipk::gemm_workspace_doubles(l, NB, m);
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(NB, NB, m));
@@ -447,6 +448,8 @@ class HipBackend : public Backend {
       skip_tier1_ = 0;   // neither Cholesky tier applies to this kind of panel: probe from the top next time
     }
     ++n_householder_;
+    grow(ws_qr_hh_, (size_t)m * NB * sizeof(double));       // the reflector block: only this tier needs it
+    w.Vbuf = (double*)ws_qr_hh_.p;
     hipk::qr_thinQ(st_, Y, m, l, ld, R, w, ws);
     check_launch("qr_thinQ");
   }
@@ -466,6 +469,7 @@ class HipBackend : public Backend {
     const size_t o_small = take(hipk::cholqr_small_doubles(l)), o_R = take((size_t)l * l), o_U = take((size_t)l * l),
                  o_M = take((size_t)l * l), o_T = take((size_t)ldt * l);
     grow(ws_svdf_, cnt * sizeof(double));
+    TrimGuard trim_svdf{this, &ws_svdf_};
     double* base = (double*)ws_svdf_.p;
     size_t gmax = hipk::gemm_workspace_doubles(l, l, m);
     gmax = std::max(gmax, hipk::gemm_syrk_workspace_doubles(l, m));
@@ -691,6 +695,15 @@ class HipBackend : public Backend {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) throw Error(GSI_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
   }
+  // Cached workspaces make repeated factorizations allocation-free; one of panel size at 512^3 (tens of GB) would
+  // instead starve the next phase, so anything above 8 GiB is given back when the call that grew it returns.
+  void trim(DevBuf& b) {
+    if (b.bytes <= ((size_t)8 << 30) || !b.p) return;
+    (void)hipStreamSynchronize(st_);
+    (void)hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+  }
+  struct TrimGuard { HipBackend* be; DevBuf* b; ~TrimGuard() { be->trim(*b); } };
   void grow(DevBuf& b, size_t bytes) {
     if (bytes <= b.bytes) return;
     HIP_CHECK(hipStreamSynchronize(st_));
@@ -713,7 +726,7 @@ class HipBackend : public Backend {
   hipStream_t st_ = nullptr;
   int32_t* flags_ = nullptr;  // [0] lu info, [1] chol info, [8] jacobi rotation counter
   double* scal_ = nullptr;
-  DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_, ws_blas2_, ws_lus_, ws_svdf_;
+  DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_, ws_blas2_, ws_lus_, ws_svdf_, ws_qr_hh_;
   std::mutex mu_;
   std::vector<DevBuf> sizes_;
   std::vector<DevBuf> pool_;

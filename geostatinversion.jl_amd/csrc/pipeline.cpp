@@ -387,10 +387,12 @@ Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
     op_mul(A, Z.p, n, l, yl, ldyl);                         // Q = A*Q                :70
     if (i < q) lu_y();                                      //                        :72-73
   }
+  Z.reset();                                                // the QR below wants a panel of its own (512^3: each is tens of GB)
   if (single) {
     tsqr(c, A, Yfull, l);                                   // pivoted-QR range       :75-76
     return Yfull;
   }
+  Yfull.reset();
   tsqr(c, A, Yloc, l);
   return Yloc;
 }
