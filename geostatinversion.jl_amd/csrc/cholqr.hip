@@ -221,8 +221,10 @@ inline CqBufs cq_bufs(double* small, int l) {
 void cq_round(hipStream_t st, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t m, int l, double* Rp,
               double* X, const CqBufs& b, bool check, int32_t* flag, double* gemm_ws, bool apply, bool shift = false) {
   const int nblk = (l + CQ_TB - 1) / CQ_TB;
-  gemm_f64_syrk_upper(st, l, m, src, lds, Rp, l, gemm_ws);                            // G = Y'Y (upper tiles)
-  hipLaunchKernelGGL(cq_mirror_upper_kernel, dim3(64), dim3(256), 0, st, Rp, l);
+  if (!syrk_full_from_upper(st, l, m, src, lds, Rp, l, gemm_ws)) {                    // G = Y'Y: panel read once (syrk_f64.hip)
+    gemm_f64_syrk_upper(st, l, m, src, lds, Rp, l, gemm_ws);                          //          or upper tiles of the general kernel
+    hipLaunchKernelGGL(cq_mirror_upper_kernel, dim3(64), dim3(256), 0, st, Rp, l);
+  }
   if (check)
     hipLaunchKernelGGL(cq_orth_check_kernel, dim3(grid_for((int64_t)l * l, 64)), dim3(256), 0, st, Rp, l, 0.1, flag);
   if (shift) hipLaunchKernelGGL(cq_shift_kernel, dim3(1), dim3(256), 0, st, Rp, l, (double)m);

@@ -392,6 +392,7 @@ class HipBackend : public Backend {
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(NB, NB, m));
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, l, m));
     gmax = std::max(gmax, hipk::gemm_syrk_workspace_doubles(l, m));     // CholeskyQR: Gram matrix, upper tiles only
+    gmax = std::max(gmax, hipk::syrk_upper_workspace_doubles(l, m));    //             : the dedicated kernel's slab partials
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(m, l, l));       // CholeskyQR2: Y R^-1 as one product
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, 32, l));      //             : the l x l inverse
     for (int64_t t = NB; t <= l; t += NB) gmax = std::max(gmax, hipk::gemm_workspace_doubles(t, NB, m));
@@ -473,6 +474,7 @@ class HipBackend : public Backend {
     double* base = (double*)ws_svdf_.p;
     size_t gmax = hipk::gemm_workspace_doubles(l, l, m);
     gmax = std::max(gmax, hipk::gemm_syrk_workspace_doubles(l, m));
+    gmax = std::max(gmax, hipk::syrk_upper_workspace_doubles(l, m));
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(m, l, l));
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, 32, l));
     gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, l, l));

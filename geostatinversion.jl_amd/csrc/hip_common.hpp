@@ -23,6 +23,9 @@ void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, doub
               int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws);
 // C (l x l) = A'A, upper-triangle tiles only; C = A * B with B upper triangular (CholeskyQR: half the flops each)
 size_t gemm_syrk_workspace_doubles(int64_t l, int64_t m);
+// syrk_f64.hip: G = A'A (both triangles) for l <= 320 by the register-resident kernel; false = shape not covered
+size_t syrk_upper_workspace_doubles(int64_t l, int64_t m);
+bool syrk_full_from_upper(hipStream_t st, int64_t l, int64_t m, const double* Y, int64_t ld, double* G, int64_t ldg, double* ws);
 void gemm_f64_syrk_upper(hipStream_t st, int64_t l, int64_t m, const double* A, int64_t lda, double* C, int64_t ldc,
                          double* ws);
 void gemm_f64_trmm_upper(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A, int64_t lda, const double* B,

@@ -1,0 +1,236 @@
+// syrk_f64.hip -- G = Y'Y for a tall panel (m x l, l <= 320): the Gram matrix of CholeskyQR (cholqr.hip), upper
+// triangle computed once, mirrored on the way out.
+//
+// Why not the general contraction kernel (gemm_f64.hip, tri = 1): its 128 x 160 output tiles cover a 320 x 320 upper
+// triangle with 5 tiles = 102 400 MFMA outputs where 51 360 are needed, and every tile streams its two operand column
+// blocks from HBM / L2 again (7.7 GB for a 2.56 GB panel): 4.2 ms per Gram matrix at n = 10^6, l = 320, a quarter of
+// the step's QR time.  Here the panel is read ONCE per half: a workgroup owns a slab of rows and HALF of the upper
+// 16 x 16 blocks (105 of 210 at l = 320 -- block rows 0..5 are exactly half), all of them accumulating in registers
+// (13-14 blocks = 112 accumulator registers per wave, 8 waves), so the kernel is bound by the matrix pipe at the
+// minimum flop count: 210 blocks x 256 x 2 x m.
+//   LDS:   chunks of 16 panel rows, [k][column] with an odd row stride (conflict-free for the k-fastest stores and the
+//          column-fastest fragment reads), double buffered; the next chunk travels HBM -> registers while this one feeds
+//          the MFMAs.
+//   MFMA:  v_mfma_f64_16x16x4_f64; the A and B fragments of a symmetric product are the SAME registers (fragment b =
+//          rows k..k+3 of columns 16 b .. 16 b + 15), loaded once per k-step for the block rows and columns the wave needs.
+//   Out:   per-slab partial blocks in the fragment layout, summed over slabs in a fixed order (deterministic, no atomics)
+//          by sy_reduce_kernel, which also writes the mirrored lower triangle.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <utility>
+#include "hip_common.hpp"
+
+namespace gsi { namespace hipk {
+
+typedef double sy_double4 __attribute__((ext_vector_type(4)));
+
+constexpr int SY_KC = 16;          // panel rows per chunk
+constexpr int SY_WAVES = 8;
+constexpr int SY_THREADS = 64 * SY_WAVES;
+constexpr int SY_SLABS = 128;      // x 2 halves = one workgroup per CU
+
+// the upper 16 x 16 blocks in row-major order: t -> (bi, bj >= bi)
+template <int NB>
+struct SyGeom {
+  static constexpr int NBLK = NB * (NB + 1) / 2;
+  static constexpr int LDW = 16 * NB + 1;                   // odd row stride of the LDS chunk
+  static constexpr int row_start(int bi) { return bi * NB - bi * (bi - 1) / 2; }
+  static constexpr int split_row() { int r = 0; while (row_start(r) * 2 < NBLK) ++r; return r; }   // half 1 starts here
+  static constexpr int bi_of(int t) { int bi = 0; while (row_start(bi + 1) <= t) ++bi; return bi; }
+  static constexpr int bj_of(int t) { return bi_of(t) + (t - row_start(bi_of(t))); }
+  static constexpr int half_begin(int h) { return h ? row_start(split_row()) : 0; }
+  static constexpr int half_end(int h) { return h ? NBLK : row_start(split_row()); }
+  static constexpr int per_wave(int h) { return (half_end(h) - half_begin(h) + SY_WAVES - 1) / SY_WAVES; }
+  static constexpr int wave_begin(int h, int w) {
+    const int b = half_begin(h) + w * per_wave(h);
+    return b < half_end(h) ? b : half_end(h);
+  }
+  static constexpr int wave_end(int h, int w) {
+    const int e = half_begin(h) + (w + 1) * per_wave(h);
+    return e < half_end(h) ? e : half_end(h);
+  }
+  static constexpr bool needs(int h, int w, int b) {       // does wave w of half h touch fragment b?
+    for (int t = wave_begin(h, w); t < wave_end(h, w); ++t)
+      if (bi_of(t) == b || bj_of(t) == b) return true;
+    return false;
+  }
+  static constexpr int col_lo(int h) { return h ? 16 * split_row() : 0; }   // half 1 never reads the first columns
+};
+
+// Geometry as template arguments: everything below folds at compile time (written as constexpr calls inside unrolled
+// loops the front end left the searches in bi_of / needs to the optimiser: a 227 000-line kernel that ran 100x slow).
+template <int NB, int H, int W, int B>
+__device__ __forceinline__ void sy_ld(double (&F)[NB], const double* p) {
+  if constexpr (SyGeom<NB>::needs(H, W, B)) F[B] = p[16 * B];
+}
+template <int NB, int H, int W, int... B>
+__device__ __forceinline__ void sy_ld_all(double (&F)[NB], const double* p, std::integer_sequence<int, B...>) {
+  (sy_ld<NB, H, W, B>(F, p), ...);
+}
+template <int NB, int H, int W, int B>
+__device__ __forceinline__ void sy_cp(double (&F)[NB], const double (&Fn)[NB]) {
+  if constexpr (SyGeom<NB>::needs(H, W, B)) F[B] = Fn[B];
+}
+template <int NB, int H, int W, int... B>
+__device__ __forceinline__ void sy_cp_all(double (&F)[NB], const double (&Fn)[NB], std::integer_sequence<int, B...>) {
+  (sy_cp<NB, H, W, B>(F, Fn), ...);
+}
+template <int NB, int H, int W, int CNT, int I>
+__device__ __forceinline__ void sy_mma(sy_double4 (&acc)[CNT], const double (&F)[NB]) {
+  constexpr int t = SyGeom<NB>::wave_begin(H, W) + I;
+  constexpr int bi = SyGeom<NB>::bi_of(t), bj = SyGeom<NB>::bj_of(t);
+  acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[bj], F[bi], acc[I], 0, 0, 0);
+}
+template <int NB, int H, int W, int CNT, int... I>
+__device__ __forceinline__ void sy_mma_all(sy_double4 (&acc)[CNT], const double (&F)[NB], std::integer_sequence<int, I...>) {
+  (sy_mma<NB, H, W, CNT, I>(acc, F), ...);
+}
+
+template <int NB, int HALF, int W>
+__device__ __forceinline__ void sy_body(const double* __restrict__ Y, int64_t ld, int64_t row0, int64_t rend, int l,
+                                        double* __restrict__ Pslab, double* smem) {
+  using G = SyGeom<NB>;
+  constexpr int T0 = G::wave_begin(HALF, W), T1 = G::wave_end(HALF, W), CNT = T1 - T0;
+  constexpr int CLO = G::col_lo(HALF), NCOL = 16 * NB - CLO;
+  constexpr int NLD = (NCOL * SY_KC + SY_THREADS - 1) / SY_THREADS;      // staged elements per thread and chunk
+  constexpr int BUF = SY_KC * G::LDW;
+  const int tid = threadIdx.x, lane = tid & 63, jl = lane & 15, kk = lane >> 4;
+
+  sy_double4 acc[CNT > 0 ? CNT : 1];
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) acc[i] = (sy_double4){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t nrows = rend - row0;
+  const int nchunks = nrows > 0 ? (int)((nrows + SY_KC - 1) / SY_KC) : 0;
+  double stage[NLD];
+  // element e of a chunk: k = e % 16 (fastest: 16 lanes cover the 128 contiguous bytes of one column), column CLO + e / 16
+  auto prefetch = [&](int c) {
+    const int64_t k0 = row0 + (int64_t)c * SY_KC;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * SY_THREADS;
+      const int k = e & (SY_KC - 1);
+      int col = CLO + (e >> 4);
+      const bool ok = (col < l) && (k0 + k < rend) && (e < NCOL * SY_KC);
+      if (col >= l) col = l - 1;
+      int64_t r = k0 + k;
+      if (r >= rend) r = rend - 1;
+      const double v = Y[r + (int64_t)col * ld];            // unconditional load of a clamped address
+      stage[i] = ok ? v : 0.0;
+    }
+  };
+  auto store = [&](int buf) {
+    double* s = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * SY_THREADS;
+      if (e < NCOL * SY_KC) s[(e & (SY_KC - 1)) * G::LDW + CLO + (e >> 4)] = stage[i];
+    }
+  };
+  if (nchunks > 0) {
+    prefetch(0);
+    store(0);
+    if (nchunks > 1) prefetch(1);
+  }
+  __syncthreads();
+  double F[NB], Fn[NB];
+  using Bs = std::make_integer_sequence<int, NB>;
+  using Is = std::make_integer_sequence<int, CNT>;
+  for (int c = 0; c < nchunks; ++c) {
+    const double* s = smem + (c & 1) * BUF + kk * G::LDW + jl;       // fragment b of step st: s[4 st LDW + 16 b]
+    sy_ld_all<NB, HALF, W>(F, s, Bs{});
+#pragma unroll
+    for (int st = 0; st < SY_KC / 4; ++st) {
+      if (st + 1 < SY_KC / 4) sy_ld_all<NB, HALF, W>(Fn, s + 4 * (st + 1) * G::LDW, Bs{});
+      if constexpr (CNT > 0) sy_mma_all<NB, HALF, W, (CNT > 0 ? CNT : 1)>(acc, F, Is{});
+      if (st == 0 && c + 1 < nchunks) {
+        // the other buffer was last read in the previous iteration, behind its closing barrier
+        store((c + 1) & 1);
+        if (c + 2 < nchunks) prefetch(c + 2);
+      }
+      if (st + 1 < SY_KC / 4) sy_cp_all<NB, HALF, W>(F, Fn, Bs{});
+    }
+    __syncthreads();
+  }
+  // lane holds D[i = kk + 4 reg][j = jl] = sum_k Y[k][16 bj + i] Y[k][16 bi + j]: stored as is, 512 contiguous bytes per register
+#pragma unroll
+  for (int i = 0; i < CNT; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Pslab[((int64_t)(T0 + i) * 4 + reg) * 64 + lane] = acc[i][reg];
+}
+
+template <int NB>
+__global__ __launch_bounds__(SY_THREADS) void sy_kernel(const double* __restrict__ Y, int64_t ld, int64_t m, int l,
+                                                        int64_t rows_per_slab, double* __restrict__ P) {
+  extern __shared__ double sy_smem[];
+  const int half = blockIdx.x & 1, slab = blockIdx.x >> 1;
+  const int64_t row0 = (int64_t)slab * rows_per_slab;
+  int64_t rend = row0 + rows_per_slab;
+  if (rend > m) rend = m;
+  double* Pslab = P + (int64_t)slab * SyGeom<NB>::NBLK * 256;
+  const int wave = threadIdx.x >> 6;
+#define GSI_SY_CASE(H, Wv) case (H) * SY_WAVES + (Wv): sy_body<NB, H, Wv>(Y, ld, row0, rend, l, Pslab, sy_smem); break;
+  switch (half * SY_WAVES + wave) {
+    GSI_SY_CASE(0, 0) GSI_SY_CASE(0, 1) GSI_SY_CASE(0, 2) GSI_SY_CASE(0, 3)
+    GSI_SY_CASE(0, 4) GSI_SY_CASE(0, 5) GSI_SY_CASE(0, 6) GSI_SY_CASE(0, 7)
+    GSI_SY_CASE(1, 0) GSI_SY_CASE(1, 1) GSI_SY_CASE(1, 2) GSI_SY_CASE(1, 3)
+    GSI_SY_CASE(1, 4) GSI_SY_CASE(1, 5) GSI_SY_CASE(1, 6) GSI_SY_CASE(1, 7)
+    default: break;
+  }
+#undef GSI_SY_CASE
+}
+
+// G (l x l, ld ldg) <- sum over slabs, fixed order; block t of the upper triangle per workgroup, both triangles written
+template <int NB>
+__global__ __launch_bounds__(256) void sy_reduce_kernel(const double* __restrict__ P, int nslab, int l, double* __restrict__ Gm,
+                                                        int64_t ldg) {
+  using G = SyGeom<NB>;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  double v = 0.0;
+  for (int s = 0; s < nslab; ++s) v += P[((int64_t)s * G::NBLK + t) * 256 + tid];
+  int bi = 0;
+  while (G::row_start(bi + 1) <= t) ++bi;
+  const int bj = bi + (t - G::row_start(bi));
+  const int reg = tid >> 6, lane = tid & 63, jl = lane & 15, kk = lane >> 4;
+  const int row = 16 * bi + jl, col = 16 * bj + kk + 4 * reg;
+  if (row <= col && col < l) {
+    Gm[row + (int64_t)col * ldg] = v;
+    Gm[col + (int64_t)row * ldg] = v;
+  }
+}
+
+size_t syrk_upper_workspace_doubles(int64_t l, int64_t m) {
+  if (l > 320 || m < 4096) return 0;
+  const int nb = (int)((l + 15) / 16);
+  const int NB = nb <= 8 ? 8 : (nb <= 10 ? 10 : (nb <= 16 ? 16 : 20));
+  return (size_t)SY_SLABS * (size_t)(NB * (NB + 1) / 2) * 256;
+}
+
+template <int NB>
+static void sy_launch(hipStream_t st, int64_t l, int64_t m, const double* Y, int64_t ld, double* Gm, int64_t ldg, double* ws) {
+  static std::atomic<uint64_t> attr_mask{0};
+  const size_t shmem = (size_t)2 * SY_KC * SyGeom<NB>::LDW * sizeof(double);
+  if (first_use_on_this_device(attr_mask))
+    (void)hipFuncSetAttribute((const void*)sy_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  int64_t rps = (m + SY_SLABS - 1) / SY_SLABS;
+  rps = (rps + SY_KC - 1) / SY_KC * SY_KC;
+  hipLaunchKernelGGL((sy_kernel<NB>), dim3(2 * SY_SLABS), dim3(SY_THREADS), shmem, st, Y, ld, m, (int)l, rps, ws);
+  hipLaunchKernelGGL((sy_reduce_kernel<NB>), dim3(SyGeom<NB>::NBLK), dim3(256), 0, st, ws, SY_SLABS, (int)l, Gm, ldg);
+}
+
+// G (l x l) = Y'Y, both triangles.  Returns false (nothing done) when the shape is not this kernel's: the caller
+// falls back to the general contraction.  ws: syrk_upper_workspace_doubles(l, m).
+bool syrk_full_from_upper(hipStream_t st, int64_t l, int64_t m, const double* Y, int64_t ld, double* Gm, int64_t ldg, double* ws) {
+  static const bool off = (getenv("GSI_NO_SYRK_KERNEL") != nullptr);
+  if (off || syrk_upper_workspace_doubles(l, m) == 0) return false;
+  const int nb = (int)((l + 15) / 16);
+  if (nb <= 8) sy_launch<8>(st, l, m, Y, ld, Gm, ldg, ws);
+  else if (nb <= 10) sy_launch<10>(st, l, m, Y, ld, Gm, ldg, ws);
+  else if (nb <= 16) sy_launch<16>(st, l, m, Y, ld, Gm, ldg, ws);
+  else sy_launch<20>(st, l, m, Y, ld, Gm, ldg, ws);
+  return true;
+}
+
+}}  // namespace gsi::hipk

@@ -92,7 +92,8 @@ def test_lu_singular_raises(gsi, ctx):
 
 
 # ---- qr -> thin Q ------------------------------------------------------------------------------
-@pytest.mark.parametrize("m,l", [(10, 2), (40, 7), (100, 25), (625, 50), (2000, 48), (5000, 160), (3000, 33)])
+@pytest.mark.parametrize("m,l", [(10, 2), (40, 7), (100, 25), (625, 50), (2000, 48), (5000, 160), (3000, 33),
+                                 (20000, 320), (9001, 250), (4100, 300), (70001, 130), (4096, 17)])   # >= 4096 rows: syrk_f64.hip
 def test_qr_thinQ(gsi, ctx, m, l):
     rng = np.random.default_rng(3 * m + l)
     Y = rng.standard_normal((m, l)) @ np.diag(np.logspace(0, -8, l))
