@@ -250,7 +250,8 @@ void cq_round(hipStream_t st, const double* src, int64_t lds, double* dst, int64
     hipLaunchKernelGGL(cq_right_mult_kernel, dim3(grid_for(j0 + bb, 1024)), dim3(256), 0, st, X, j0 + bb, (int64_t)l,
                        j0, bb, b.Rinv + (size_t)jb * CQ_TB * CQ_TB);
   }
-  if (apply) gemm_f64_trmm_upper(st, m, l, l, src, lds, X, l, dst, ldd, gemm_ws);         // dst = src R^-1 (R^-1 upper)
+  if (apply && !trmm_upper_tall(st, m, l, src, lds, X, l, dst, ldd))                      // dst = src R^-1 (R^-1 upper)
+    gemm_f64_trmm_upper(st, m, l, l, src, lds, X, l, dst, ldd, gemm_ws);
 }
 }  // namespace
 
@@ -270,7 +271,7 @@ void cholqr2_apply(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t ld
                    double* R, double* small, double* gemm_ws) {
   const int l = (int)l64;
   const CqBufs b = cq_bufs(small, l);
-  gemm_f64_trmm_upper(st, m, l, l, T, ldt, b.X2, l, Y, ld, gemm_ws);
+  if (!trmm_upper_tall(st, m, l, T, ldt, b.X2, l, Y, ld)) gemm_f64_trmm_upper(st, m, l, l, T, ldt, b.X2, l, Y, ld, gemm_ws);
   if (R != nullptr)
     hipLaunchKernelGGL(cq_triprod_kernel, dim3(grid_for((int64_t)l * l, 256)), dim3(256), 0, st, b.R2, b.R1, l, R);
 }
@@ -301,7 +302,7 @@ void scholqr3_apply(hipStream_t st, double* Y, int64_t m, int64_t l64, int64_t l
                     double* R, double* small, double* gemm_ws) {
   const int l = (int)l64;
   const CqBufs b = cq_bufs(small, l);
-  gemm_f64_trmm_upper(st, m, l, l, S, lds_, b.X3, l, Y, ld, gemm_ws);
+  if (!trmm_upper_tall(st, m, l, S, lds_, b.X3, l, Y, ld)) gemm_f64_trmm_upper(st, m, l, l, S, lds_, b.X3, l, Y, ld, gemm_ws);
   if (R != nullptr) {
     const int g = grid_for((int64_t)l * l, 256);
     hipLaunchKernelGGL(cq_triprod_kernel, dim3(g), dim3(256), 0, st, b.R2, b.R1, l, b.X1);   // X1 is free: R2 R1

@@ -26,6 +26,9 @@ size_t gemm_syrk_workspace_doubles(int64_t l, int64_t m);
 // syrk_f64.hip: G = A'A (both triangles) for l <= 320 by the register-resident kernel; false = shape not covered
 size_t syrk_upper_workspace_doubles(int64_t l, int64_t m);
 bool syrk_full_from_upper(hipStream_t st, int64_t l, int64_t m, const double* Y, int64_t ld, double* G, int64_t ldg, double* ws);
+// C (m x l) = A X, X (l x l) upper triangular, l <= 320, C not aliasing A; false = shape not covered
+bool trmm_upper_tall(hipStream_t st, int64_t m, int64_t l, const double* A, int64_t lda, const double* X, int64_t ldx, double* C,
+                     int64_t ldc);
 void gemm_f64_syrk_upper(hipStream_t st, int64_t l, int64_t m, const double* A, int64_t lda, double* C, int64_t ldc,
                          double* ws);
 void gemm_f64_trmm_upper(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A, int64_t lda, const double* B,

@@ -233,4 +233,154 @@ bool syrk_full_from_upper(hipStream_t st, int64_t l, int64_t m, const double* Y,
   return true;
 }
 
+// ---- C (m x l) = A (m x l) * X, X (l x l) upper triangular: the Y R^-1 of a CholeskyQR round ----------------------
+// The general kernel runs this shape (K = l = 320: ten K tiles per 128 x 160 output tile) mostly in its prologue and
+// epilogue: 3.65 ms at m = 10^6 against 1.4 ms of MFMA time for the triangular flop count.  Here a workgroup owns 128
+// rows and ALL l columns (wave r: rows 16 r .. 16 r + 15, 20 accumulator blocks = 160 registers), walks the 16-row
+// chunks kb of X and skips the column blocks left of the diagonal (bj < kb): exactly the 210 x 4 MFMAs per row block the
+// triangle needs, every wave the same schedule.  X (0.8 MB) streams from L2 once per tile, A and C move once.
+template <class Fn, int... I>
+__device__ __forceinline__ void sy_for_each(Fn& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+constexpr int TR_ROWS = 128;
+constexpr int TR_LDA = TR_ROWS + 1;
+constexpr int TR_G = 5;            // X fragments per group
+
+template <int NB>
+__global__ __launch_bounds__(SY_THREADS) void tr_kernel(const double* __restrict__ A, int64_t lda, int64_t m,
+                                                        const double* __restrict__ X, int64_t ldx, int l,
+                                                        double* __restrict__ C, int64_t ldc) {
+  constexpr int LDW = 16 * NB + 1;
+  constexpr int ABUF = SY_KC * TR_LDA, XBUF = SY_KC * LDW, BUF = ABUF + XBUF;
+  constexpr int NLA = TR_ROWS * SY_KC / SY_THREADS;                      // 4
+  constexpr int NLX = (16 * NB * SY_KC + SY_THREADS - 1) / SY_THREADS;   // <= 10
+  extern __shared__ double sy_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, jl = lane & 15, kk = lane >> 4, r = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * TR_ROWS;
+  const int nkb = (l + 15) >> 4;
+
+  sy_double4 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = (sy_double4){0.0, 0.0, 0.0, 0.0};
+  double sa[NLA], sx[NLX];
+  auto prefetch = [&](int kb) {
+    const int k0 = 16 * kb;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {                  // A: rows fastest (512 contiguous bytes per wave)
+      const int e = tid + i * SY_THREADS;
+      const int row = e & (TR_ROWS - 1), k = k0 + (e >> 7);
+      const bool ok = (r0 + row < m) && (k < l);
+      const int64_t rr = (r0 + row < m) ? r0 + row : m - 1;
+      const double v = A[rr + (int64_t)(k < l ? k : l - 1) * lda];
+      sa[i] = ok ? v : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {                  // X: rows k0..k0+15 of the columns right of the diagonal block
+      const int e = tid + i * SY_THREADS;
+      const int k = k0 + (e & 15), c = k0 + (e >> 4);
+      const bool ok = (k < l) && (c < l);
+      const double v = X[(k < l ? k : l - 1) + (int64_t)(c < l ? c : l - 1) * ldx];
+      sx[i] = ok ? v : 0.0;
+    }
+  };
+  auto store = [&](int buf, int kb) {
+    double* as = sy_smem + buf * BUF;
+    double* xs = as + ABUF;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      const int e = tid + i * SY_THREADS;
+      as[(e >> 7) * TR_LDA + (e & (TR_ROWS - 1))] = sa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int e = tid + i * SY_THREADS;
+      const int c = 16 * kb + (e >> 4);
+      if (c < 16 * NB) xs[(e & 15) * LDW + c] = sx[i];
+    }
+  };
+  prefetch(0);
+  store(0, 0);
+  if (nkb > 1) prefetch(1);
+  __syncthreads();
+  // The chunk index is a template argument: which column blocks a chunk touches (bb >= kb) is then known at compile
+  // time -- as uniform branches around every load and MFMA the same loop ran no faster than the general kernel.
+  auto chunk = [&](auto KBc) {
+    constexpr int kb = decltype(KBc)::value;
+    if (kb >= nkb) return;
+    const double* as = sy_smem + (kb & 1) * BUF + kk * TR_LDA + 16 * r + jl;
+    const double* xs = sy_smem + (kb & 1) * BUF + ABUF + kk * LDW + jl;
+#pragma unroll
+    for (int st = 0; st < SY_KC / 4; ++st) {
+      const double fa = as[4 * st * TR_LDA];
+      // X fragments in groups of TR_G, one group ahead of the MFMAs that consume them (all NB at once would not
+      // fit next to 160 accumulator registers)
+      constexpr int G0 = kb / TR_G, NG = (NB + TR_G - 1) / TR_G;
+      double F[2][TR_G];
+#pragma unroll
+      for (int b = 0; b < TR_G; ++b) {
+        const int bb = G0 * TR_G + b;
+        if (bb < NB && bb >= kb) F[G0 & 1][b] = xs[4 * st * LDW + 16 * bb];
+      }
+#pragma unroll
+      for (int g = G0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int b = 0; b < TR_G; ++b) {
+            const int bb = (g + 1) * TR_G + b;
+            if (bb < NB && bb >= kb) F[(g + 1) & 1][b] = xs[4 * st * LDW + 16 * bb];
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < TR_G; ++b) {
+          const int bb = g * TR_G + b;
+          if (bb < NB && bb >= kb) acc[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[g & 1][b], fa, acc[bb], 0, 0, 0);
+        }
+      }
+      if (st == 0 && kb + 1 < nkb) {
+        store((kb + 1) & 1, kb + 1);
+        if (kb + 2 < nkb) prefetch(kb + 2);
+      }
+    }
+    __syncthreads();
+  };
+  sy_for_each(chunk, std::make_integer_sequence<int, NB>{});
+  // lane holds D[i = kk + 4 reg][j = jl] = C[r0 + 16 r + jl][16 b + kk + 4 reg]
+  const int64_t row = r0 + 16 * r + jl;
+  if (row < m) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int col = 16 * b + kk + 4 * reg;
+        if (col < l) C[row + (int64_t)col * ldc] = acc[b][reg];
+      }
+  }
+}
+
+template <int NB>
+static void tr_launch(hipStream_t st, int64_t m, int64_t l, const double* A, int64_t lda, const double* X, int64_t ldx,
+                      double* C, int64_t ldc) {
+  static std::atomic<uint64_t> attr_mask{0};
+  const size_t shmem = (size_t)2 * SY_KC * (TR_LDA + 16 * NB + 1) * sizeof(double);
+  if (first_use_on_this_device(attr_mask))
+    (void)hipFuncSetAttribute((const void*)tr_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL((tr_kernel<NB>), dim3((unsigned)((m + TR_ROWS - 1) / TR_ROWS)), dim3(SY_THREADS), shmem, st, A, lda, m, X, ldx,
+                     (int)l, C, ldc);
+}
+
+// C = A X for square upper-triangular X (entries below the diagonal must be zero: the diagonal blocks are read whole).
+// false = shape not covered (the caller runs the general kernel).  C must not alias A.
+bool trmm_upper_tall(hipStream_t st, int64_t m, int64_t l, const double* A, int64_t lda, const double* X, int64_t ldx, double* C,
+                     int64_t ldc) {
+  static const bool off = (getenv("GSI_NO_TRMM_KERNEL") != nullptr);
+  if (off || l > 320 || l < 1 || m < 4096 || (m + TR_ROWS - 1) / TR_ROWS > 0x7fffffff) return false;
+  const int nb = (int)((l + 15) / 16);
+  if (nb <= 8) tr_launch<8>(st, m, l, A, lda, X, ldx, C, ldc);
+  else if (nb <= 10) tr_launch<10>(st, m, l, A, lda, X, ldx, C, ldc);
+  else if (nb <= 16) tr_launch<16>(st, m, l, A, lda, X, ldx, C, ldc);
+  else tr_launch<20>(st, m, l, A, lda, X, ldx, C, ldc);
+  return true;
+}
+
 }}  // namespace gsi::hipk
