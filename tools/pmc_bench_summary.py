@@ -10,7 +10,8 @@ import bench
 
 def load(counter):
     fs = glob.glob(f"{root}/pmc_bench_{counter}/*/*counter_collection.csv")
-    rows = [r for r in csv.DictReader(open(fs[0])) if r["Counter_Name"] == counter]
+    newest = max(fs, key=os.path.getmtime)            # gpurun_out accumulates the runs of earlier calls
+    rows = [r for r in csv.DictReader(open(newest)) if r["Counter_Name"] == counter]
     out = collections.defaultdict(list)
     for r in rows:
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -50,5 +51,8 @@ def phase(prefixes, count_name, per_unit):
             "traffic_over_one_read_plus_write": ((fb + wb) / units / (16.0 * n * l)) if units else None}
 
 res["lu"] = phase(["lu_leaf_kernel", "lu_rankk_kernel", "lu_u12_kernel", "lu2_extract"], "lu_leaf_kernel", l // 8)
+# CholeskyQR2: two Gram matrices (sy_kernel: the panel is read once per half) + two triangular products per factorization;
+# the thin-SVD factorization's second product runs in the general kernel and is not counted here
+res["qr"] = phase(["sy_kernel", "sy_reduce_kernel", "tr_kernel", "cq_"], "sy_kernel", 2)
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -1,5 +1,5 @@
 """Per-kernel averages of the tools/pmc_fft.sh passes: python tools/pmc_fft_summary.py <gpurun_out> <tag>"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 root, tag = sys.argv[1], sys.argv[2]
 out = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob(f"{root}/pmc_fft_{tag}_*/")):
@@ -7,7 +7,7 @@ for d in sorted(glob.glob(f"{root}/pmc_fft_{tag}_*/")):
     if not fs:
         continue
     seen = set()
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         m = re.search(r"fft_pass_kernel<(\d+)[,>]", r["Kernel_Name"])
         if not m:
             continue

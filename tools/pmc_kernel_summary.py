@@ -1,5 +1,5 @@
 """Per-kernel averages of tools/pmc_kernels.sh passes: python tools/pmc_kernel_summary.py <gpurun_out> <tag> <substr> [...]"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 root, tag, subs = sys.argv[1], sys.argv[2], sys.argv[3:]
 out = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob(f"{root}/pmc_k_{tag}_*/")):
@@ -7,7 +7,7 @@ for d in sorted(glob.glob(f"{root}/pmc_k_{tag}_*/")):
     if not fs:
         continue
     seen = set()
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         k = next((s for s in subs if s in r["Kernel_Name"]), None)
         if k is None:
             continue
