@@ -576,7 +576,9 @@ def test_randsvd_shape_sweep(gsi, ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("Ns,beta,l", [((50,), -2.0, 7), ((24, 17), -3.5, 10), ((40, 64), -2.5, 33), ((9, 6, 11), -3.0, 4),
-                                        ((300, 200), -3.5, 5)])
+                                        ((300, 200), -3.5, 5),
+                                        ((4096,), -2.0, 3), ((3000,), -2.5, 2), ((2048, 4), -3.0, 3), ((3, 1100), -2.0, 2),   # 8192- / 4096-point lines
+                                        ((2, 3), -2.0, 2), ((5, 2, 3), -3.0, 3)])                                            # lines shorter than 16 points
 def test_fft_powerlaw_operator(gsi, ctx, Ns, beta, l):
     """The hand-written LDS FFT passes of the matrix-free covariance (gsi_op_fft_powerlaw) against numpy's FFT:
     odd/even column counts (two real columns per complex transform), 1/2/3 axes, non-power-of-two grids."""
