@@ -36,68 +36,76 @@ __global__ __launch_bounds__(256) void cq_diagmax_kernel(const double* __restric
   if (threadIdx.x == 0) tiny[0] = s[0] * (double)l * DBL_EPSILON * 16.0;
 }
 
-// One block column jb: U11 = chol(G11) and X = U11^-1 in LDS, then the block row U12 = U11^-T G12.
+// broadcast of lane `src` (compile-time after unrolling) of a double: two v_readlane_b32, the result is wave-uniform
+__device__ __forceinline__ double cq_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// One block column jb: U11 = chol(G11) and X = U11^-1, then the block row U12 = U11^-T G12.
 // The trailing update G22 -= U12' U12 is an MFMA GEMM issued by the host.  One workgroup.
+// The 32 x 32 factorization and inverse run in ONE WAVE, lane c = column c of the block held in registers, the pivot
+// row reaching the other lanes through v_readlane (as 32 column steps x 3 __syncthreads over LDS, plus a
+// one-thread-per-column back substitution, the same arithmetic took 63 us per block: 10 % of a CholeskyQR2 at l = 320).
+// The operations and their order are those of the LDS form: results are bit-identical to it.
 __global__ __launch_bounds__(256) void cq_chol_block_kernel(double* __restrict__ G, int l, int j0, int b,
                                                             const double* __restrict__ tiny_p,
                                                             double* __restrict__ Xout /* TB x TB */,
                                                             int32_t* __restrict__ flag) {
-  __shared__ double U[CQ_TB][CQ_TB + 1];
   __shared__ double X[CQ_TB][CQ_TB + 1];
   const int tid = threadIdx.x;
-  const double tiny = tiny_p[0];
-  for (int e = tid; e < CQ_TB * CQ_TB; e += 256) {
-    const int r = e % CQ_TB, c = e / CQ_TB;
-    U[r][c] = (r < b && c < b) ? G[(j0 + r) + (int64_t)(j0 + c) * l] : (r == c ? 1.0 : 0.0);
-    X[r][c] = 0.0;
+  if (tid < 64) {
+    const double tiny = tiny_p[0];
+    const int c = tid & (CQ_TB - 1);                  // lanes 32..63 mirror lanes 0..31 (no stores)
+    double col[CQ_TB], x[CQ_TB];
+#pragma unroll
+    for (int r = 0; r < CQ_TB; ++r)
+      col[r] = (r < b && c < b) ? G[(j0 + r) + (int64_t)(j0 + c) * l] : (r == c ? 1.0 : 0.0);
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < CQ_TB; ++k) {
+      double d = cq_bcast(col[k], k);
+      if (k < b && !(d > tiny)) { bad = true; d = 1.0; }
+      const double ukk = sqrt(d);
+      col[k] = (c == k) ? ukk : col[k] / ukk;          // row k of U (lanes c < k hold nothing that is read)
+#pragma unroll
+      for (int r = k + 1; r < CQ_TB; ++r) col[r] -= cq_bcast(col[k], r) * col[k];
+      __builtin_amdgcn_sched_barrier(0);               // or the scheduler hoists hundreds of broadcasts (SGPR pairs) at once and spills
+    }
+    if (bad && tid == 0) atomicOr(flag, 1);
+    // X = U^-1 (upper): column c by back substitution, the terms with p > c multiply exact zeros
+#pragma unroll
+    for (int r = CQ_TB - 1; r >= 0; --r) {
+      double sacc = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int p = r + 1; p < CQ_TB; ++p) sacc -= cq_bcast(col[r], p) * x[p];
+      x[r] = (r <= c) ? sacc / cq_bcast(col[r], r) : 0.0;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid < CQ_TB) {
+#pragma unroll
+      for (int r = 0; r < CQ_TB; ++r) {
+        X[r][c] = x[r];
+        Xout[r + c * CQ_TB] = x[r];
+        if (r < b && c < b) G[(j0 + r) + (int64_t)(j0 + c) * l] = (r <= c) ? col[r] : 0.0;
+      }
+    }
   }
   __syncthreads();
-  for (int k = 0; k < b; ++k) {
-    if (tid == 0) {
-      double d = U[k][k];
-      if (!(d > tiny)) { atomicOr(flag, 1); d = 1.0; }
-      U[k][k] = sqrt(d);
-    }
-    __syncthreads();
-    if (tid > k && tid < b) U[k][tid] /= U[k][k];
-    __syncthreads();
-    for (int e = tid; e < CQ_TB * CQ_TB; e += 256) {
-      const int r = e % CQ_TB, c = e / CQ_TB;
-      if (r > k && r <= c && c < b) U[r][c] -= U[k][r] * U[k][c];
-    }
-    __syncthreads();
-  }
-  // X = U^-1 (upper): column c by back substitution, thread = column
-  if (tid < b) {
-    const int c = tid;
-    for (int r = c; r >= 0; --r) {
-      double s = (r == c) ? 1.0 : 0.0;
-      for (int p = r + 1; p <= c; ++p) s -= U[r][p] * X[p][c];
-      X[r][c] = s / U[r][r];
-    }
-  } else if (tid < CQ_TB) {
-    X[tid][tid] = 1.0;
-  }
-  __syncthreads();
-  for (int e = tid; e < CQ_TB * CQ_TB; e += 256) {
-    const int r = e % CQ_TB, c = e / CQ_TB;
-    Xout[r + c * CQ_TB] = X[r][c];
-    if (r < b && c < b) G[(j0 + r) + (int64_t)(j0 + c) * l] = (r <= c) ? U[r][c] : 0.0;
-  }
   // block row: U12[:, c] = X' * G12[:, c]  (thread = one trailing column), and zero the block below U11
+  // (r is a run-time loop on purpose: fully unrolled, the 528 entries of X were hoisted out of the column loop into
+  // registers and from there to scratch; the entries below the diagonal of X are exact zeros, so every row sums all 32)
   for (int c = j0 + b + tid; c < l; c += 256) {
     double g[CQ_TB];
 #pragma unroll
     for (int r = 0; r < CQ_TB; ++r) g[r] = (r < b) ? G[(j0 + r) + (int64_t)c * l] : 0.0;
+#pragma unroll 1
+    for (int r = 0; r < b; ++r) {
+      double s = 0.0;
 #pragma unroll
-    for (int r = 0; r < CQ_TB; ++r) {
-      if (r < b) {
-        double s = 0.0;
-#pragma unroll
-        for (int p = 0; p < CQ_TB; ++p)
-          if (p <= r) s += X[p][r] * g[p];
-        G[(j0 + r) + (int64_t)c * l] = s;
-      }
+      for (int p = 0; p < CQ_TB; ++p) s += X[p][r] * g[p];
+      G[(j0 + r) + (int64_t)c * l] = s;
     }
   }
   for (int e = tid; e < b * (l - j0 - b); e += 256) {   // strictly-lower part of this block column -> 0
@@ -106,27 +114,25 @@ __global__ __launch_bounds__(256) void cq_chol_block_kernel(double* __restrict__
   }
 }
 
-// ---- Y[:, j0:j0+b] <- Y[:, j0:j0+b] * X  (X upper triangular b x b, ld CQ_TB); thread = one row ----
+// ---- Y[:, j0:j0+b] <- Y[:, j0:j0+b] * X  (X upper triangular b x b, ld CQ_TB, zeros below the diagonal) ----
+// A workgroup takes 8 rows: the 8 x 32 inputs go through LDS, thread (row, c) sums its 32 products in the order
+// p = 0..31 (the terms past the diagonal are exact zeros).  With one thread per row the l x l inverse ran on 320
+// threads, each a chain of 32 strided loads and 528 FMAs: 26-37 us per block, ten blocks per Cholesky round.
 __global__ __launch_bounds__(256) void cq_right_mult_kernel(double* __restrict__ Y, int64_t m, int64_t ld,
                                                             int64_t j0, int b, const double* __restrict__ X) {
-  __shared__ double Xs[CQ_TB * CQ_TB];
-  for (int e = threadIdx.x; e < CQ_TB * CQ_TB; e += 256) Xs[e] = X[e];
-  __syncthreads();
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m; r += (int64_t)gridDim.x * 256) {
-    double x[CQ_TB];
-    double* row = Y + r + j0 * ld;
+  __shared__ double Xs[CQ_TB][CQ_TB + 1];
+  __shared__ double xs[8][CQ_TB + 1];
+  const int tid = threadIdx.x, c = tid & (CQ_TB - 1), rl = tid >> 5;
+  for (int e = tid; e < CQ_TB * CQ_TB; e += 256) Xs[e & (CQ_TB - 1)][e >> 5] = X[e];       // Xs[p][c] = X[p + c * TB]
+  for (int64_t r0 = (int64_t)blockIdx.x * 8; r0 < m; r0 += (int64_t)gridDim.x * 8) {
+    const int64_t r = r0 + rl;
+    __syncthreads();                                  // Xs written / the previous pass's reads of xs done
+    xs[rl][c] = (r < m && c < b) ? Y[r + (j0 + c) * ld] : 0.0;
+    __syncthreads();
+    double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < CQ_TB; ++c) x[c] = (c < b) ? row[c * ld] : 0.0;
-#pragma unroll
-    for (int c = CQ_TB - 1; c >= 0; --c) {
-      if (c < b) {
-        double s = 0.0;
-#pragma unroll
-        for (int p = 0; p < CQ_TB; ++p)
-          if (p <= c) s += x[p] * Xs[p + c * CQ_TB];
-        row[c * ld] = s;
-      }
-    }
+    for (int p = 0; p < CQ_TB; ++p) s += xs[rl][p] * Xs[p][c];
+    if (r < m && c < b) Y[r + (j0 + c) * ld] = s;
   }
 }
 
@@ -247,7 +253,7 @@ void cq_round(hipStream_t st, const double* src, int64_t lds, double* dst, int64
     const int bb = (int)((l - j0 < CQ_TB) ? (l - j0) : CQ_TB);
     if (j0 > 0)
       gemm_f64(st, false, j0 + bb, bb, j0, -1.0, X, l, Rp + j0 * (int64_t)l, l, 1.0, X + j0 * l, l, gemm_ws);
-    hipLaunchKernelGGL(cq_right_mult_kernel, dim3(grid_for(j0 + bb, 1024)), dim3(256), 0, st, X, j0 + bb, (int64_t)l,
+    hipLaunchKernelGGL(cq_right_mult_kernel, dim3((unsigned)((j0 + bb + 7) / 8)), dim3(256), 0, st, X, j0 + bb, (int64_t)l,
                        j0, bb, b.Rinv + (size_t)jb * CQ_TB * CQ_TB);
   }
   if (apply && !trmm_upper_tall(st, m, l, src, lds, X, l, dst, ldd))                      // dst = src R^-1 (R^-1 upper)
