@@ -202,7 +202,9 @@ __global__ __launch_bounds__(256) void sy_reduce_kernel(const double* __restrict
 }
 
 size_t syrk_upper_workspace_doubles(int64_t l, int64_t m) {
-  if (l > 320 || m < 4096) return 0;
+  // l < 96: the Gram matrix is HBM-bound (l / 8 flop per panel byte against a ridge of ~10) and the general kernel reads
+  // the panel once where this one reads it 1.7 times (once per half)
+  if (l > 320 || l < 96 || m < 4096) return 0;
   const int nb = (int)((l + 15) / 16);
   const int NB = nb <= 8 ? 8 : (nb <= 10 ? 10 : (nb <= 16 ? 16 : 20));
   return (size_t)SY_SLABS * (size_t)(NB * (NB + 1) / 2) * 256;
