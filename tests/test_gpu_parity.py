@@ -889,3 +889,54 @@ print("rccl-sharded-lu-ok")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "rccl-sharded-lu-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- the bench's own workload at BASELINE.json's full size (n = 1e6, N_s = 1024, K = 256, p = 64, q = 2): properties
+#      that do not depend on the size -- Z[:, K:] == 0, S positive and descending, V = Z S^-1/2 orthonormal, a second run
+#      bit-identical (every reduction in the path has a fixed order), V spans an invariant subspace of A (A V = V (V'AV)
+#      for the leading vectors), and the build with the general contraction kernel in place of the dedicated
+#      Gram / triangular-product / small-Cholesky kernels (GSI_NO_SYRK_KERNEL, GSI_NO_TRMM_KERNEL) gives the same singular
+#      values.  Separate processes: the switches are read once per process. --------------------------------------------
+@pytest.mark.gpu
+def test_headline_size_properties(gsi):
+    import os, subprocess, sys, tempfile
+    code = r'''
+import os, sys, numpy as np
+import gsi_amd as gsi
+ctx = gsi.Context(0)
+n, Ns, K, p, q = 1000000, 1024, 256, 64, 2
+op = gsi.lowrank_synthetic_operator(ctx, n, Ns, seed=0, decay=0.75)
+Om = gsi.DeviceMatrix(ctx, n, K + p).randn(1)
+Z = gsi.DeviceMatrix(ctx, n, K + p); S = gsi.DeviceMatrix(ctx, K + p, 1)
+def run():
+    gsi._lib.check(ctx.lib.gsi_randsvd_dev(ctx.h, op.h, Om.h, K, p, q, Z.h, S.h), ctx.lib)
+    return Z.to_host(), S.to_host()[:, 0]
+Zh, Sh = run()
+assert np.all(Zh[:, K:] == 0.0)
+assert np.all(Sh[:K] > 0) and np.all(np.diff(Sh) <= 0)
+if os.environ.get("GSI_TEST_FULL"):
+    Z2, S2 = run()
+    assert np.array_equal(Zh, Z2) and np.array_equal(Sh, S2)            # deterministic
+    V = Zh[:, :K] / np.sqrt(Sh[:K])
+    G = V.T @ V
+    assert np.abs(G - np.eye(K)).max() < 1e-10, np.abs(G - np.eye(K)).max()
+    j = 12
+    AV = op.matmul(np.asfortranarray(V[:, :j]))
+    T = V[:, :j].T @ AV
+    assert np.abs(T - np.diag(Sh[:j])).max() < 1e-6 * Sh[0]             # V'AV = diag(S) on the leading vectors (q = 2)
+    assert np.linalg.norm(AV - V[:, :j] * Sh[:j]) < 1e-5 * Sh[0] * np.sqrt(j)
+np.save(sys.argv[1], Sh)
+print("headline-ok")
+'''
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("dedicated", {"GSI_TEST_FULL": "1"}), ("general", {"GSI_NO_SYRK_KERNEL": "1", "GSI_NO_TRMM_KERNEL": "1"})):
+            env = dict(os.environ)
+            env.update(extra)
+            path = os.path.join(td, tag + ".npy")
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=900, env=env, cwd=here)
+            assert r.returncode == 0 and "headline-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+            out[tag] = np.load(path)
+    S1, S2 = out["dedicated"], out["general"]
+    assert np.abs(S1 - S2).max() < 1e-11 * S1[0], np.abs(S1 - S2).max() / S1[0]
