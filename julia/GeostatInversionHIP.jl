@@ -118,6 +118,48 @@ function GridCovImplicit(nx::Int, ny::Int, ell::Float64; c::Context=ctx())
 	return op
 end
 
+"The same operator for another stationary kernel on the nx x ny unit grid: `kind = :gaussian` (exp(-d^2/(2 ell^2))),
+`kind = :exponential` (exp(-d/ell)), or any covariance of the grid offsets handed over as a table
+`table[dy + 1, dx + 1] = k(dx, dy)` (ny x nx: Matern, anisotropic, nested ...).  `gsi_op_gridcov_implicit_kind`,
+`gsi_op_gridcov_implicit_table`; entries are looked up in that 8 n-byte table inside the product kernel."
+function GridCovImplicit(nx::Int, ny::Int, ell::Float64, kind::Symbol; c::Context=ctx())
+	k = kind == :gaussian ? 0 : kind == :exponential ? 1 : error("GridCovImplicit: kind must be :gaussian or :exponential")
+	r = Ref{Ptr{Cvoid}}(C_NULL)
+	check(ccall((:gsi_op_gridcov_implicit_kind, libgsi), Cint,
+		(Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Int64, Int64, Cdouble, Cint, Int64, Int64),
+		c.h, r, nx, ny, ell, k, 0, nx * ny))
+	op = DeviceOperator(r[], c, nx * ny, nx * ny)
+	finalizer(finalize_op!, op)
+	return op
+end
+function GridCovImplicit(table::Matrix{Float64}; c::Context=ctx())
+	ny, nx = size(table)                       # column-major ny x nx  ==  t[dx * ny + dy] of the C ABI
+	r = Ref{Ptr{Cvoid}}(C_NULL)
+	check(ccall((:gsi_op_gridcov_implicit_table, libgsi), Cint,
+		(Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Float64}, Int64, Int64),
+		c.h, r, nx, ny, table, 0, nx * ny))
+	op = DeviceOperator(r[], c, nx * ny, nx * ny)
+	finalizer(finalize_op!, op)
+	return op
+end
+
+"The covariance of `FFTRF.powerlaw_structuredgrid(Ns, k0, dk, beta)` fields themselves (up to dk^2 and the per-sample
+mean / std normalisation, FFTRF.jl:94-98): FFTRF's own embedding of exactly 2N points per axis and its integer
+wavenumbers (FFTRF.jl:83-90, computesqrtS_f :40-72), `gsi_op_fft_powerlaw_fftrf`.  Acts on `vec(field)`; every grid
+dimension must be a power of two (the exact `getxis(samplefield, ...)` sample estimate becomes this operator as the number
+of fields grows: tests/test_fftrf_covariance.py)."
+function FFTRFCovariance(Ns::Vector{Int}, beta::Float64; c::Context=ctx())
+	r = Ref{Ptr{Cvoid}}(C_NULL)
+	N64 = Int64.(Ns)
+	check(ccall((:gsi_op_fft_powerlaw_fftrf, libgsi), Cint,
+		(Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Cint, Ptr{Int64}, Cdouble),
+		c.h, r, length(N64), N64, beta))
+	n = prod(Ns)
+	op = DeviceOperator(r[], c, n, n)
+	finalizer(finalize_op!, op)
+	return op
+end
+
 "Matrix-free stationary power-law covariance on a structured grid (circulant embedding on the next power of two
 >= 2N per axis, spectrum |k|^beta with k in cycles per grid spacing, unit diagonal): `gsi_op_fft_powerlaw`.  Acts on
 `vec(field)`.  It is the covariance family FFTRF.powerlaw_structuredgrid samples from; it coincides with the
