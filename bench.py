@@ -20,7 +20,8 @@ roofline     = the dominant kernel, the fp64 MFMA contraction gemm_f64_kernel: 2
                different build of the kernel)
 phases_hbm   = the HBM-bound panel phases (LU, QR, Z = Q_W U): one read + one write of the n x l panel per
                factorization over the measured time per factorization, against 8 TB/s
-secondary    = BASELINE.json configs[1] (dense fp64 65536^2, K = 128, q = 2: the MFMA-bound stored operator) and ONE
+secondary    = BASELINE.json configs[1] (dense fp64 65536^2, K = 128, q = 2: the MFMA-bound stored operator), the
+               matrix-free FFT covariance of a 1000^2 grid (configs[2] at n = 1e6: the HBM-bound operator) and ONE
                step of the n = 10^6 implicit dense exponential covariance (entries generated in the contraction kernel)
 cpu_baseline = the numpy/scipy oracle (the reference's algorithm: N_s rank-1 ger!/gemv sweeps per product,
                dgetrf/dgeqp3/dgesdd panels) on a bounded sample of the same operator class, all host cores; the
@@ -294,6 +295,25 @@ def main():
             "steps": 1, "ms_per_step": 1e3 * e3, "equivalent_stored_GB/s": dense_bytes(n3, l3, q3) / e3 / 1e9,
             "gemm_TFLOP/s": tf, "gemm_frac_of_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
             "phases_ms_per_step": {k: v[0] for k, v in ph3.items()}}
+        # BASELINE.json configs[2] (C3), at the size whose rank-256 panels fit one GPU: matrix-free FFT power-law
+        # covariance of a 1000 x 1000 grid (n = 1e6), K = 205, p = 51 (l = 256), q = 2.  HBM-bound operator:
+        # algorithmic bytes per column pair = what its 2d - 1 passes must move.
+        import numpy as np
+        gf, K4, p4, q4 = 1000, 205, 51, 2
+        n4, l4 = gf * gf, K4 + p4
+        op4 = gsi.fft_powerlaw_operator(ctx, [gf, gf], -3.5)
+        e4, ph4, _ = run_steps(gsi, ctx, op4, n4, K4, p4, q4, 5, 1, barrier)
+        op4.close()
+        Mf = 1 << int(np.ceil(np.log2(2 * gf)))
+        pair_bytes = 16.0 * (2 * (gf + Mf) * gf + 2 * Mf * gf) + 8.0 * Mf * Mf
+        prod_ms = (ph4["gemm_n"][0] + ph4["gemm_t"][0]) / (ph4["gemm_n"][1] + ph4["gemm_t"][1])
+        sec["fft_powerlaw_1000sq"] = {
+            "workload": f"matrix-free FFT power-law covariance (beta = -3.5) of a {gf}x{gf} grid, embedding {Mf}x{Mf}, "
+                        f"K={K4}, p={p4}, q={q4} (BASELINE.json configs[2] at n = 1e6; the 512^3 grid runs up to l = 48, DESIGN.md 4.6)",
+            "steps": 5, "ms_per_step": 1e3 * e4 / 5, "ms_per_product": prod_ms,
+            "product_algorithmic_GB/s": (l4 // 2) * pair_bytes / (prod_ms * 1e-3) / 1e9,
+            "product_frac_of_hbm_peak": (l4 // 2) * pair_bytes / (prod_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "phases_ms_per_step": {k: v[0] / 5 for k, v in ph4.items()}}
         out["secondary"] = sec
 
     if rank == 0:
