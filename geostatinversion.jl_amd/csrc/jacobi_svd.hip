@@ -41,6 +41,59 @@ __device__ inline double quarter_allsum(double v) {
   return v;
 }
 
+// One column pair handled by a quarter wave (16 lanes): the three inner products, the rotation, its application.
+// NI > 0: l == 16 NI exactly -- every lane holds its NI elements of both columns in registers from the inner products to
+// the rotation (one burst of LDS reads per round, a third less LDS traffic; the common sketch widths l = 160, 256, 320).
+// NI == 0: any l, two walks over the columns with eight reads in flight.  Same sums in the same order either way.
+template <int NI>
+__device__ __forceinline__ int jacobi_pair(double* __restrict__ gp, double* __restrict__ gq, int l, int l16, bool active,
+                                           double tol2) {
+  double a = 0.0, b = 0.0, c = 0.0;
+  double xr[NI > 0 ? NI : 1], yr[NI > 0 ? NI : 1];
+  if constexpr (NI > 0) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) { xr[k] = gp[l16 + 16 * k]; yr[k] = gq[l16 + 16 * k]; }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) { a += xr[k] * xr[k]; b += yr[k] * yr[k]; c += xr[k] * yr[k]; }
+  } else {
+#pragma unroll 8
+    for (int i = l16; i < l; i += 16) {
+      const double x = gp[i], y = gq[i];
+      a += x * x; b += y * y; c += x * y;
+    }
+  }
+  a = quarter_allsum(a); b = quarter_allsum(b); c = quarter_allsum(c);
+  if (!(active && a > 0.0 && b > 0.0 && c * c > tol2 * (a * b))) return 0;
+  // Rutishauser rotation, t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (b-a)/(2c),
+  // rewritten as t = sign(d*e) |e| / (|d| + hypot(d, e)).  The angle only has to be approximately
+  // optimal -- what must hold to fp64 rounding is cs^2 + sn^2 = 1 -- so t comes from the
+  // one-instruction v_rsq_f64 / v_rcp_f64 approximations and only cs gets Newton steps.
+  const double d = b - a, e = 2.0 * c;
+  const double q2 = d * d + e * e;
+  const double r = q2 * __builtin_amdgcn_rsq(q2);                      // ~ hypot(d, e)
+  const double t = copysign(fabs(e), d * e) * __builtin_amdgcn_rcp(fabs(d) + r);
+  const double w = 1.0 + t * t;
+  double cs = __builtin_amdgcn_rsq(w);
+  cs = cs * (1.5 - 0.5 * w * cs * cs);                                 // Newton: 1/sqrt(w) to fp64
+  cs = cs * (1.5 - 0.5 * w * cs * cs);
+  const double sn = cs * t;
+  if constexpr (NI > 0) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      gp[l16 + 16 * k] = cs * xr[k] - sn * yr[k];
+      gq[l16 + 16 * k] = sn * xr[k] + cs * yr[k];
+    }
+  } else {
+#pragma unroll 8
+    for (int i = l16; i < l; i += 16) {
+      const double x = gp[i], y = gq[i];
+      gp[i] = cs * x - sn * y;
+      gq[i] = sn * x + cs * y;
+    }
+  }
+  return l16 == 0 ? 1 : 0;
+}
+
 // grid.x = number of block pairs in this round; SVD_W = columns per block (16, or 8 for l > 600)
 template <int SVD_W>
 __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __restrict__ G, int l, int lp,
@@ -66,6 +119,7 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   }
   __syncthreads();
   int rots = 0;
+  const int ni = ((l & 15) == 0) ? (l >> 4) : 0;      // elements per lane when the columns divide evenly
   for (int sw = 0; sw < inner_sweeps; ++sw) {
     // cross_only: only pairs (column of block a, column of block b) -- SVD_W rounds of a bipartite
     // tournament; otherwise all pairs of the 2*SVD_W resident columns (2*SVD_W - 1 rounds).  The pairs
@@ -79,38 +133,10 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
       else rr_pair(SVD_C, r, active ? pairidx : 0, &p, &q);
       double* gp = cols + p * lp;
       double* gq = cols + q * lp;
-      double a = 0.0, b = 0.0, c = 0.0;
-      // unrolled: the LDS reads of eight iterations go out back to back instead of one round trip per iteration
-      // (a quarter wave walks 20 elements of each column at l = 320: the inner rounds are latency, not bandwidth;
-      // keeping the elements in registers from the inner products to the rotation measured slower: 57 vs 54 us)
-#pragma unroll 8
-      for (int i = l16; i < l; i += 16) {
-        const double x = gp[i], y = gq[i];
-        a += x * x; b += y * y; c += x * y;
-      }
-      a = quarter_allsum(a); b = quarter_allsum(b); c = quarter_allsum(c);
-      if (active && a > 0.0 && b > 0.0 && c * c > tol2 * (a * b)) {
-        // Rutishauser rotation, t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (b-a)/(2c),
-        // rewritten as t = sign(d*e) |e| / (|d| + hypot(d, e)).  The angle only has to be approximately
-        // optimal -- what must hold to fp64 rounding is cs^2 + sn^2 = 1 -- so t comes from the
-        // one-instruction v_rsq_f64 / v_rcp_f64 approximations and only cs gets Newton steps.
-        const double d = b - a, e = 2.0 * c;
-        const double q2 = d * d + e * e;
-        const double r = q2 * __builtin_amdgcn_rsq(q2);                      // ~ hypot(d, e)
-        const double t = copysign(fabs(e), d * e) * __builtin_amdgcn_rcp(fabs(d) + r);
-        const double w = 1.0 + t * t;
-        double cs = __builtin_amdgcn_rsq(w);
-        cs = cs * (1.5 - 0.5 * w * cs * cs);                                 // Newton: 1/sqrt(w) to fp64
-        cs = cs * (1.5 - 0.5 * w * cs * cs);
-        const double sn = cs * t;
-#pragma unroll 8
-        for (int i = l16; i < l; i += 16) {
-          const double x = gp[i], y = gq[i];
-          gp[i] = cs * x - sn * y;
-          gq[i] = sn * x + cs * y;
-        }
-        if (l16 == 0) ++rots;
-      }
+      if (ni == 20) rots += jacobi_pair<20>(gp, gq, l, l16, active, tol2);
+      else if (ni == 16) rots += jacobi_pair<16>(gp, gq, l, l16, active, tol2);
+      else if (ni == 10) rots += jacobi_pair<10>(gp, gq, l, l16, active, tol2);
+      else rots += jacobi_pair<0>(gp, gq, l, l16, active, tol2);
       __syncthreads();
     }
   }
