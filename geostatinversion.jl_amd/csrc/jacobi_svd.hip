@@ -34,10 +34,21 @@ __device__ inline double wave_allsum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-// sum over the 16 lanes of a quarter wave (stays inside one DPP row)
-__device__ inline double quarter_allsum(double v) {
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+// sum over the 16 lanes of a quarter wave = one DPP row: four row rotations (row_ror 8, 4, 2, 1), VALU only.
+// (__shfl_xor is ds_bpermute on gfx9: four dependent LDS-pipe round trips per sum, three sums per column pair and
+// round.)  The partial sums are periodic in the lane index, so each rotation adds the same two numbers the xor
+// butterfly added: bit-identical results.
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quarter_allsum(double v) {
+  v += dpp_row_mov<0x128>(v);      // row_ror:8
+  v += dpp_row_mov<0x124>(v);      // row_ror:4
+  v += dpp_row_mov<0x122>(v);      // row_ror:2
+  v += dpp_row_mov<0x121>(v);      // row_ror:1
   return v;
 }
 
