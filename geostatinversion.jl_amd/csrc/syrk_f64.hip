@@ -339,9 +339,11 @@ __global__ __launch_bounds__(SY_THREADS) void tr_kernel(const double* __restrict
           if (bb < NB && bb >= kb) acc[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[g & 1][b], fa, acc[bb], 0, 0, 0);
         }
       }
-      if (st == 0 && kb + 1 < nkb) {
+      if (st == ((r & 4) ? 2 : 0) && kb + 1 < nkb) {      // waves r and r + 4 share a SIMD: staging chores half a chunk apart,
+        __builtin_amdgcn_s_setprio(0);                     // at low priority (one of the two is always in an MFMA stretch)
         store((kb + 1) & 1, kb + 1);
         if (kb + 2 < nkb) prefetch(kb + 2);
+        __builtin_amdgcn_s_setprio(1);
       }
     }
     __syncthreads();
