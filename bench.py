@@ -40,7 +40,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
-KERNEL_SOURCES = ["gemm_f64.hip"]          # what `traffic` was measured on (hash recorded next to the counters)
+KERNEL_SOURCES = ["gemm_f64.hip", "panel_lu_leaf.hip", "syrk_f64.hip", "cholqr.hip"]   # what the counters in
+# profiles/r02_bench_traffic.json were measured on (hash recorded next to them: stale counters are not replayed)
 
 
 def kernel_source_hash():
@@ -205,6 +206,7 @@ def main():
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     hbm_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
+    panel_traffic = {}
     tpath = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
     if os.path.exists(tpath) and world == 1:
         try:
@@ -212,8 +214,12 @@ def main():
             if (t.get("kernel_source_hash") == kernel_source_hash() and t.get("n") == n and t.get("samples") == Ns
                     and t.get("l") == l):
                 traffic = t.get("hbm_bytes_per_launch")
+                for k in ("lu", "qr"):
+                    if t.get(k, {}).get("hbm_bytes_per_factorization"):
+                        panel_traffic[k] = float(t[k]["hbm_bytes_per_factorization"])
         except Exception:
             traffic = None
+            panel_traffic = {}
     roofline = {
         "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
@@ -235,6 +241,10 @@ def main():
             phases_hbm[name] = {"ms_per_factorization": per, "factorizations_per_step": cnt / args.steps,
                                 "algorithmic_bytes": panel_bytes, "GB/s": panel_bytes / (per * 1e-3) / 1e9,
                                 "frac_of_hbm_peak": panel_bytes / (per * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            if name in panel_traffic:        # bytes the factorization actually moved (PMC passes of this command)
+                phases_hbm[name]["traffic"] = panel_traffic[name]
+                phases_hbm[name]["traffic_GB/s"] = panel_traffic[name] / (per * 1e-3) / 1e9
+                phases_hbm[name]["traffic_frac_of_hbm_peak"] = panel_traffic[name] / (per * 1e-3) / 1e9 / PEAK_HBM_GBS
     phases_hbm["svd_small_jacobi_ms_per_step"] = phases["svd"][0] / args.steps
 
     if rank == 0:
