@@ -123,10 +123,24 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   else rr_pair(nblk, round, blockIdx.x, &ba, &bb);
   if (tid == 0) s_rot = 0;
   // load: local column c <- global column (c < W ? ba*W + c : bb*W + c - W), zero beyond l
-  for (int e = tid; e < SVD_C * lp; e += SVD_THREADS) {
-    const int c = e / lp, r = e % lp;
-    const int gc = (c < SVD_W) ? ba * SVD_W + c : bb * SVD_W + (c - SVD_W);
-    cols[e] = (gc < l && r < l) ? G[r + (int64_t)gc * l] : 0.0;
+  if ((l & 1) == 0) {
+    // even l (lp is even by construction): row pairs as 16-byte loads, column by column -- no division per element,
+    // half the load instructions
+    for (int r2 = tid; 2 * r2 < lp; r2 += SVD_THREADS) {
+#pragma unroll 8
+      for (int c = 0; c < SVD_C; ++c) {
+        const int gc = (c < SVD_W) ? ba * SVD_W + c : bb * SVD_W + (c - SVD_W);
+        double2 v = make_double2(0.0, 0.0);
+        if (gc < l && 2 * r2 < l) v = *reinterpret_cast<const double2*>(G + 2 * r2 + (int64_t)gc * l);
+        *reinterpret_cast<double2*>(cols + c * lp + 2 * r2) = v;
+      }
+    }
+  } else {
+    for (int e = tid; e < SVD_C * lp; e += SVD_THREADS) {
+      const int c = e / lp, r = e % lp;
+      const int gc = (c < SVD_W) ? ba * SVD_W + c : bb * SVD_W + (c - SVD_W);
+      cols[e] = (gc < l && r < l) ? G[r + (int64_t)gc * l] : 0.0;
+    }
   }
   __syncthreads();
   int rots = 0;
@@ -153,10 +167,20 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   }
   if (l16 == 0 && rots) atomicAdd(&s_rot, rots);
   __syncthreads();
-  for (int e = tid; e < SVD_C * lp; e += SVD_THREADS) {
-    const int c = e / lp, r = e % lp;
-    const int gc = (c < SVD_W) ? ba * SVD_W + c : bb * SVD_W + (c - SVD_W);
-    if (gc < l && r < l) G[r + (int64_t)gc * l] = cols[e];
+  if ((l & 1) == 0) {
+    for (int r2 = tid; 2 * r2 < l; r2 += SVD_THREADS) {
+#pragma unroll 8
+      for (int c = 0; c < SVD_C; ++c) {
+        const int gc = (c < SVD_W) ? ba * SVD_W + c : bb * SVD_W + (c - SVD_W);
+        if (gc < l) *reinterpret_cast<double2*>(G + 2 * r2 + (int64_t)gc * l) = *reinterpret_cast<const double2*>(cols + c * lp + 2 * r2);
+      }
+    }
+  } else {
+    for (int e = tid; e < SVD_C * lp; e += SVD_THREADS) {
+      const int c = e / lp, r = e % lp;
+      const int gc = (c < SVD_W) ? ba * SVD_W + c : bb * SVD_W + (c - SVD_W);
+      if (gc < l && r < l) G[r + (int64_t)gc * l] = cols[e];
+    }
   }
   if (tid == 0 && s_rot) atomicAdd(rotcount, s_rot);
 }
