@@ -570,15 +570,19 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
 
 // U12 = L11^-1 A12 for the K x K unit-lower block at (jb, jb) and the columns [c0, c1): out[k + (c - c0) K].
 // Thread = one column; L11 in LDS (broadcast reads), the column in registers.
+// (256 threads bring L11 in -- K^2 / 256 loads each instead of K^2 / 64: the kernel sits between two blocks of the
+// factorization and is all latency -- then the first wave solves its 64 columns.)
 template <int K>
-__global__ __launch_bounds__(64) void lu_u12_kernel(const double* __restrict__ Y, int64_t ld, int64_t jb, int64_t c0,
-                                                    int64_t c1, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void lu_u12_kernel(const double* __restrict__ Y, int64_t ld, int64_t jb, int64_t c0,
+                                                     int64_t c1, double* __restrict__ out) {
   __shared__ double L11[K * K];
-  for (int e = threadIdx.x; e < K * K; e += 64) {
+#pragma unroll 8
+  for (int e = threadIdx.x; e < K * K; e += 256) {
     const int r = e % K, c = e / K;
     L11[r * K + c] = Y[(jb + r) + (jb + c) * ld];       // [row][col]: a row's multipliers are contiguous
   }
   __syncthreads();
+  if (threadIdx.x >= 64) return;
   const int64_t c = c0 + (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (c >= c1) return;
   double x[K];
@@ -728,10 +732,10 @@ void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu
       const unsigned gu = (unsigned)((t + 63) / 64);
       const unsigned gr = (unsigned)((mr + 127) / 128);
       if (b == 64) {
-        hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(64), 0, st, Y, ld, jb, c0, l, w.u12);
+        hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(256), 0, st, Y, ld, jb, c0, l, w.u12);
         if (mr > 0) launch_rankk<64>(st, gr, Y, ld, m, c0, jb, c0, t, w.u12);
       } else {
-        hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(64), 0, st, Y, ld, jb, c0, l, w.u12);
+        hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(256), 0, st, Y, ld, jb, c0, l, w.u12);
         if (mr > 0) launch_rankk<32>(st, gr, Y, ld, m, c0, jb, c0, t, w.u12);
       }
     }
@@ -984,8 +988,8 @@ void lus_pending(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t ro
 void lus_u12_block(hipStream_t st, const double* Y, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t c1,
                    double* U12) {
   const unsigned gu = (unsigned)((c1 - c0 + 63) / 64);
-  if (b == 64) hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(64), 0, st, Y, ld, jb - row0, c0, c1, U12);
-  else hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(64), 0, st, Y, ld, jb - row0, c0, c1, U12);
+  if (b == 64) hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(256), 0, st, Y, ld, jb - row0, c0, c1, U12);
+  else hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(256), 0, st, Y, ld, jb - row0, c0, c1, U12);
 }
 void lus_rankk(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t jb, int b, int64_t c0, int64_t t,
                const double* U12) {
