@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void sy_reduce_kernel(const double* __restrict
   using G = SyGeom<NB>;
   const int t = blockIdx.x, tid = threadIdx.x;
   double v = 0.0;
-  for (int s = 0; s < nslab; ++s) v += P[((int64_t)s * G::NBLK + t) * 256 + tid];
+#pragma unroll 16
+  for (int s = 0; s < nslab; ++s) v += P[((int64_t)s * G::NBLK + t) * 256 + tid];      // loads in flight, sums in slab order
   int bi = 0;
   while (G::row_start(bi + 1) <= t) ++bi;
   const int bj = bi + (t - G::row_start(bi));
