@@ -184,9 +184,23 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
 
   // ---- pending update of the block's earlier columns: a -= L[:, jb:j0] * (L11^-1 A12) ----------------------
   if (kp > 0) {
-    for (int e = tid; e < kp * kp; e += BS) {
-      const int r = e % kp, c = e / kp;
-      Ls[r * LSP + c] = Y[(jb + r) + (int64_t)(jb + c) * ld];
+    {
+      // all of a thread's elements of the kp x kp block are requested before the first one is used: as a plain loop this
+      // was one HBM / L2 round trip per iteration (up to KPMAX^2 / BS of them) at the head of every leaf
+      constexpr int NLS = (KPMAX * KPMAX + BS - 1) / BS;
+      double lsv[NLS];
+#pragma unroll
+      for (int i = 0; i < NLS; ++i) {
+        const int e = tid + i * BS;
+        const int ec = e < kp * kp ? e : 0;
+        const int r = ec % kp, c = ec / kp;
+        lsv[i] = Y[(jb + r) + (int64_t)(jb + c) * ld];
+      }
+#pragma unroll
+      for (int i = 0; i < NLS; ++i) {
+        const int e = tid + i * BS;
+        if (e < kp * kp) Ls[(e % kp) * LSP + e / kp] = lsv[i];
+      }
     }
     __syncthreads();
     for (int v = wave; v < LW; v += NW) {          // one wave per leaf column: forward substitution along the lanes
