@@ -40,15 +40,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
-KERNEL_SOURCES = ["gemm_f64.hip", "panel_lu_leaf.hip", "syrk_f64.hip", "cholqr.hip"]   # what the counters in
-# profiles/r02_bench_traffic.json were measured on (hash recorded next to them: stale counters are not replayed)
+TRAFFIC_FILES = ["r03_bench_traffic.json", "r02_bench_traffic.json"]   # newest first; replayed only on a hash match
 
 
 def kernel_source_hash():
+    """sha256 over EVERY file of csrc/ (kernels, backend, pipeline, ABI) + the public header: any change to what is
+    launched, or how, invalidates the replayed PMC traffic figures."""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "geostatinversion.jl_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+    d = os.path.join(ROOT, "geostatinversion.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if os.path.isfile(os.path.join(d, f)):
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    with open(os.path.join(ROOT, "include", "gsi_hip.h"), "rb") as fh:
+        h.update(fh.read())
     return h.hexdigest()[:16]
 
 
@@ -62,7 +68,30 @@ def dense_bytes(n, l, q):
     return P * (8.0 * n * n + 16.0 * n * l)
 
 
-def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234):
+def fft_pair_bytes(Ns, Ms):
+    """Bytes the 2d - 1 passes of the FFT operator must move per column PAIR (the zero padding is neither
+    stored nor read): a forward pass along axis a < d-1 reads prod_{b<a} M_b * N_a * prod_{b>a} N_b complex values and
+    writes the same with M_a, the inverse passes mirror that; the fused last-axis pass reads and writes
+    prod_{b<d-1} M_b * N_{d-1}; plus 8 B per embedded point for the spectrum."""
+    units, d = 0.0, len(Ns)
+    for ax in range(d - 1):
+        lo, hi = 1.0, 1.0
+        for b in range(ax):
+            lo *= Ms[b]
+        for b in range(ax + 1, d):
+            hi *= Ns[b]
+        units += 2.0 * lo * (Ns[ax] + Ms[ax]) * hi
+    lo = 1.0
+    for b in range(d - 1):
+        lo *= Ms[b]
+    units += 2.0 * lo * Ns[-1]
+    M = 1.0
+    for m in Ms:
+        M *= m
+    return 16.0 * units + 8.0 * M
+
+
+def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234, keep=None):
     """warmup + timed randsvd steps on device-resident inputs; returns (elapsed_s, phases, counters)."""
     l = K + p
     Omega = gsi.DeviceMatrix(ctx, n, l).randn(seed)
@@ -86,6 +115,10 @@ def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234):
     phases = ctx.phase_times()
     ctx.profile(False)
     Sh = S.to_host()[:, 0].copy()
+    if keep is not None:                 # the caller compares this very step with the oracle (full-size parity leg)
+        keep["Omega"], keep["Z"] = Omega, Z
+        S.close()
+        return elapsed, phases, Sh
     for m in (Omega, Z, S):
         m.close()
     return elapsed, phases, Sh
@@ -126,6 +159,28 @@ def cpu_baseline_and_parity(gsi, ctx, Ns, K, p, q, n_s, decay):
     }, err, xerr
 
 
+def full_size_parity(host, Ns, K, p, q, Sv):
+    """The metric's rel-err AT the metric's size: the oracle (RandMatFact.jl:83-90 over lowrank.jl's operator, dgetrf /
+    dgeqp3 / dgesdd panels) on the very operator, Omega and step the HIP path was timed on -- the centred samples, Omega
+    and Z of the last timed step downloaded from HBM.  The oracle's products run in GEMM form S'(S X)/(N-1) here (the
+    ger! loop of lowrank.jl:115-121 would take hours at n = 1e6; rounding-order difference only); the n = 16384 sample
+    of cpu_baseline keeps the reference's loop."""
+    from oracle import oracle as orc
+    from helpers import rel_sv_err
+    n = host["Omega"].shape[0]
+    t0 = time.perf_counter()
+    A = orc.LowRankCovMatrix(host.pop("samples"), gemm_form=True)
+    Zref, Sref, _ = orc.randsvd_full(A, K, p, q, host["Omega"])
+    t_cpu = time.perf_counter() - t0
+    err = rel_sv_err(Sv, Sref, K)
+    xerr = orc.xis_error_up_to_sign(host["Z"], Zref, K)
+    tail_zero = bool((host["Z"][:, K:] == 0.0).all())
+    return {"n": int(n), "samples": int(Ns), "K": K, "p": p, "q": q, "sv_rel_err": err, "xis_err_up_to_sign": xerr,
+            "trailing_p_columns_zero": tail_zero, "oracle_seconds": t_cpu, "oracle_threads": host_threads(),
+            "oracle_products": "gemm form S'(S X)/(N-1) (rounding-order difference from lowrank.jl:115-121's ger! loop)",
+            "inputs": "centred samples, Omega and the last timed step's Z/S downloaded from HBM: the timed operator itself"}
+
+
 def main():
     # stdout carries exactly ONE line (the JSON result of rank 0): libraries that chat on fd 1 (gloo's
     # "[Gloo] Rank 0 is connected ...", RCCL's version banner) are sent to stderr for the whole run.
@@ -145,7 +200,10 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 dense and the implicit 10^6 steps")
+    ap.add_argument("--no-fft-512cube", action="store_true", help="skip the one 512^3 FFT-operator step (~230 GB of HBM)")
     ap.add_argument("--cpu-sample-n", type=int, default=16384)
+    ap.add_argument("--no-full-parity", action="store_true",
+                    help="skip the oracle run at the headline size (about 1-2 min of host LAPACK, ~40 GB of host memory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,10 +247,17 @@ def main():
     Ns, K, p, q = args.samples, args.K, args.p, args.q
     l = K + p
     op = gsi.lowrank_synthetic_operator(ctx, n, Ns, seed=0, decay=args.decay)      # samples generated + centred in HBM
-    elapsed, phases, Sv = run_steps(gsi, ctx, op, n, K, p, q, args.steps, args.warmup, barrier)
+    full_parity = world == 1 and not args.no_cpu_baseline and not args.no_full_parity
+    keep = {} if full_parity else None
+    elapsed, phases, Sv = run_steps(gsi, ctx, op, n, K, p, q, args.steps, args.warmup, barrier, keep=keep)
     elapsed = max_over_ranks(elapsed)
     counters = ctx.counters()
     dev_bytes = ctx.device_bytes()
+    host = None
+    if full_parity:                      # after the timed region: what the oracle needs, off the device
+        host = {"samples": gsi.device_samples(op, Ns), "Omega": keep["Omega"].to_host(), "Z": keep["Z"].to_host()}
+        keep["Omega"].close()
+        keep["Z"].close()
     op.close()
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -207,22 +272,28 @@ def main():
     hbm_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     panel_traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
-    if os.path.exists(tpath) and world == 1:
+    traffic_source = None
+    for tname in TRAFFIC_FILES if world == 1 else []:
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tpath):
+            continue
         try:
             t = json.load(open(tpath))
-            if (t.get("kernel_source_hash") == kernel_source_hash() and t.get("n") == n and t.get("samples") == Ns
+            if (t.get("csrc_hash") == kernel_source_hash() and t.get("n") == n and t.get("samples") == Ns
                     and t.get("l") == l):
                 traffic = t.get("hbm_bytes_per_launch")
                 for k in ("lu", "qr"):
                     if t.get(k, {}).get("hbm_bytes_per_factorization"):
                         panel_traffic[k] = float(t[k]["hbm_bytes_per_factorization"])
+                traffic_source = "replayed from profiles/%s (rocprofv3 --pmc passes of this command on this build: " \
+                                 "csrc hash %s); not measured in this run" % (tname, t.get("csrc_hash"))
+                break
         except Exception:
             traffic = None
             panel_traffic = {}
     roofline = {
         "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+        "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
         "kernel": "gemm_f64_kernel<NT,TRANS_A,GEN,XMODE> (v_mfma_f64_16x16x4_f64) + its fixed-order split-K slab reduction",
         "avg_launch_ms": avg_ms, "launches": int(g_cnt),
         "flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -315,7 +386,7 @@ def main():
         e4, ph4, _ = run_steps(gsi, ctx, op4, n4, K4, p4, q4, 5, 1, barrier)
         op4.close()
         Mf = 1 << int(np.ceil(np.log2(2 * gf)))
-        pair_bytes = 16.0 * (2 * (gf + Mf) * gf + 2 * Mf * gf) + 8.0 * Mf * Mf
+        pair_bytes = fft_pair_bytes([gf, gf], [Mf, Mf])
         prod_ms = (ph4["gemm_n"][0] + ph4["gemm_t"][0]) / (ph4["gemm_n"][1] + ph4["gemm_t"][1])
         sec["fft_powerlaw_1000sq"] = {
             "workload": f"matrix-free FFT power-law covariance (beta = -3.5) of a {gf}x{gf} grid, embedding {Mf}x{Mf}, "
@@ -324,14 +395,48 @@ def main():
             "product_algorithmic_GB/s": (l4 // 2) * pair_bytes / (prod_ms * 1e-3) / 1e9,
             "product_frac_of_hbm_peak": (l4 // 2) * pair_bytes / (prod_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "phases_ms_per_step": {k: v[0] / 5 for k, v in ph4.items()}}
+        # BASELINE.json configs[2]'s own grid: 512^3 points (n = 1.34e8), FFTRF convention (512 is a power of two:
+        # exactly FFTRF.jl:83-90's 1024^3 embedding), at the sketch width one GPU's 288 GB hold (four n x l fp64 panels
+        # of 51 GB + spectrum + work array); rank 256 needs the panels spread over GPUs.  ONE step.
+        if not args.no_fft_512cube:
+            gc3, K5, p5, q5 = 512, 39, 9, 2
+            n5, l5 = gc3 ** 3, K5 + p5
+            op5 = gsi.fft_powerlaw_operator(ctx, [gc3, gc3, gc3], -3.5, fftrf=True)
+            e5, ph5, _ = run_steps(gsi, ctx, op5, n5, K5, p5, q5, 1, 0, barrier)
+            peak_bytes5 = ctx.device_bytes()
+            op5.close()
+            M5 = 2 * gc3
+            pair5 = fft_pair_bytes([gc3] * 3, [M5] * 3)
+            prod5 = (ph5["gemm_n"][0] + ph5["gemm_t"][0]) / (ph5["gemm_n"][1] + ph5["gemm_t"][1])
+            sec["fft_powerlaw_512cube"] = {
+                "workload": f"matrix-free FFTRF-convention power-law covariance (beta = -3.5) of a {gc3}^3 grid "
+                            f"(n = {n5}), embedding {M5}^3, K={K5}, p={p5} (l={l5}: what one GPU's HBM holds), q={q5} "
+                            "(BASELINE.json configs[2]'s grid; rank 256 needs column-sharded panels over GPUs)",
+                "steps": 1, "ms_per_step": 1e3 * e5, "ms_per_product": prod5,
+                "product_algorithmic_GB/s": (l5 // 2) * pair5 / (prod5 * 1e-3) / 1e9,
+                "product_frac_of_hbm_peak": (l5 // 2) * pair5 / (prod5 * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "device_bytes_in_use_after_step": peak_bytes5,
+                "phases_ms_per_step": {k: v[0] for k, v in ph5.items()}}
         out["secondary"] = sec
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             cb, err, xerr = cpu_baseline_and_parity(gsi, ctx, Ns, K, p, q, args.cpu_sample_n, args.decay)
             out["cpu_baseline"] = cb
-            out["sv_rel_err"] = err
-            out["xis_err_up_to_sign"] = xerr
+            small = {"n": args.cpu_sample_n, "sv_rel_err": err, "xis_err_up_to_sign": xerr,
+                     "oracle_products": "the reference's ger!/gemv loop (lowrank.jl:115-121)"}
+            if host is not None:
+                # the metric's rel-err on the metric's configuration: HIP vs oracle on the timed operator itself
+                full = full_size_parity(host, Ns, K, p, q, Sv)
+                out["sv_rel_err"] = {"value": full["sv_rel_err"], "n": full["n"], "K": K, "tolerance": 1e-5}
+                out["xis_err_up_to_sign"] = {"value": full["xis_err_up_to_sign"], "n": full["n"], "K": K,
+                                             "tolerance": 1e-6}
+                out["parity_full_size"] = full
+                out["parity_cpu_sample"] = small
+            else:
+                out["sv_rel_err"] = {"value": err, "n": args.cpu_sample_n, "K": K, "tolerance": 1e-5}
+                out["xis_err_up_to_sign"] = {"value": xerr, "n": args.cpu_sample_n, "K": K, "tolerance": 1e-6}
+                out["parity_cpu_sample"] = small
         else:
             out["cpu_baseline"] = None
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -37,6 +37,7 @@ SIGNATURES = {
     "gsi_op_dense": (C.c_int, [c_vp, C.POINTER(c_vp), c_dp, c_i64, c_i64, c_i64, c_i64, c_i64]),
     "gsi_op_lowrank": (C.c_int, [c_vp, C.POINTER(c_vp), c_dp, c_i64, c_i64, c_i64, C.c_int, c_i64, c_i64]),
     "gsi_op_lowrank_synthetic": (C.c_int, [c_vp, C.POINTER(c_vp), c_i64, c_i64, C.c_uint64, C.c_double, c_i64, c_i64]),
+    "gsi_op_lowrank_samples": (C.c_int, [c_vp, c_vp, c_dp, c_i64]),
     "gsi_op_dense_gridcov": (C.c_int, [c_vp, C.POINTER(c_vp), c_i64, c_i64, C.c_double, C.c_int, c_i64, c_i64]),
     "gsi_op_gridcov_implicit": (C.c_int, [c_vp, C.POINTER(c_vp), c_i64, c_i64, C.c_double, c_i64, c_i64]),
     "gsi_op_gridcov_implicit_kind": (C.c_int, [c_vp, C.POINTER(c_vp), c_i64, c_i64, C.c_double, C.c_int, c_i64, c_i64]),

@@ -192,6 +192,17 @@ int gsi_op_lowrank_synthetic(gsi_ctx* ctx, gsi_op** op, int64_t n, int64_t N, ui
   });
 }
 
+int gsi_op_lowrank_samples(gsi_ctx* ctx, const gsi_op* op, double* samples_out, int64_t ld) {
+  return guarded([&] {
+    REQUIRE(ctx && op && samples_out, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c, "operator belongs to another context");
+    const Operator& A = op->op;
+    REQUIRE(A.kind == OP_LOWRANK, "the operator is not a LowRankCovMatrix");
+    REQUIRE(ld >= A.mloc && ld >= 1, "leading dimension too small");
+    if (A.mloc > 0) ctx->c.be->download2d(samples_out, ld, A.data.p, A.ld, A.mloc, A.N);
+  });
+}
+
 int gsi_op_dense_gridcov(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t ny, double ell, int kind,
                          int64_t row0, int64_t m_local) {
   return guarded([&] {

@@ -65,6 +65,11 @@ class LowRankCovMatrix:
     def todense(self):
         return self.matmul(np.eye(self.n))
 
+    @property
+    def samples(self):
+        """`A.samples` (lowrank.jl:14-16): the mean-removed samples as the device holds them, N x n (one per row)."""
+        return device_samples(self._device_operator(), self.N)
+
     def solve(self, b, *, return_iterations=False):
         """`\\(A::LowRankCovMatrix, b::Vector)`  (lowrank.jl:141-144): `lsqr(A, b; maxiter=length(A.samples))` with
         IterativeSolvers' defaults, every vector resident in HBM (`gsi_op_lowrank_solve`)."""
@@ -82,6 +87,18 @@ class LowRankCovMatrix:
         if self._op is not None:
             self._op.close()
             self._op = None
+
+
+def device_samples(op, N):
+    """Centred samples of a device LowRankCovMatrix operator (`gsi_op_lowrank_samples`), N x n, one sample per row
+    (this rank's columns when the operator is row-sharded)."""
+    m = C.c_int64()
+    r0 = C.c_int64()
+    ml = C.c_int64()
+    L.check(op.ctx.lib.gsi_op_size(op.h, C.byref(m), None, C.byref(r0), C.byref(ml)), op.ctx.lib)
+    out = np.empty((int(N), max(ml.value, 1)))                # C order N x n_local == column-major n_local x N
+    L.check(op.ctx.lib.gsi_op_lowrank_samples(op.ctx.h, op.h, out.ctypes.data_as(L.c_dp), max(ml.value, 1)), op.ctx.lib)
+    return out[:, :ml.value]
 
 
 class PCGALowRankMatrix:

@@ -106,6 +106,15 @@ function LowRankCovMatrix(samples::Array{Array{Float64, 1}, 1}; c::Context=ctx()
 	return op
 end
 
+"`A.samples` of a device LowRankCovMatrix (lowrank.jl:14-16; mean-removed, lowrank.jl:25-27) back on the host as the
+reference keeps them: a Vector of N sample vectors (`gsi_op_lowrank_samples`)."
+function samples(A::DeviceOperator, N::Int)
+	S = Matrix{Float64}(undef, A.m, N)
+	check(ccall((:gsi_op_lowrank_samples, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64),
+		A.c.h, A.h, S, A.m))
+	return [S[:, i] for i = 1:N]
+end
+
 "Gaussian covariance exp(-d^2/(2 ell^2)) of an nx x ny unit grid as a matrix-free operator: entries are regenerated
 inside the product kernel, nothing of size n^2 is stored (`gsi_op_gridcov_implicit`).  Usable wherever a Matrix is."
 function GridCovImplicit(nx::Int, ny::Int, ell::Float64; c::Context=ctx())

@@ -206,13 +206,18 @@ class LowRankCovMatrix:
     """``LowRankCovMatrix(samples)``  (lowrank.jl:14-30): implicit A = sum_i s_i s_i' / (N-1)
     over mean-removed samples; symmetric, ``adjoint(A) === A`` (lowrank.jl:38-44)."""
 
-    def __init__(self, samples):
+    def __init__(self, samples, gemm_form=False):
         S = np.asarray(samples, dtype=np.float64)         # N x n (one sample per row)
         if S.ndim != 2:
             raise ValueError("samples must be a sequence of equal-length vectors")
         means = S.sum(axis=0) / S.shape[0]                # :18-24
         self.samples = S - means[None, :]                 # :25-27
         self.N, self.n = S.shape
+        # gemm_form: the matrix products as S' (S B) / (N - 1) -- the sum of lowrank.jl:115-121's N rank-1 terms
+        # associated as two dgemms (differs from the ger! loop by rounding order only).  For sizes where N
+        # read-modify-write sweeps of the n x l result on the host would take hours (n = 1e6: bench.py's full-size
+        # parity leg); the default stays the reference's loop.
+        self.gemm_form = bool(gemm_form)
 
     @property
     def shape(self):                                      # size(A)  lowrank.jl:50-60
@@ -235,6 +240,10 @@ class LowRankCovMatrix:
             for s in self.samples:
                 out += alpha * (s * np.dot(B, s))             # BLAS.axpy!(1/(N-1), s * dot(x, s), v)   :75-81
             return out
+        if self.gemm_form:
+            T = self.samples @ B2                         # T[i, :] = (B' s_i)'      the gemv of :117
+            T *= alpha
+            return np.asfortranarray((T.T @ self.samples).T)   # sum_i s_i T[i, :]      the ger! of :118, summed by dgemm
         # BLAS.ger!(1/(N-1), s, B's, result), in place like the reference (:115-121)
         out = np.zeros((self.n, B2.shape[1]), order="F")
         Bt = np.ascontiguousarray(B2.T)

@@ -54,6 +54,21 @@ def test_golden_lowrank(gsi, cx):
     lrcm.close()
 
 
+def test_lowrank_samples_field(gsi, cx):
+    """`A.samples` (lowrank.jl:14-16, 25-27) comes back mean-removed, sample i = row i; the oracle's GEMM-form products
+    (bench.py's full-size parity leg) agree with the reference's ger! loop."""
+    rng = np.random.default_rng(5)
+    fields = rng.standard_normal((9, 37)) + 3.0
+    lrcm = gsi.LowRankCovMatrix(fields, ctx=cx)
+    ref = orc.LowRankCovMatrix(fields)
+    assert np.abs(lrcm.samples - ref.samples).max() < 1e-14
+    with pytest.raises(gsi.GsiError):
+        gsi.device_samples(gsi.dense_operator(cx, np.eye(4)), 3)
+    X = rng.standard_normal((37, 5))
+    assert np.abs(orc.LowRankCovMatrix(fields, gemm_form=True).matmul(X) - ref.matmul(X)).max() < 1e-13
+    lrcm.close()
+
+
 @pytest.mark.parametrize("n,m", [(10, 2), (100, 10), (100, 25)])
 def test_rangefinders_exact_rank(gsi, cx, n, m):
     """test/testrmf.jl:11-19 through the C ABI."""

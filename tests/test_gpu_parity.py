@@ -940,3 +940,46 @@ print("headline-ok")
             out[tag] = np.load(path)
     S1, S2 = out["dedicated"], out["general"]
     assert np.abs(S1 - S2).max() < 1e-11 * S1[0], np.abs(S1 - S2).max() / S1[0]
+
+
+# ---- the metric's rel-err at the metric's size (BASELINE.json "top-k singular-value rel-err, n=1e6 rank=256"): the oracle
+#      on the operator the HIP path ran on (samples, Omega downloaded), products in GEMM form.  Opt-in: ~2-5 min of host
+#      LAPACK and ~40 GB of host memory (GSI_TEST_HEADLINE_PARITY=1); bench.py runs the same comparison in every default
+#      run and records it in the driver's line. ----------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.skipif(not __import__("os").environ.get("GSI_TEST_HEADLINE_PARITY"),
+                    reason="opt-in (GSI_TEST_HEADLINE_PARITY=1): minutes of host LAPACK at n = 1e6")
+def test_headline_parity_vs_oracle(gsi):
+    ctx = gsi.default_context()
+    n, Ns, K, p, q = 1000000, 1024, 256, 64, 2
+    op = gsi.lowrank_synthetic_operator(ctx, n, Ns, seed=0, decay=0.75)
+    Om = gsi.DeviceMatrix(ctx, n, K + p).randn(1234)
+    Z = gsi.DeviceMatrix(ctx, n, K + p)
+    S = gsi.DeviceMatrix(ctx, K + p, 1)
+    gsi._lib.check(ctx.lib.gsi_randsvd_dev(ctx.h, op.h, Om.h, K, p, q, Z.h, S.h), ctx.lib)
+    samples, Omh, Zh, Sh = gsi.device_samples(op, Ns), Om.to_host(), Z.to_host(), S.to_host()[:, 0]
+    for h in (op, Om, Z, S):
+        h.close()
+    A = orc.LowRankCovMatrix(samples, gemm_form=True)
+    del samples
+    Zref, Sref, _ = orc.randsvd_full(A, K, p, q, Omh)
+    assert rel_sv_err(Sh, Sref, K) < 1e-9                      # bar 1e-5 (north_star)
+    assert orc.xis_error_up_to_sign(Zh, Zref, K) < 1e-6        # test/testrpcga.jl:100
+    assert np.all(Zh[:, K:] == 0.0)
+
+
+# ---- lu_leaf_kernel<512, 8>: the instantiation the headline panel (m = 1e6) runs -- 524288 < m <= 1048576 rows -- against
+#      dgetrf for pivots and L, a tie case included ---------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,l,ties", [(600001, 24, False), (1000000, 16, True)])
+def test_lu_headline_height_matches_lapack(gsi, ctx, m, l, ties):
+    rng = np.random.default_rng(m + l)
+    Y = rng.standard_normal((m, l))
+    if ties:                       # equal-magnitude maxima far apart, across workgroups: the lowest row must win
+        for j in range(0, l, 3):
+            r = rng.choice(m, size=3, replace=False)
+            Y[r, j] = [7.5, -7.5, 7.5]
+    L, piv = gsi.lu_L(Y, return_pivots=True, ctx=ctx)
+    assert np.array_equal(piv, orc.lu_pivots(Y))
+    Lref = orc.lu_L(Y)
+    assert np.abs(L - Lref).max() < 1e-11 * max(1.0, np.abs(Lref).max())
