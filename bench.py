@@ -159,6 +159,89 @@ def cpu_baseline_and_parity(gsi, ctx, Ns, K, p, q, n_s, decay):
     }, err, xerr
 
 
+def secondary_c2(gsi, ctx, barrier):
+    """BASELINE.json configs[1]: dense fp64 65536^2 Gaussian covariance, K = 128, p = 32, q = 2."""
+    g, K2, p2, q2 = 256, 128, 32, 2
+    n2, l2 = g * g, K2 + p2
+    op2 = gsi.gridcov_operator(ctx, g, g, 16.0, 0)
+    e2, ph2, _ = run_steps(gsi, ctx, op2, n2, K2, p2, q2, 5, 1, barrier)
+    op2.close()
+    gm = ph2["gemm_n"][0] + ph2["gemm_t"][0]
+    gc = ph2["gemm_n"][1] + ph2["gemm_t"][1]
+    tf = 2.0 * n2 * n2 * l2 / (gm / gc * 1e-3) / 1e12
+    return {
+        "workload": f"dense fp64 {n2}x{n2} Gaussian covariance (256x256 grid, ell=16), K={K2}, p={p2}, q={q2} "
+                    "(BASELINE.json configs[1])",
+        "steps": 5, "ms_per_step": 1e3 * e2 / 5, "GB/s": dense_bytes(n2, l2, q2) * 5 / e2 / 1e9,
+        "gemm_TFLOP/s": tf, "gemm_frac_of_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
+        "hbm_frac_of_A_stream": 8.0 * n2 * n2 / (gm / gc * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        "phases_ms_per_step": {k: v[0] / 5 for k, v in ph2.items()}}
+
+
+def secondary_implicit(gsi, ctx, barrier):
+    """n = 1e6 dense covariance, never stored (north_star "10^6 x 10^6-implicit"): ONE step, no warm-up."""
+    gi, K3, p3, q3 = 1000, 256, 64, 2
+    n3, l3 = gi * gi, K3 + p3
+    op3 = gsi.gridcov_implicit_operator(ctx, gi, gi, 100.0, kind=1)      # exponential kernel, ell = 100 (SURVEY 8d C4-i)
+    e3, ph3, _ = run_steps(gsi, ctx, op3, n3, K3, p3, q3, 1, 0, barrier)
+    op3.close()
+    gm = ph3["gemm_n"][0] + ph3["gemm_t"][0]
+    gc = ph3["gemm_n"][1] + ph3["gemm_t"][1]
+    tf = 2.0 * n3 * n3 * l3 / (gm / gc * 1e-3) / 1e12
+    return {
+        "workload": f"implicit dense fp64 {n3}x{n3} exponential grid covariance exp(-d/100) (1000x1000 grid; 8 TB if "
+                    f"stored), K={K3}, p={p3}, q={q3}: entries generated inside the contraction kernel from an 8 MB "
+                    "table of the kernel over grid offsets",
+        "steps": 1, "ms_per_step": 1e3 * e3, "equivalent_stored_GB/s": dense_bytes(n3, l3, q3) / e3 / 1e9,
+        "gemm_TFLOP/s": tf, "gemm_frac_of_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
+        "phases_ms_per_step": {k: v[0] for k, v in ph3.items()}}
+
+
+def secondary_fft_1000sq(gsi, ctx, barrier):
+    """BASELINE.json configs[2] (C3) at the size whose rank-256 panels fit one GPU: matrix-free FFT power-law covariance of
+    a 1000 x 1000 grid (n = 1e6), K = 205, p = 51 (l = 256), q = 2.  HBM-bound operator."""
+    import numpy as np
+    gf, K4, p4, q4 = 1000, 205, 51, 2
+    n4, l4 = gf * gf, K4 + p4
+    op4 = gsi.fft_powerlaw_operator(ctx, [gf, gf], -3.5)
+    e4, ph4, _ = run_steps(gsi, ctx, op4, n4, K4, p4, q4, 5, 1, barrier)
+    op4.close()
+    Mf = 1 << int(np.ceil(np.log2(2 * gf)))
+    pair_bytes = fft_pair_bytes([gf, gf], [Mf, Mf])
+    prod_ms = (ph4["gemm_n"][0] + ph4["gemm_t"][0]) / (ph4["gemm_n"][1] + ph4["gemm_t"][1])
+    return {
+        "workload": f"matrix-free FFT power-law covariance (beta = -3.5) of a {gf}x{gf} grid, embedding {Mf}x{Mf}, "
+                    f"K={K4}, p={p4}, q={q4} (BASELINE.json configs[2] at n = 1e6)",
+        "steps": 5, "ms_per_step": 1e3 * e4 / 5, "ms_per_product": prod_ms,
+        "product_algorithmic_GB/s": (l4 // 2) * pair_bytes / (prod_ms * 1e-3) / 1e9,
+        "product_frac_of_hbm_peak": (l4 // 2) * pair_bytes / (prod_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        "phases_ms_per_step": {k: v[0] / 5 for k, v in ph4.items()}}
+
+
+def secondary_fft_512cube(gsi, ctx, barrier):
+    """BASELINE.json configs[2]'s own grid: 512^3 points (n = 1.34e8), FFTRF convention (512 is a power of two: exactly
+    FFTRF.jl:83-90's 1024^3 embedding), at the sketch width one GPU's 288 GB hold (four n x l fp64 panels of 51 GB +
+    spectrum + work array); rank 256 needs the panels spread over GPUs.  ONE step."""
+    gc3, K5, p5, q5 = 512, 39, 9, 2
+    n5, l5 = gc3 ** 3, K5 + p5
+    op5 = gsi.fft_powerlaw_operator(ctx, [gc3, gc3, gc3], -3.5, fftrf=True)
+    e5, ph5, _ = run_steps(gsi, ctx, op5, n5, K5, p5, q5, 1, 0, barrier)
+    peak_bytes5 = ctx.device_bytes()
+    op5.close()
+    M5 = 2 * gc3
+    pair5 = fft_pair_bytes([gc3] * 3, [M5] * 3)
+    prod5 = (ph5["gemm_n"][0] + ph5["gemm_t"][0]) / (ph5["gemm_n"][1] + ph5["gemm_t"][1])
+    return {
+        "workload": f"matrix-free FFTRF-convention power-law covariance (beta = -3.5) of a {gc3}^3 grid "
+                    f"(n = {n5}), embedding {M5}^3, K={K5}, p={p5} (l={l5}: what one GPU's HBM holds), q={q5} "
+                    "(BASELINE.json configs[2]'s grid; rank 256 needs column-sharded panels over GPUs)",
+        "steps": 1, "ms_per_step": 1e3 * e5, "ms_per_product": prod5,
+        "product_algorithmic_GB/s": (l5 // 2) * pair5 / (prod5 * 1e-3) / 1e9,
+        "product_frac_of_hbm_peak": (l5 // 2) * pair5 / (prod5 * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        "device_bytes_in_use_after_step": peak_bytes5,
+        "phases_ms_per_step": {k: v[0] for k, v in ph5.items()}}
+
+
 def full_size_parity(host, Ns, K, p, q, Sv):
     """The metric's rel-err AT the metric's size: the oracle (RandMatFact.jl:83-90 over lowrank.jl's operator, dgetrf /
     dgeqp3 / dgesdd panels) on the very operator, Omega and step the HIP path was timed on -- the centred samples, Omega
@@ -344,79 +427,21 @@ def main():
     # ---------------- secondary workloads (one GPU only) -------------------------------------------------------
     if world == 1 and not args.no_secondary:
         sec = {}
-        # BASELINE.json configs[1]: dense fp64 65536^2 Gaussian covariance, K = 128, p = 32, q = 2
-        g, K2, p2, q2 = 256, 128, 32, 2
-        n2, l2 = g * g, K2 + p2
-        op2 = gsi.gridcov_operator(ctx, g, g, 16.0, 0)
-        e2, ph2, _ = run_steps(gsi, ctx, op2, n2, K2, p2, q2, 5, 1, barrier)
-        op2.close()
-        gm = ph2["gemm_n"][0] + ph2["gemm_t"][0]
-        gc = ph2["gemm_n"][1] + ph2["gemm_t"][1]
-        tf = 2.0 * n2 * n2 * l2 / (gm / gc * 1e-3) / 1e12
-        sec["c2_dense_65536"] = {
-            "workload": f"dense fp64 {n2}x{n2} Gaussian covariance (256x256 grid, ell=16), K={K2}, p={p2}, q={q2} "
-                        "(BASELINE.json configs[1])",
-            "steps": 5, "ms_per_step": 1e3 * e2 / 5, "GB/s": dense_bytes(n2, l2, q2) * 5 / e2 / 1e9,
-            "gemm_TFLOP/s": tf, "gemm_frac_of_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
-            "hbm_frac_of_A_stream": 8.0 * n2 * n2 / (gm / gc * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            "phases_ms_per_step": {k: v[0] / 5 for k, v in ph2.items()}}
-        # n = 1e6 dense covariance, never stored (north_star "10^6 x 10^6-implicit"): ONE step, no warm-up
-        gi, K3, p3, q3 = 1000, 256, 64, 2
-        n3, l3 = gi * gi, K3 + p3
-        op3 = gsi.gridcov_implicit_operator(ctx, gi, gi, 100.0, kind=1)      # exponential kernel, ell = 100
-        e3, ph3, _ = run_steps(gsi, ctx, op3, n3, K3, p3, q3, 1, 0, barrier)
-        op3.close()
-        gm = ph3["gemm_n"][0] + ph3["gemm_t"][0]
-        gc = ph3["gemm_n"][1] + ph3["gemm_t"][1]
-        tf = 2.0 * n3 * n3 * l3 / (gm / gc * 1e-3) / 1e12
-        sec["implicit_dense_1e6"] = {
-            "workload": f"implicit dense fp64 {n3}x{n3} exponential grid covariance exp(-d/100) (1000x1000 grid; 8 TB if "
-                        f"stored), K={K3}, p={p3}, q={q3}: entries generated inside the contraction kernel from an 8 MB "
-                        "table of the kernel over grid offsets",
-            "steps": 1, "ms_per_step": 1e3 * e3, "equivalent_stored_GB/s": dense_bytes(n3, l3, q3) / e3 / 1e9,
-            "gemm_TFLOP/s": tf, "gemm_frac_of_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
-            "phases_ms_per_step": {k: v[0] for k, v in ph3.items()}}
-        # BASELINE.json configs[2] (C3), at the size whose rank-256 panels fit one GPU: matrix-free FFT power-law
-        # covariance of a 1000 x 1000 grid (n = 1e6), K = 205, p = 51 (l = 256), q = 2.  HBM-bound operator:
-        # algorithmic bytes per column pair = what its 2d - 1 passes must move.
-        import numpy as np
-        gf, K4, p4, q4 = 1000, 205, 51, 2
-        n4, l4 = gf * gf, K4 + p4
-        op4 = gsi.fft_powerlaw_operator(ctx, [gf, gf], -3.5)
-        e4, ph4, _ = run_steps(gsi, ctx, op4, n4, K4, p4, q4, 5, 1, barrier)
-        op4.close()
-        Mf = 1 << int(np.ceil(np.log2(2 * gf)))
-        pair_bytes = fft_pair_bytes([gf, gf], [Mf, Mf])
-        prod_ms = (ph4["gemm_n"][0] + ph4["gemm_t"][0]) / (ph4["gemm_n"][1] + ph4["gemm_t"][1])
-        sec["fft_powerlaw_1000sq"] = {
-            "workload": f"matrix-free FFT power-law covariance (beta = -3.5) of a {gf}x{gf} grid, embedding {Mf}x{Mf}, "
-                        f"K={K4}, p={p4}, q={q4} (BASELINE.json configs[2] at n = 1e6; the 512^3 grid runs up to l = 48, DESIGN.md 4.6)",
-            "steps": 5, "ms_per_step": 1e3 * e4 / 5, "ms_per_product": prod_ms,
-            "product_algorithmic_GB/s": (l4 // 2) * pair_bytes / (prod_ms * 1e-3) / 1e9,
-            "product_frac_of_hbm_peak": (l4 // 2) * pair_bytes / (prod_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            "phases_ms_per_step": {k: v[0] / 5 for k, v in ph4.items()}}
-        # BASELINE.json configs[2]'s own grid: 512^3 points (n = 1.34e8), FFTRF convention (512 is a power of two:
-        # exactly FFTRF.jl:83-90's 1024^3 embedding), at the sketch width one GPU's 288 GB hold (four n x l fp64 panels
-        # of 51 GB + spectrum + work array); rank 256 needs the panels spread over GPUs.  ONE step.
+
+        def guarded(name, fn):
+            # a secondary workload must never take the headline line down with it: its failure is recorded instead
+            try:
+                sec[name] = fn()
+            except Exception as exc:                        # noqa: BLE001
+                sec[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                for ch in list(ctx._children):             # whatever the failed workload left on the device
+                    ch.close()
+
+        guarded("c2_dense_65536", lambda: secondary_c2(gsi, ctx, barrier))
+        guarded("implicit_dense_1e6", lambda: secondary_implicit(gsi, ctx, barrier))
+        guarded("fft_powerlaw_1000sq", lambda: secondary_fft_1000sq(gsi, ctx, barrier))
         if not args.no_fft_512cube:
-            gc3, K5, p5, q5 = 512, 39, 9, 2
-            n5, l5 = gc3 ** 3, K5 + p5
-            op5 = gsi.fft_powerlaw_operator(ctx, [gc3, gc3, gc3], -3.5, fftrf=True)
-            e5, ph5, _ = run_steps(gsi, ctx, op5, n5, K5, p5, q5, 1, 0, barrier)
-            peak_bytes5 = ctx.device_bytes()
-            op5.close()
-            M5 = 2 * gc3
-            pair5 = fft_pair_bytes([gc3] * 3, [M5] * 3)
-            prod5 = (ph5["gemm_n"][0] + ph5["gemm_t"][0]) / (ph5["gemm_n"][1] + ph5["gemm_t"][1])
-            sec["fft_powerlaw_512cube"] = {
-                "workload": f"matrix-free FFTRF-convention power-law covariance (beta = -3.5) of a {gc3}^3 grid "
-                            f"(n = {n5}), embedding {M5}^3, K={K5}, p={p5} (l={l5}: what one GPU's HBM holds), q={q5} "
-                            "(BASELINE.json configs[2]'s grid; rank 256 needs column-sharded panels over GPUs)",
-                "steps": 1, "ms_per_step": 1e3 * e5, "ms_per_product": prod5,
-                "product_algorithmic_GB/s": (l5 // 2) * pair5 / (prod5 * 1e-3) / 1e9,
-                "product_frac_of_hbm_peak": (l5 // 2) * pair5 / (prod5 * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "device_bytes_in_use_after_step": peak_bytes5,
-                "phases_ms_per_step": {k: v[0] for k, v in ph5.items()}}
+            guarded("fft_powerlaw_512cube", lambda: secondary_fft_512cube(gsi, ctx, barrier))
         out["secondary"] = sec
 
     if rank == 0:

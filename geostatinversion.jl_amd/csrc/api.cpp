@@ -59,6 +59,19 @@ int guarded(F&& f) {
   }
 }
 
+// Runs f; if it fails because the backend lost a resource it no longer depends on (Backend::retryable_failure: the
+// persistent LU kernel's co-residency on a shared GPU), runs it once more -- the entry points below never modify
+// their inputs (operator, Omega, the host panel), so a second run starts from the same state.
+template <class F>
+void with_retry(Context& c, F&& f) {
+  try {
+    f();
+  } catch (const Error&) {
+    if (!c.be->retryable_failure() || getenv("GSI_NO_RETRY") != nullptr) throw;   // GSI_NO_RETRY: tests of the error path
+    f();
+  }
+}
+
 #define REQUIRE(cond, msg) \
   do { if (!(cond)) throw Error(GSI_ERR_ARG, msg); } while (0)
 
@@ -350,11 +363,13 @@ int gsi_rangefinder(gsi_ctx* ctx, const gsi_op* op, const double* Omega, int64_t
     REQUIRE(l >= 1, "l must be positive");
     Buf Om(be, (size_t)A.n * l);
     be->upload2d(Om.p, A.n, Omega, A.n, A.n, l);
-    Buf Qloc = rangefinder(A, Om.p, l, numiterations);
-    Buf Qfull(be, (size_t)A.m * l);
-    gather_rows(ctx->c, A, Qloc.p, A.mloc, l, Qfull.p);
-    be->download2d(Q_out, A.m, Qfull.p, A.m, A.m, l);
-    check_async_errors(ctx->c);
+    with_retry(ctx->c, [&] {
+      Buf Qloc = rangefinder(A, Om.p, l, numiterations);
+      Buf Qfull(be, (size_t)A.m * l);
+      gather_rows(ctx->c, A, Qloc.p, A.mloc, l, Qfull.p);
+      check_async_errors(ctx->c);
+      be->download2d(Q_out, A.m, Qfull.p, A.m, A.m, l);
+    });
   });
 }
 
@@ -369,10 +384,12 @@ int gsi_randsvd(gsi_ctx* ctx, const gsi_op* op, const double* Omega, int64_t K, 
     const int64_t l = K + p;
     Buf Om(be, (size_t)A.n * l), Z(be, (size_t)A.n * l), S(be, (size_t)l);
     be->upload2d(Om.p, A.n, Omega, A.n, A.n, l);
-    randsvd(A, Om.p, K, p, q, Z.p, S.p);
+    with_retry(ctx->c, [&] {
+      randsvd(A, Om.p, K, p, q, Z.p, S.p);
+      check_async_errors(ctx->c);
+    });
     be->download2d(Z_out, A.n, Z.p, A.n, A.n, l);
     if (S_out) be->download2d(S_out, l, S.p, l, l, 1);
-    check_async_errors(ctx->c);
   });
 }
 
@@ -470,9 +487,11 @@ int gsi_rangefinder_dev(gsi_ctx* ctx, const gsi_op* op, const gsi_mat* Omega, in
     const int64_t l = Omega->cols;
     REQUIRE(Omega->rows == A.n, "Omega must have size(A,2) rows");
     REQUIRE(Q->rows == A.m && Q->cols == l, "Q must be size(A,1) x l");
-    Buf Qloc = rangefinder(A, Omega->buf.p, l, numiterations);
-    gather_rows(ctx->c, A, Qloc.p, A.mloc, l, Q->buf.p);
-    check_async_errors(ctx->c);
+    with_retry(ctx->c, [&] {
+      Buf Qloc = rangefinder(A, Omega->buf.p, l, numiterations);
+      gather_rows(ctx->c, A, Qloc.p, A.mloc, l, Q->buf.p);
+      check_async_errors(ctx->c);
+    });
   });
 }
 
@@ -496,8 +515,10 @@ int gsi_randsvd_dev(gsi_ctx* ctx, const gsi_op* op, const gsi_mat* Omega, int64_
       Stmp = Buf(be, (size_t)l);
       Sp = Stmp.p;
     }
-    randsvd(A, Omega->buf.p, K, p, q, Z->buf.p, Sp);
-    check_async_errors(ctx->c);
+    with_retry(ctx->c, [&] {
+      randsvd(A, Omega->buf.p, K, p, q, Z->buf.p, Sp);
+      check_async_errors(ctx->c);
+    });
   });
 }
 
@@ -508,10 +529,12 @@ int gsi_lu_L(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double* L_out,
     REQUIRE(m >= 1 && l >= 1 && l <= m, "lu_L: need 1 <= l <= m (tall panel)");
     Backend* be = ctx->c.be.get();
     Buf P(be, (size_t)m * l);
-    be->upload2d(P.p, m, Y, m, m, l);
-    be->lu_L(P.p, m, l, m, ipiv_out);
+    with_retry(ctx->c, [&] {
+      be->upload2d(P.p, m, Y, m, m, l);
+      be->lu_L(P.p, m, l, m, ipiv_out);
+      check_async_errors(ctx->c);
+    });
     be->download2d(L_out, m, P.p, m, m, l);
-    check_async_errors(ctx->c);
   });
 }
 
@@ -536,6 +559,36 @@ int gsi_lu_L_sharded(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double
     be->download2d(L_out, m, Full.p, m, m, l);
     if (ipiv_out) be->lus_pivots(ipiv_out, l);
     check_async_errors(c);
+  });
+}
+
+int gsi_lu_L_sharded_virtual(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, int nshards, double* L_out,
+                             int32_t* ipiv_out) {
+  return guarded([&] {
+    REQUIRE(ctx && Y && L_out, "NULL argument");
+    REQUIRE(m >= 1 && l >= 1 && l <= m, "lu_L: need 1 <= l <= m (tall panel)");
+    REQUIRE(nshards >= 1 && nshards <= 64, "need 1 <= nshards <= 64");
+    REQUIRE(nshards == 1 || l <= (m + nshards - 1) / nshards,
+            "sharded lu: the first shard must hold the first l rows (l <= ceil(m / nshards))");
+    Context& c = ctx->c;
+    Backend* be = c.be.get();
+    std::vector<Buf> shards;
+    std::vector<double*> ptrs;
+    for (int g = 0; g < nshards; ++g) {
+      int64_t r0, ml;
+      default_shard(m, nshards, g, &r0, &ml);
+      shards.emplace_back(be, (size_t)std::max<int64_t>(ml, 1) * l);
+      if (ml > 0) be->upload2d(shards.back().p, ml, Y + r0, m, ml, l);
+      ptrs.push_back(shards.back().p);
+    }
+    lu_panel_sharded_virtual(c, ptrs.data(), m, l, nshards);
+    check_async_errors(c);
+    for (int g = 0; g < nshards; ++g) {
+      int64_t r0, ml;
+      default_shard(m, nshards, g, &r0, &ml);
+      if (ml > 0) be->download2d(L_out + r0, m, ptrs[(size_t)g], ml, ml, l);
+    }
+    if (ipiv_out) be->lus_pivots(ipiv_out, l);
   });
 }
 

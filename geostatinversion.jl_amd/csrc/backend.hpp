@@ -150,6 +150,9 @@ class Backend {
   // error flags raised asynchronously by kernels (zero pivot, non-posdef); checked and
   // cleared by the pipeline at the end of each entry point. Returns GSI_* code or 0.
   virtual int take_error(std::string* msg) = 0;
+  // true (once) if the last error was a lost resource rather than a property of the input, and the backend has switched
+  // to a path that does not need it: the caller may run the same entry point again on its intact inputs
+  virtual bool retryable_failure() { return false; }
 
   // ---- profiling ----
   virtual void profile(bool on) = 0;

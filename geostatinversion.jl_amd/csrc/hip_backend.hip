@@ -266,7 +266,13 @@ class HipBackend : public Backend {
     // (panel_lu_leaf.hip).  Taller panels (and GSI_LU_SWEEPS=1, the A/B knob) take the per-column sweeps below.
     static const bool force_sweeps = (getenv("GSI_LU_SWEEPS") != nullptr);
     hipk::Lu2Work w2;
-    if (!force_sweeps && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid)) {
+    if (!force_sweeps && !lu2_lost_ && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid) &&
+        lu2_fits(w2.bs, w2.rpt, w2.grid)) {
+      // test / A-B knobs, read per call: GSI_LU_POLL_LIMIT (polls before a workgroup gives up), GSI_LU_TEST_MUTE_EPOCH
+      // (one workgroup stays silent at that pivot step: exercises the info = -1 path), GSI_LU_COOPERATIVE=1
+      if (const char* e = getenv("GSI_LU_POLL_LIMIT")) w2.poll_limit = atoi(e);
+      if (const char* e = getenv("GSI_LU_TEST_MUTE_EPOCH")) w2.mute_epoch = (uint32_t)atoi(e);
+      if (const char* e = getenv("GSI_LU_COOPERATIVE")) w2.cooperative = (e[0] == '1');
       static const int nb_env = getenv("GSI_LU_NB") ? atoi(getenv("GSI_LU_NB")) : 0;
       w2.nb = (nb_env == 32 || nb_env == 64) ? nb_env : hipk::LU2_NB;
       const size_t rec_bytes = sizeof(unsigned long long) * 2 * ((size_t)w2.grid + hipk::LU2_RES_COPIES) * hipk::LU2_REC_GRANULES;
@@ -621,6 +627,20 @@ class HipBackend : public Backend {
     check_launch("basis_gemv_f32");
   }
 
+  // The persistent leaf kernel spins on records of ALL its workgroups: the grid must fit the chip at this kernel's
+  // occupancy (registers, LDS, waves).  Queried once per instantiation; a panel that does not fit takes the sweeps.
+  bool lu2_fits(int bs, int rpt, int grid) {
+    const int key = bs * 16 + rpt;
+    auto it = lu2_resident_.find(key);
+    if (it == lu2_resident_.end()) it = lu2_resident_.emplace(key, hipk::lu2_resident_per_cu(bs, rpt)).first;
+    return (int64_t)it->second * ncus_ >= grid;
+  }
+  bool retryable_failure() override {
+    const bool r = lu2_retry_;
+    lu2_retry_ = false;
+    return r;
+  }
+
   int take_error(std::string* msg) override {
     bind();
     int32_t h[16];
@@ -630,7 +650,13 @@ class HipBackend : public Backend {
     if (h[0] != 0 || h[1] != 0) {
       HIP_CHECK(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), st_));
       if (h[0] < 0) {
-        if (msg) *msg = "lu(): the pivot exchange between workgroups timed out (GPU shared with another job?)";
+        // co-residency of the persistent leaf kernel was lost (a workgroup never got a CU: the GPU is shared with
+        // another queue).  The panel of that factorization is destroyed; this context factors with the per-column
+        // sweeps (no spin-waits between workgroups) from now on, and the entry point may be re-run on its inputs.
+        lu2_lost_ = true;
+        lu2_retry_ = true;
+        if (msg) *msg = "lu(): the pivot exchange between workgroups timed out (GPU shared with another job?); "
+                        "this context now uses the per-column sweeps";
         return GSI_ERR_INTERNAL;
       }
       if (h[0] != 0) {
@@ -713,7 +739,16 @@ class HipBackend : public Backend {
     b.p = nullptr; b.bytes = 0;
     bytes = (bytes + 4095) & ~(size_t)4095;
     hipError_t e = hipMalloc(&b.p, bytes);
-    if (e != hipSuccess) { (void)hipGetLastError(); throw Error(GSI_ERR_OOM, "workspace hipMalloc failed"); }
+    if (e != hipSuccess) {   // give the cache of released panels back and retry once (the other phases' workspaces may be
+      (void)hipGetLastError();   // in use by the caller: they stay)
+      trim_pool(0);
+      e = hipMalloc(&b.p, bytes);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
+      throw Error(GSI_ERR_OOM, "workspace hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    }
     b.bytes = bytes;
   }
   double* gemm_ws(size_t doubles) {
@@ -742,6 +777,8 @@ class HipBackend : public Backend {
   int last_svd_sweeps_ = 0;
   int64_t n_cholqr_ = 0, n_householder_ = 0, n_scholqr3_ = 0;
   std::map<std::pair<int64_t, bool>, int> skip_tier1_by_height_;
+  std::map<int, int> lu2_resident_;   // (bs, rpt) -> resident workgroups per CU of that leaf instantiation
+  bool lu2_lost_ = false, lu2_retry_ = false;
 };
 
 // ---- RCCL, bound lazily so a single-GPU user never needs librccl to resolve -----------------

@@ -72,7 +72,12 @@ struct Lu2Work {
   int32_t* ipiv;    // [l]
   int32_t* info;    // [1] first exactly-zero pivot (1-based); -1: the exchange between workgroups timed out
   int bs, rpt, grid, nb;
+  int poll_limit = 0;          // polls before a workgroup gives up on a record (0: the default, ~ seconds)
+  uint32_t mute_epoch = 0;     // tests only: the last workgroup publishes nothing at this pivot step (1-based)
+  bool cooperative = false;    // launch the leaves with hipLaunchCooperativeKernel (co-residency guaranteed by the runtime)
 };
+// workgroups of the (bs, rpt) leaf kernel that fit one CU (occupancy query); 0 if the query fails
+int lu2_resident_per_cu(int bs, int rpt);
 // launch geometry for an m-row panel on a chip with `ncus` CUs; false: the panel does not fit the register file
 bool lu2_config(int64_t m, int ncus, int* bs, int* rpt, int* grid);
 void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu2Work& w);

@@ -36,7 +36,7 @@ constexpr int LW = LU2_LEAF;           // leaf width (columns kept in registers)
 constexpr int KPMAX = LU2_NB - LW;     // deepest pending update inside a block
 constexpr int LSP = KPMAX + 1;         // padded row stride of the L11 image
 constexpr int REC = LU2_REC_GRANULES;  // 8-byte granules per published record (512 B): unit u = granules 2u (low half), 2u + 1
-constexpr int POLL_LIMIT = 4000000;    // ~ seconds: a record that never arrives ends the launch with info = -1
+constexpr int POLL_LIMIT = 4000000;    // default poll budget (~ seconds): a record that never arrives ends the launch with info = -1
 
 __device__ inline double readlane_d(double x, int srclane) {   // srclane wave-uniform
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -139,7 +139,8 @@ template <int BS, int R>
 __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int64_t ld, int32_t m, int32_t l,
                                                      int32_t jb, int32_t j0, int w, unsigned long long* __restrict__ recs,
                                                      uint32_t epoch_base, int32_t* __restrict__ ipiv,
-                                                     int32_t* __restrict__ info, int onehop) {
+                                                     int32_t* __restrict__ info, int onehop, int poll_limit,
+                                                     uint32_t mute_epoch) {
   constexpr int NW = BS / 64;
   constexpr int LPR = BS / 256;               // leader: consumer lanes per record (G <= 256 records)
   constexpr int GPL = (2 * (2 + LW)) / LPR;   // leader: granules per consumer lane
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x, G = gridDim.x;
   const int kp = j0 - jb;
-  if (tid == 0) s_abort = 0;
+  // a launch that follows a timed-out one (info < 0, same stream) drains without polling: one time-out per factorization
+  if (tid == 0) s_abort = (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) ? 1 : 0;
 
   // addressing: one uniform 64-bit column base (SGPRs) + a 32-bit per-thread byte offset, so no 64-bit per-element
   // address stays live in VGPRs between the load at the top and the store at the bottom (m < 2^28 rows)
@@ -303,7 +305,10 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
       const unsigned long long own = __ballot(lane < NW && pi >= 0 && mywi == pi);
       const int ww = own ? (__ffsll((long long)own) - 1) : 0;
       const int unit = lane >> 1;
-      if (unit < 2 + LW || (g == 0 && unit < 2 + 2 * LW)) {
+      // mute_epoch != 0 (tests only): the last workgroup stays silent at that step, as a workgroup that never got a CU
+      // would -- everyone else runs out of polls and the launch ends with info = -1
+      const bool muted = (mute_epoch != 0u && epoch == mute_epoch && g == G - 1);
+      if (!muted && (unit < 2 + LW || (g == 0 && unit < 2 + 2 * LW))) {
         unsigned long long bits;
         if (unit == 0) bits = (unsigned long long)__double_as_longlong(pv);
         else if (unit == 1) bits = (unsigned long long)(long long)pi;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
         const bool extra = tid < 2 * LW;                                    // workgroup 0's copy of row j
         const unsigned long long* xsrc = rec_set + 2 * (2 + LW) + (extra ? tid : 0);
         unsigned long long g0 = 0, g1 = 0, g2 = 0, gx = 0;
-        int tries = s_abort ? POLL_LIMIT : 0;
+        int tries = s_abort ? poll_limit : 0;
         bool ok;
         for (;;) {
           if (mine) {
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
           ok = !mine || ((uint32_t)(g0 >> 32) == epoch && (uint32_t)(g1 >> 32) == epoch && (uint32_t)(g2 >> 32) == epoch);
           if (extra) ok = ok && ((uint32_t)(gx >> 32) == epoch);
           if (__all(ok)) break;
-          if (++tries > POLL_LIMIT) break;
+          if (++tries > poll_limit) break;
           __builtin_amdgcn_s_sleep(1);
         }
         if (!__all(ok)) s_abort = 1;
@@ -375,13 +380,13 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
         const bool mine = lane < 2 * LW;
         const unsigned long long* rsrc = rec_set + (size_t)gw * REC + 4 + (mine ? lane : 0);
         unsigned long long gv = 0;
-        int tries = s_abort ? POLL_LIMIT : 0;
+        int tries = s_abort ? poll_limit : 0;
         bool ok;
         for (;;) {
           if (mine) gv = __hip_atomic_load(rsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = !mine || ((uint32_t)(gv >> 32) == epoch);
           if (__all(ok)) break;
-          if (++tries > POLL_LIMIT) break;
+          if (++tries > poll_limit) break;
           __builtin_amdgcn_s_sleep(1);
         }
         if (!__all(ok)) s_abort = 1;
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
       const unsigned long long* xsrc = rec_set + 2 * (2 + LW) + (extra ? tid : 0);
       if (wave < ncw) {
         unsigned long long gl[GPL], gx = 0;
-        int tries = s_abort ? POLL_LIMIT : 0;   // a timed-out launch drains without polling again
+        int tries = s_abort ? poll_limit : 0;   // a timed-out launch drains without polling again
         bool ok;
         for (;;) {
 #pragma unroll
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
           }
           if (extra) ok = ok && ((uint32_t)(gx >> 32) == epoch);
           if (__all(ok)) break;
-          if (++tries > POLL_LIMIT) break;
+          if (++tries > poll_limit) break;
           __builtin_amdgcn_s_sleep(1);
         }
         if (!__all(ok)) s_abort = 1;
@@ -472,13 +477,13 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
       if (wave == 0) {                          // poll the leader's result: granule `lane`
         const bool mine = lane < 2 * (2 + 2 * LW);
         unsigned long long gv = 0;
-        int tries = s_abort ? POLL_LIMIT : 0;
+        int tries = s_abort ? poll_limit : 0;
         bool ok;
         for (;;) {
           if (mine) gv = __hip_atomic_load(res + (size_t)(g % LU2_RES_COPIES) * REC + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = !mine || ((uint32_t)(gv >> 32) == epoch);
           if (__all(ok)) break;
-          if (++tries > POLL_LIMIT) break;
+          if (++tries > poll_limit) break;
           __builtin_amdgcn_s_sleep(1);
         }
         if (!__all(ok)) s_abort = 1;
@@ -587,20 +592,21 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
 // (256 threads bring L11 in -- K^2 / 256 loads each instead of K^2 / 64: the kernel sits between two blocks of the
 // factorization and is all latency -- then the first wave solves its 64 columns.)
 template <int K>
-__global__ __launch_bounds__(256) void lu_u12_kernel(const double* __restrict__ Y, int64_t ld, int64_t jb, int64_t c0,
-                                                     int64_t c1, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void lu_u12_kernel(const double* __restrict__ Y, int64_t ld, int64_t jb, int64_t jbrow,
+                                                     int64_t c0, int64_t c1, double* __restrict__ out) {
+  // jb: the block's first COLUMN (global); jbrow: the row of Y that holds global row jb (jb - row0 for a row shard)
   __shared__ double L11[K * K];
 #pragma unroll 8
   for (int e = threadIdx.x; e < K * K; e += 256) {
     const int r = e % K, c = e / K;
-    L11[r * K + c] = Y[(jb + r) + (jb + c) * ld];       // [row][col]: a row's multipliers are contiguous
+    L11[r * K + c] = Y[(jbrow + r) + (jb + c) * ld];    // [row][col]: a row's multipliers are contiguous
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;
   const int64_t c = c0 + (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (c >= c1) return;
   double x[K];
-  const double* col = Y + jb + c * ld;
+  const double* col = Y + jbrow + c * ld;
 #pragma unroll
   for (int r = 0; r < K; ++r) x[r] = col[r];
 #pragma unroll
@@ -718,10 +724,42 @@ bool lu2_config(int64_t m, int ncus, int* bs, int* rpt, int* grid) {
 
 template <int BS, int R>
 static void launch_leaf(hipStream_t st, int grid, double* Y, int64_t ld, int64_t m, int64_t l, int64_t jb, int64_t j0,
-                        int w, unsigned long long* recs, uint32_t epoch_base, int32_t* ipiv, int32_t* info) {
+                        int w, const Lu2Work& wk, uint32_t epoch_base) {
   static const int onehop = getenv("GSI_LU_ONEHOP") ? atoi(getenv("GSI_LU_ONEHOP")) : 1;   // A/B knob; 0 = two hops via a leader
-  hipLaunchKernelGGL((lu_leaf_kernel<BS, R>), dim3(grid), dim3(BS), 0, st, Y, ld, (int32_t)m, (int32_t)l, (int32_t)jb,
-                     (int32_t)j0, w, recs, epoch_base, ipiv, info, onehop);
+  const int poll_limit = wk.poll_limit > 0 ? wk.poll_limit : POLL_LIMIT;
+  if (!wk.cooperative) {
+    hipLaunchKernelGGL((lu_leaf_kernel<BS, R>), dim3(grid), dim3(BS), 0, st, Y, ld, (int32_t)m, (int32_t)l, (int32_t)jb,
+                       (int32_t)j0, w, wk.recs, epoch_base, wk.ipiv, wk.info, onehop, poll_limit, wk.mute_epoch);
+    return;
+  }
+  // cooperative launch: the runtime guarantees that all `grid` workgroups are resident together (and refuses the launch
+  // otherwise) -- what the spin-waits between workgroups rely on when the device is shared with other queues
+  int32_t m32 = (int32_t)m, l32 = (int32_t)l, jb32 = (int32_t)jb, j032 = (int32_t)j0;
+  int oh = onehop, pl = poll_limit;
+  uint32_t eb = epoch_base, mute = wk.mute_epoch;
+  unsigned long long* recs = wk.recs;
+  int32_t* ipiv = wk.ipiv;
+  int32_t* info = wk.info;
+  void* args[] = {&Y, &ld, &m32, &l32, &jb32, &j032, &w, &recs, &eb, &ipiv, &info, &oh, &pl, &mute};
+  (void)hipLaunchCooperativeKernel((const void*)lu_leaf_kernel<BS, R>, dim3(grid), dim3(BS), args, 0, st);
+}
+
+template <int BS, int R>
+static int leaf_resident_per_cu() {
+  int nblk = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)lu_leaf_kernel<BS, R>, BS, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return nblk;
+}
+// How many workgroups of the (bs, rpt) leaf kernel one CU holds (registers, LDS, waves): the persistent launch needs
+// grid <= that x CUs, or its spin-waits would wait for workgroups that cannot start.
+int lu2_resident_per_cu(int bs, int rpt) {
+  if (bs == 256 && rpt == 1) return leaf_resident_per_cu<256, 1>();
+  if (bs == 256) return leaf_resident_per_cu<256, 4>();
+  if (rpt == 4) return leaf_resident_per_cu<512, 4>();
+  return leaf_resident_per_cu<512, 8>();
 }
 
 void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu2Work& w) {
@@ -734,10 +772,10 @@ void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu
     for (int64_t j0 = jb; j0 < jb + b; j0 += LW) {
       const int wd = (int)((jb + b - j0 < LW) ? (jb + b - j0) : LW);
       // every leaf keeps the same grid: workgroups whose rows lie beyond m still take part in the exchange
-      if (w.bs == 256 && w.rpt == 1) launch_leaf<256, 1>(st, w.grid, Y, ld, m, l, jb, j0, wd, w.recs, epoch, w.ipiv, w.info);
-      else if (w.bs == 256) launch_leaf<256, 4>(st, w.grid, Y, ld, m, l, jb, j0, wd, w.recs, epoch, w.ipiv, w.info);
-      else if (w.rpt == 4) launch_leaf<512, 4>(st, w.grid, Y, ld, m, l, jb, j0, wd, w.recs, epoch, w.ipiv, w.info);
-      else launch_leaf<512, 8>(st, w.grid, Y, ld, m, l, jb, j0, wd, w.recs, epoch, w.ipiv, w.info);
+      if (w.bs == 256 && w.rpt == 1) launch_leaf<256, 1>(st, w.grid, Y, ld, m, l, jb, j0, wd, w, epoch);
+      else if (w.bs == 256) launch_leaf<256, 4>(st, w.grid, Y, ld, m, l, jb, j0, wd, w, epoch);
+      else if (w.rpt == 4) launch_leaf<512, 4>(st, w.grid, Y, ld, m, l, jb, j0, wd, w, epoch);
+      else launch_leaf<512, 8>(st, w.grid, Y, ld, m, l, jb, j0, wd, w, epoch);
       epoch += (uint32_t)LW;            // a narrow last leaf still runs (gated) 8 steps
     }
     const int64_t c0 = jb + b, t = l - c0;
@@ -746,10 +784,10 @@ void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu
       const unsigned gu = (unsigned)((t + 63) / 64);
       const unsigned gr = (unsigned)((mr + 127) / 128);
       if (b == 64) {
-        hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(256), 0, st, Y, ld, jb, c0, l, w.u12);
+        hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(256), 0, st, Y, ld, jb, jb, c0, l, w.u12);
         if (mr > 0) launch_rankk<64>(st, gr, Y, ld, m, c0, jb, c0, t, w.u12);
       } else {
-        hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(256), 0, st, Y, ld, jb, c0, l, w.u12);
+        hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(256), 0, st, Y, ld, jb, jb, c0, l, w.u12);
         if (mr > 0) launch_rankk<32>(st, gr, Y, ld, m, c0, jb, c0, t, w.u12);
       }
     }
@@ -1002,8 +1040,8 @@ void lus_pending(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t ro
 void lus_u12_block(hipStream_t st, const double* Y, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t c1,
                    double* U12) {
   const unsigned gu = (unsigned)((c1 - c0 + 63) / 64);
-  if (b == 64) hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(256), 0, st, Y, ld, jb - row0, c0, c1, U12);
-  else hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(256), 0, st, Y, ld, jb - row0, c0, c1, U12);
+  if (b == 64) hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(256), 0, st, Y, ld, jb, jb - row0, c0, c1, U12);
+  else hipLaunchKernelGGL(lu_u12_kernel<32>, dim3(gu), dim3(256), 0, st, Y, ld, jb, jb - row0, c0, c1, U12);
 }
 void lus_rankk(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t jb, int b, int64_t c0, int64_t t,
                const double* U12) {

@@ -264,6 +264,46 @@ void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t
   be->lus_finish(Yloc, mloc, ld, row0, l);
 }
 
+// The same factorization with G VIRTUAL ranks on one device: shard g = rows [row0_g, row0_g + mloc_g) of the panel in a
+// buffer of its own, every lus_* primitive called with that shard's real row0 / mloc, the all-gather and the all-reduces
+// with zeros replaced by the device copies they amount to.  This is how the row0 != 0 branches of the HIP primitives are
+// exercised on a single GPU (gsi_lu_L_sharded_virtual; the multi-rank run itself needs G devices).
+void lu_panel_sharded_virtual(Context& c, double* const* Yloc, int64_t m, int64_t l, int G) {
+  Backend* be = c.be.get();
+  if (G < 1) throw Error(GSI_ERR_ARG, "lu_panel_sharded_virtual: need at least one shard");
+  if (G > 1 && l > (m + G - 1) / G)
+    throw Error(GSI_ERR_ARG, "lu_panel_sharded: the first rank must hold the first l rows");
+  ScopedPhase ph(be, PH_LU);
+  const int64_t reclen = 4 + 2 * l;
+  const int nb = be->lus_block();
+  std::vector<int64_t> r0((size_t)G), ml((size_t)G);
+  for (int g = 0; g < G; ++g) default_shard(m, G, g, &r0[(size_t)g], &ml[(size_t)g]);
+  auto ldg = [&](int g) { return std::max<int64_t>(ml[(size_t)g], 1); };
+  Buf recs(be, (size_t)reclen * G), u12leaf(be, (size_t)nb * 8), u12blk(be, (size_t)nb * l);
+  for (int64_t jb = 0; jb < l; jb += nb) {
+    const int b = (int)std::min<int64_t>(nb, l - jb);
+    for (int64_t j0 = jb; j0 < jb + b; j0 += 8) {
+      const int w = (int)std::min<int64_t>(8, jb + b - j0);
+      if (j0 > jb) {
+        be->lus_u12_leaf(Yloc[0], ldg(0), r0[0], jb, j0, w, u12leaf.p);           // rank 0 holds rows jb .. j0
+        for (int g = 0; g < G; ++g) be->lus_pending(Yloc[g], ml[(size_t)g], ldg(g), r0[(size_t)g], jb, j0, w, u12leaf.p);
+      }
+      for (int s = 0; s < w; ++s) {
+        for (int g = 0; g < G; ++g)                                               // = the all-gather of the records
+          be->lus_candidate(Yloc[g], ml[(size_t)g], ldg(g), r0[(size_t)g], l, j0 + s, recs.p + (size_t)g * reclen);
+        for (int g = 0; g < G; ++g)
+          be->lus_apply(Yloc[g], ml[(size_t)g], ldg(g), r0[(size_t)g], m, l, j0, s, w, recs.p, G);
+      }
+    }
+    const int64_t c0 = jb + b, t = l - c0;
+    if (t > 0) {
+      be->lus_u12_block(Yloc[0], ldg(0), r0[0], jb, b, c0, l, u12blk.p);
+      for (int g = 0; g < G; ++g) be->lus_rankk(Yloc[g], ml[(size_t)g], ldg(g), r0[(size_t)g], jb, b, c0, t, u12blk.p);
+    }
+  }
+  for (int g = 0; g < G; ++g) be->lus_finish(Yloc[g], ml[(size_t)g], ldg(g), r0[(size_t)g], l);
+}
+
 // When is the sharded form used?  It trades the all-gather of the m x l panel plus a replicated factorization for ~l
 // latency-bound collectives (DESIGN.md section 6 has the numbers).  A LowRankCovMatrix never needs the panel whole
 // (its products take and give row shards), so with the sharded LU its range finder moves nothing of size n x l at

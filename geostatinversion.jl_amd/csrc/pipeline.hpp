@@ -66,6 +66,9 @@ void gather_rows(Context& c, const Operator& A, const double* Yloc, int64_t ldy,
 // place; bit-identical to the single-rank factorization.  One small all-gather per pivot step, one all-reduce per
 // leaf / block for the U12 rows of rank 0; nothing of size m x l is communicated.  Needs l <= rows of rank 0.
 void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l);
+// the same with G virtual ranks on ONE device (Yloc[g]: shard g, ld = max(mloc_g, 1), block layout of default_shard(m)):
+// every primitive runs with real row offsets, the exchanges are device copies -- the one-GPU check of the multi-rank kernels
+void lu_panel_sharded_virtual(Context& c, double* const* Yloc, int64_t m, int64_t l, int G);
 bool use_sharded_lu(Context& c, const Operator& A, int64_t rows, int64_t l);
 // rangefinder(A, l, numiterations)  RandMatFact.jl:50-80.  Omega replicated n x l (ld n).
 // Returns this rank's rows of Q (mloc x l, ld mloc).

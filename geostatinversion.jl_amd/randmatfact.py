@@ -157,6 +157,19 @@ def lu_L_sharded(Y, *, return_pivots=False, ctx=None):
     return (out, piv) if return_pivots else out
 
 
+def lu_L_sharded_virtual(Y, nshards, *, return_pivots=False, ctx=None):
+    """`lu(Y).L` through the row-sharded kernels with `nshards` virtual ranks on one GPU (`gsi_lu_L_sharded_virtual`):
+    bit-identical to `lu_L`."""
+    ctx = ctx or default_context()
+    Yf = L.fmat(Y, "Y")
+    m, l = Yf.shape
+    out = np.empty((m, l), order="F")
+    piv = np.empty(l, dtype=np.int32)
+    L.check(ctx.lib.gsi_lu_L_sharded_virtual(ctx.h, L.dptr(Yf), m, l, int(nshards), L.dptr(out),
+                                             piv.ctypes.data_as(C.POINTER(C.c_int32))), ctx.lib)
+    return (out, piv) if return_pivots else out
+
+
 def qr_thinQ(Y, *, return_R=False, ctx=None):
     """`Matrix(qr(Y, Val(true)).Q)` up to an orthogonal change of basis  (RandMatFact.jl:57-58)."""
     ctx = ctx or default_context()

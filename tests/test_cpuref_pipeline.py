@@ -345,3 +345,18 @@ def test_lu_sharded_single_rank_equals_lu(gsi, cx, m, l):
     assert np.array_equal(ps, p1)
     assert np.array_equal(ps, orc.lu_pivots(Y))
     assert np.array_equal(Ls, L1)
+
+
+@pytest.mark.parametrize("m,l,G", [(100, 25, 2), (625, 50, 3), (3000, 136, 4), (9, 2, 4), (1000, 100, 7)])
+def test_lu_sharded_virtual_ranks(gsi, cx, m, l, G):
+    """gsi_lu_L_sharded_virtual (pipeline.cpp:lu_panel_sharded_virtual) on the CPU reference backend: G virtual ranks with
+    real row offsets give dgetrf's pivots and the single-rank L exactly."""
+    rng = np.random.default_rng(m + l + G)
+    Y = rng.standard_normal((m, l))
+    pad = -(-m // G)
+    if m == 3000:
+        Y[pad + 10:pad + 110] = Y[100:200]
+    Lv, pv = gsi.lu_L_sharded_virtual(Y, G, return_pivots=True, ctx=cx)
+    L1, p1 = gsi.lu_L(Y, return_pivots=True, ctx=cx)
+    assert np.array_equal(pv, orc.lu_pivots(Y)) and np.array_equal(pv, p1)
+    assert np.array_equal(Lv, L1)

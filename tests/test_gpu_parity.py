@@ -983,3 +983,88 @@ def test_lu_headline_height_matches_lapack(gsi, ctx, m, l, ties):
     assert np.array_equal(piv, orc.lu_pivots(Y))
     Lref = orc.lu_L(Y)
     assert np.abs(L - Lref).max() < 1e-11 * max(1.0, np.abs(Lref).max())
+
+
+# ---- the row-sharded LU with REAL row offsets on one GPU: G virtual ranks, every lus_* kernel launched with
+#      its shard's row0 / mloc, the exchanges as device copies; bit-identical to the single-rank factorization.  Cases: a
+#      pivot search that crosses shards, ties across the shard boundary (the lowest global row must win), a ragged last
+#      shard, an empty last shard, several 64-column blocks (rank-64 updates with row0 != 0) -----------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,l,G", [(100, 25, 2), (625, 50, 3), (5000, 160, 3), (3000, 33, 4), (70001, 72, 8),
+                                   (300000, 136, 2), (9, 2, 4), (1000, 100, 7)])
+def test_lu_sharded_virtual_ranks_bit_identical(gsi, ctx, m, l, G):
+    rng = np.random.default_rng(m + l + G)
+    Y = rng.standard_normal((m, l))
+    pad = -(-m // G)
+    if m == 3000:                       # exact ties between rows of different shards
+        Y[pad + 10:pad + 110] = Y[100:200]
+        Y[2 * pad + 5:2 * pad + 55] = -Y[100:150]
+    Lv, pv = gsi.lu_L_sharded_virtual(Y, G, return_pivots=True, ctx=ctx)
+    L1, p1 = gsi.lu_L(Y, return_pivots=True, ctx=ctx)
+    assert np.array_equal(pv, p1)
+    assert np.array_equal(Lv, L1)
+    if m <= 5000:
+        assert np.array_equal(pv, orc.lu_pivots(Y))
+
+
+# ---- the persistent leaf kernel's time-out path (info = -1): one workgroup stays silent at a pivot step (test knob), every
+#      other workgroup runs out of polls, the launch drains, the call fails with GSI_ERR_INTERNAL (GSI_NO_RETRY) -- and
+#      without that switch the entry point re-runs on the per-column sweeps and returns LAPACK's factorization.  Then: two
+#      contexts on ONE GPU factoring concurrently (plain launches may interleave their workgroups; whatever happens both
+#      results must be dgetrf's). ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_lu_lost_coresidency_paths(gsi):
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, threading, numpy as np
+sys.path.insert(0, os.getcwd())
+import gsi_amd as gsi
+from oracle import oracle as orc
+rng = np.random.default_rng(11)
+Y = rng.standard_normal((40000, 40))
+pref, Lref = orc.lu_pivots(Y), orc.lu_L(Y)
+os.environ["GSI_LU_POLL_LIMIT"] = "20000"
+os.environ["GSI_LU_TEST_MUTE_EPOCH"] = "13"
+os.environ["GSI_NO_RETRY"] = "1"
+ctx = gsi.Context(0)
+try:
+    gsi.lu_L(Y, ctx=ctx)
+    raise SystemExit("the muted exchange did not time out")
+except gsi.GsiError as e:
+    assert e.code == 8 and "timed out" in str(e), str(e)
+L2, p2 = gsi.lu_L(Y, return_pivots=True, ctx=ctx)          # the context has switched to the sweeps
+assert np.array_equal(p2, pref) and np.abs(L2 - Lref).max() < 1e-11
+del os.environ["GSI_NO_RETRY"]
+ctx3 = gsi.Context(0)                                       # fresh context: time-out, then the automatic re-run
+L3, p3 = gsi.lu_L(Y, return_pivots=True, ctx=ctx3)
+assert np.array_equal(p3, pref) and np.abs(L3 - Lref).max() < 1e-11
+A = rng.standard_normal((3000, 40)) @ rng.standard_normal((40, 3000))
+Om = rng.standard_normal((3000, 24))
+ctx4 = gsi.Context(0)
+Z4, S4 = gsi.randsvd(A, 16, 8, 2, Omega=Om, return_S=True, ctx=ctx4)   # time-out inside randsvd -> re-run on its inputs
+del os.environ["GSI_LU_TEST_MUTE_EPOCH"]
+ctx5 = gsi.Context(0)
+Z5, S5 = gsi.randsvd(A, 16, 8, 2, Omega=Om, return_S=True, ctx=ctx5)
+assert np.abs(S4 - S5).max() < 1e-11 * S5[0]
+print("abort-path-ok")
+# two contexts, one GPU, concurrent factorizations
+os.environ["GSI_LU_POLL_LIMIT"] = "400000"
+Yb = rng.standard_normal((1000000, 16))      # <512, 8> leaves: one workgroup per CU, 245 of 256 CUs each -- two do not fit
+pb = orc.lu_pivots(Yb)
+out = {}
+def work(tag):
+    c = gsi.Context(0)
+    for _ in range(3):
+        out[tag] = gsi.lu_L(Yb, return_pivots=True, ctx=c)[1]
+ts = [threading.Thread(target=work, args=(t,)) for t in ("a", "b")]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert np.array_equal(out["a"], pb) and np.array_equal(out["b"], pb)
+print("two-contexts-ok")
+'''
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "abort-path-ok" in r.stdout and "two-contexts-ok" in r.stdout, \
+        r.stdout[-2000:] + r.stderr[-4000:]
