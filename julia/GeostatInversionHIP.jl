@@ -377,6 +377,35 @@ function eig_nystrom(A::Matrix{Float64}, Q::Matrix{Float64})
 end
 end # module RandMatFact
 
+# ---- panel primitives: what the reference takes from LinearAlgebra (RandMatFact.jl:57-61, 86) ----------------------
+"`LinearAlgebra.lu(Y).L` in pivoted row order (`gsi_lu_L`): returns (L, p) with p the 1-based LAPACK pivot rows."
+function lu_L(Y::Matrix{Float64}; c::Context=ctx())
+	m, l = size(Y)
+	Lout = Matrix{Float64}(undef, m, l)
+	piv = Vector{Int32}(undef, l)
+	check(ccall((:gsi_lu_L, libgsi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Int32}),
+		c.h, Y, m, l, Lout, piv))
+	return Lout, piv .+ Int32(1)
+end
+"`Matrix(qr(Y, Val(true)).Q)` up to an orthogonal change of basis (`gsi_qr_thinQ`): returns (Q, R) with Y = Q R."
+function qr_thinQ(Y::Matrix{Float64}; c::Context=ctx())
+	m, l = size(Y)
+	Q = Matrix{Float64}(undef, m, l)
+	R = Matrix{Float64}(undef, l, l)
+	check(ccall((:gsi_qr_thinQ, libgsi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}),
+		c.h, Y, m, l, Q, R))
+	return Q, R
+end
+"(S, V) of `svd(W')` for a tall W (`gsi_svd_tall`): what RandMatFact.jl:86 takes from `svd(B)`."
+function svd_tall(W::Matrix{Float64}; c::Context=ctx())
+	n, l = size(W)
+	V = Matrix{Float64}(undef, n, l)
+	S = Vector{Float64}(undef, l)
+	check(ccall((:gsi_svd_tall, libgsi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}),
+		c.h, W, n, l, V, S))
+	return S, V
+end
+
 # ---- getxis (GeostatInversion.jl:20-70) ---------------------------------------------------------------
 randsvdwithseed(Q, numxis, p, q, seed::Nothing) = RandMatFact.randsvd(Q, numxis, p, q)
 function randsvdwithseed(Q, numxis, p, q, seed::Int)
