@@ -462,6 +462,53 @@ void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3
   hipLaunchKernelGGL(fft_normalise_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, part64, 64);
 }
 
+// ---- FFTRF's convention on a grid whose 2 N embedding is not a power of two ------------------------------------------
+// A = R C R' touches the circulant kernel c = F^-1_{2N} lambda only at the lags |t_a| <= N_a - 1 (i, j both in the box), so
+// ANY periodic embedding of M'_a >= 2 N_a - 1 points that carries those lags gives the same matrix.  The products keep their
+// power-of-two Stockham passes (M' = next power of two >= 2 N); what changes is the spectrum they multiply by:
+//     lambda' = F_{M'} c',   c'_t = c_{|t|} for |t_a| <= N_a - 1, 0 elsewhere,   c = F^-1_{2N} lambda (FFTRF.jl:83-90's lambda).
+// lambda is real and even along every axis, so both transforms are cosine sums, and both are tensor products of small
+// per-axis matrices: computed once per plan with the MFMA contraction kernel (hip_backend.hip:fftcov_create).
+//   out[r + c rows] = (weighted && r > 0 ? 2 : 1) cos(2 pi r c / period)
+__global__ __launch_bounds__(256) void fft_cos_matrix_kernel(double* __restrict__ out, int64_t rows, int64_t cols, int64_t period,
+                                                             int weighted) {
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e % rows, c = e / rows;
+    const int64_t a = (r * c) % period;                    // exact argument reduction
+    const double v = cospi(2.0 * (double)a / (double)period);
+    out[e] = (weighted && r > 0) ? 2.0 * v : v;
+  }
+}
+void fft_cos_matrix(hipStream_t st, double* out, int64_t rows, int64_t cols, int64_t period, bool weighted) {
+  hipLaunchKernelGGL(fft_cos_matrix_kernel, dim3(grid_for(rows * cols, 4096)), dim3(256), 0, st, out, rows, cols, period,
+                     weighted ? 1 : 0);
+}
+// natural order (axis 0 fastest) -> the line-by-line layout of the fused last-axis pass: out[inner * mlast + k_last]
+__global__ __launch_bounds__(256) void fft_lines_layout_kernel(const double* __restrict__ nat, double* __restrict__ out, int64_t Mtot,
+                                                               int64_t lines, int64_t mlast) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < Mtot; e += (int64_t)gridDim.x * 256)
+    out[(e % lines) * mlast + e / lines] = nat[e];
+}
+void fft_lines_layout(hipStream_t st, const double* nat, double* out, const int64_t M[3]) {
+  const int64_t Mtot = M[0] * M[1] * M[2];
+  const int64_t mlast = (M[2] > 1) ? M[2] : ((M[1] > 1) ? M[1] : Mtot);
+  hipLaunchKernelGGL(fft_lines_layout_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, nat, out, Mtot, Mtot / mlast, mlast);
+}
+// |k|^beta on the grid M (integer wavenumbers when fftrf), NATURAL order, not normalised
+void fft_spectrum_natural(hipStream_t st, double* lam, const int64_t M[3], double beta, int fftrf) {
+  const int64_t Mtot = M[0] * M[1] * M[2];
+  hipLaunchKernelGGL(fft_spectrum_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, M[0], M[1], M[2], beta, fftrf,
+                     (int64_t)1, Mtot);
+}
+// lam[0, Mtot) *= 1 / sum (unit diagonal); twiddle table behind the 64 scratch doubles, as fft_spectrum leaves them
+void fft_finish_plan(hipStream_t st, double* lam, double* part64, const int64_t M[3]) {
+  const int64_t Mtot = M[0] * M[1] * M[2];
+  hipLaunchKernelGGL(fft_twiddle_kernel, dim3(FFT_TW_LEN / 2 / 256), dim3(256), 0, st, reinterpret_cast<double2*>(lam + Mtot + 64));
+  hipLaunchKernelGGL(fft_sum_kernel, dim3(64), dim3(256), 0, st, lam, Mtot, part64);
+  hipLaunchKernelGGL(fft_normalise_kernel, dim3(grid_for(Mtot, 4096)), dim3(256), 0, st, lam, Mtot, part64, 64);
+}
+
 template <int MODE, int LR, bool SHORT>
 static void launch_pass_k(hipStream_t st, int ncus, int threads, size_t shmem, double2* W, int64_t Mtot, const FftPass& ps,
                         const double* lam, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t N0, int64_t col0,

@@ -226,13 +226,12 @@ class HipBackend : public Backend {
     int64_t Mtot = 1;
     int d = 0;
     for (int a = 0; a < 3; ++a) { p->N[a] = 1; p->M[a] = 1; }
+    bool reembed = false;                // FFTRF's exact 2 N embedding is not a power of two on some axis
     for (int a = 0; a < 3; ++a) {        // squeeze singleton axes: vec() of a 1 x 50 field is a 50-point line
       if (N[a] < 1) throw Error(GSI_ERR_ARG, "fft covariance: grid dimensions must be >= 1");
       if (N[a] == 1) continue;
       p->N[d] = N[a]; p->M[d] = hipk::fft_embed_size(N[a]);
-      if (fftrf && p->M[d] != 2 * N[a])
-        throw Error(GSI_ERR_ARG, "FFTRF-convention covariance: the embedding is exactly 2 N per axis and the line "
-                                 "transforms are power-of-two Stockham -- every grid dimension must be a power of two");
+      if (fftrf && p->M[d] != 2 * N[a]) reembed = true;
       if (p->M[d] > 8192) throw Error(GSI_ERR_ARG, "fft covariance: at most 4096 grid points per axis (a line must fit LDS)");
       Mtot *= p->M[d];
       ++d;
@@ -242,8 +241,55 @@ class HipBackend : public Backend {
     p->nb_max = (int)std::max<int64_t>(1, std::min<int64_t>(nb, 64));
     p->lam = alloc(hipk::fft_plan_doubles(p->M));
     try { p->W = alloc((size_t)2 * Mtot * p->nb_max); } catch (...) { release(p->lam); throw; }
-    hipk::fft_spectrum(st_, p->lam, p->lam + Mtot, p->M, beta, fftrf);
-    check_launch("fft_spectrum");
+    if (!reembed) {
+      hipk::fft_spectrum(st_, p->lam, p->lam + Mtot, p->M, beta, fftrf);
+      check_launch("fft_spectrum");
+      return p.release();
+    }
+    // FFTRF's convention on an arbitrary grid (FFTRF.jl:83-90 embeds on exactly 2 N points for ANY N): the same matrix
+    // through the power-of-two passes with a re-embedded spectrum (fft_cov.hip, "FFTRF's convention on a grid ...").
+    //   c  = (x_a C_a) lambda_{2N}    C_a[t, k]  = cos(2 pi t k / 2 N_a),            t < N_a, k < 2 N_a     (lags 0 .. N_a - 1)
+    //   l' = (x_a D_a) c              D_a[k', t] = w_t cos(2 pi t k' / M'_a), w_0 = 1, w_t = 2              (c' even, 0 beyond)
+    // Each factor is applied to the FASTEST axis as cur' = cur^T B (the contraction kernel's A'B form: the array as a
+    // k x rest matrix), which also rotates that axis to the back: d applications restore the natural order.
+    try {
+      int64_t cur[3] = {1, 1, 1};
+      for (int a = 0; a < d; ++a) cur[a] = 2 * p->N[a];
+      int64_t tot = cur[0] * cur[1] * cur[2];
+      double* buf = alloc((size_t)tot);
+      hipk::fft_spectrum_natural(st_, buf, cur, beta, 1);
+      auto rotate_apply = [&](int64_t rows_out, int64_t period, bool weighted) {
+        // cur = (k, rest) column-major; B = k x rows_out; result (rest x rows_out) = the array with axis 0 replaced and last
+        const int64_t k = cur[0], rest = (tot / k);
+        double* B = alloc((size_t)k * rows_out);
+        // B[kk + t k] : weighted (the D factors) is indexed [t = row of the INPUT, k' = output]; unweighted [k, t]
+        if (!weighted) hipk::fft_cos_matrix(st_, B, k, rows_out, period, false);          // C_a^T: B[k, t]
+        else hipk::fft_cos_matrix(st_, B, k, rows_out, period, true);                     // D_a^T: B[t, k'] = w_t cos(.)
+        double* out = nullptr;
+        try { out = alloc((size_t)rest * rows_out); } catch (...) { release(B); throw; }
+        double* ws = gemm_ws(hipk::gemm_workspace_doubles(rest, rows_out, k));
+        hipk::gemm_f64(st_, true, rest, rows_out, k, 1.0, buf, k, B, k, 0.0, out, rest, ws);
+        check_launch("fft re-embedding product");
+        release(B);
+        release(buf);
+        buf = out;
+        tot = rest * rows_out;
+        // rotate the dimension list: (k, c1, c2) -> (c1, c2, rows_out) over the d real axes
+        int64_t nd[3] = {1, 1, 1};
+        for (int a = 0; a + 1 < d; ++a) nd[a] = cur[a + 1];
+        nd[d - 1] = rows_out;
+        for (int a = 0; a < 3; ++a) cur[a] = nd[a];
+      };
+      for (int a = 0; a < d; ++a) rotate_apply(p->N[a], 2 * p->N[a], false);   // lags 0 .. N_a - 1 of c
+      for (int a = 0; a < d; ++a) rotate_apply(p->M[a], p->M[a], true);        // the spectrum of the re-embedded kernel
+      hipk::fft_lines_layout(st_, buf, p->lam, p->M);
+      hipk::fft_finish_plan(st_, p->lam, p->lam + Mtot, p->M);
+      check_launch("fft re-embedded spectrum");
+      release(buf);
+    } catch (...) {
+      release(p->W); release(p->lam);
+      throw;
+    }
     return p.release();
   }
   void fftcov_destroy(void* plan) override {

@@ -42,6 +42,11 @@ int64_t fft_embed_size(int64_t N);   // next power of two >= 2 N (1 for a single
 size_t fft_plan_doubles(const int64_t M[3]);   // spectrum + scratch + twiddle table
 // lam (fft_plan_doubles) <- |k|^beta / sum, scratch part64 = lam + Mtot, twiddles behind it
 void fft_spectrum(hipStream_t st, double* lam, double* part64, const int64_t M[3], double beta, int fftrf);
+// FFTRF's 2 N embedding on grids that are not powers of two (fft_cov.hip): pieces of the re-embedded spectrum
+void fft_cos_matrix(hipStream_t st, double* out, int64_t rows, int64_t cols, int64_t period, bool weighted);
+void fft_lines_layout(hipStream_t st, const double* nat, double* out, const int64_t M[3]);
+void fft_spectrum_natural(hipStream_t st, double* lam, const int64_t M[3], double beta, int fftrf);
+void fft_finish_plan(hipStream_t st, double* lam, double* part64, const int64_t M[3]);
 void fft_cov_apply(hipStream_t st, const int64_t N[3], const int64_t M[3], const double* lam, double2* W, int nb_max,
                    int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy);
 

@@ -778,7 +778,11 @@ def test_pcgalsqr_c5_fp32_vs_fp64(gsi, ctx):
 #      tests/test_fftrf_covariance.py for the statistical tie to the restated FFTRF.jl) -------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("Ns,beta,l", [((64,), -2.0, 5), ((32, 8), -3.5, 9), ((16, 64), -2.5, 33), ((8, 4, 16), -3.0, 6),
-                                       ((256, 128), -3.5, 16)])
+                                       ((256, 128), -3.5, 16),
+                                       # grids whose 2N embedding is NOT a power of two (FFTRF.jl:83-90 takes any N): the
+                                       # reference's own 25 x 25 (test/testrpcga.jl:84-88), ragged 2-D, 3-D, 1-D, a prime
+                                       ((25, 25), -3.5, 50), ((50, 40), -3.5, 12), ((9, 6, 11), -3.0, 7), ((100,), -2.0, 3),
+                                       ((7,), -2.5, 4), ((24, 16), -3.5, 5), ((300, 200), -3.5, 6)])
 def test_fft_powerlaw_fftrf_convention(gsi, ctx, Ns, beta, l):
     n = int(np.prod(Ns))
     rng = np.random.default_rng(n + l)
@@ -791,8 +795,44 @@ def test_fft_powerlaw_fftrf_convention(gsi, ctx, Ns, beta, l):
     if len(set(Ns)) > 1:
         assert np.abs(Yiso - Yref).max() > 1e-3 * np.abs(Yref).max()       # a different operator on unequal axes
     op.close()
-    with pytest.raises(gsi.GsiError):
-        gsi.fft_powerlaw_operator(ctx, [24, 16], beta, fftrf=True)           # 2N embedding needs power-of-two axes here
+
+
+@pytest.mark.gpu
+def test_fftrf_covariance_on_the_reference_grid(gsi, ctx):
+    """`FFTRFCovariance([25, 25], -3.5)`: the grid and beta of the reference's own getxis test (test/testrpcga.jl:84-88).
+    (i) the HIP operator is the oracle's matrix, symmetric with a unit diagonal; (ii) randsvd through it (K = 30, p = 20,
+    q = 3 as at :85-86,91) equals the oracle's on the materialised matrix with the same Omega; (iii) the sample covariance
+    of restated FFTRF.jl fields on a non-power-of-two grid converges to the HIP operator (the statistical tie of
+    tests/test_fftrf_covariance.py, now through the GPU on a grid the power-of-two transforms do not embed exactly)."""
+    Ns, beta = [25, 25], -3.5
+    n = 625
+    op = gsi.fft_powerlaw_operator(ctx, Ns, beta, fftrf=True)
+    A = op.matmul(np.eye(n))
+    Aref = orc.fft_powerlaw_apply(np.eye(n), Ns, beta, fftrf=True)
+    assert np.abs(A - Aref).max() < 1e-12
+    assert np.abs(A - A.T).max() < 1e-12 and np.abs(np.diag(A) - 1.0).max() < 1e-12
+    rng = np.random.default_rng(0)
+    K, p, q = 30, 20, 3
+    Om = rng.standard_normal((n, K + p))
+    Z, S = gsi.randsvd(op, K, p, q, Omega=Om, return_S=True)
+    Zref, Sref, _ = orc.randsvd_full(Aref, K, p, q, Om)
+    assert rel_sv_err(S, Sref, K) < 1e-9
+    assert orc.xis_error_up_to_sign(Z, Zref, K) < 1e-6
+    op.close()
+    Ns2 = [6, 5]
+    n2 = 30
+    op2 = gsi.fft_powerlaw_operator(ctx, Ns2, -2.5, fftrf=True)
+    A2 = op2.matmul(np.eye(n2))
+    op2.close()
+    rng = np.random.default_rng(1234)
+    C = np.zeros((n2, n2))
+    nsamples = 6000
+    for _ in range(nsamples):
+        f = orc.fftrf_powerlaw_structuredgrid(Ns2, 0.0, 1.0, -2.5, rng, raw=True).reshape(-1, order="F")
+        C += np.outer(f, f)
+    C /= nsamples
+    scale = np.trace(C) / n2
+    assert np.linalg.norm(C / scale - A2) / np.linalg.norm(A2) < 0.09
 
 
 # ---- implicit operator, exponential kernel (SURVEY 8d C4-i) and a caller-supplied stationary kernel table, against the
