@@ -137,6 +137,15 @@ class Backend {
   virtual void scal(int64_t n, double a, double* x) = 0;                          // x *= a
   virtual void diag_mul_add(int64_t n, const double* d, const double* x, double* y) = 0;   // y += d .* x
 
+  // ---- IterativeSolvers.lsqr with the scalar recurrences resident in backend memory (lsqr_state.hpp): `work` holds
+  //      lsqr_work_doubles() doubles = [state | partial sums]; pipeline.cpp:lsqr sequences the two operator products
+  //      around these and polls the state every few iterations ----
+  virtual size_t lsqr_work_doubles() = 0;
+  virtual void lsqr_begin(int64_t n, const double* w, double* work) = 0;                       // |w|^2 of the initial w
+  virtual void lsqr_step_u(int64_t m, const double* t, double* u, double* work) = 0;           // u = t - alpha u; beta; u /= beta
+  virtual void lsqr_step_v(int64_t n, const double* t, double* v, double* w, double* x, double* work) = 0;
+  //                                     v = t - beta v; alpha; the recurrences and stopping rules; v /= alpha; x += t1 w; w = v + t2 w
+
   // ---- fp32-STORED xi-basis (BASELINE configs[4], "fp32 mixed precision"): the n x K basis is the one big HBM stream
   //      of the PCGA iteration's own algebra; stored in fp32 it is half the bytes, every sum stays in fp64 ----
   virtual void f64_to_f32(const double* src, void* dst32, size_t count) = 0;

@@ -654,6 +654,22 @@ class HipBackend : public Backend {
     bind();
     hipk::diag_mul_add(st_, n, d, x, y);
   }
+  size_t lsqr_work_doubles() override { return hipk::lsqr_work_doubles(); }
+  void lsqr_begin(int64_t n, const double* w, double* work) override {
+    bind();
+    hipk::lsqr_begin(st_, n, w, work);
+    check_launch("lsqr_begin");
+  }
+  void lsqr_step_u(int64_t m, const double* t, double* u, double* work) override {
+    bind();
+    hipk::lsqr_step_u(st_, m, t, u, work);
+    check_launch("lsqr_step_u");
+  }
+  void lsqr_step_v(int64_t n, const double* t, double* v, double* w, double* x, double* work) override {
+    bind();
+    hipk::lsqr_step_v(st_, n, t, v, w, x, work);
+    check_launch("lsqr_step_v");
+  }
   void f64_to_f32(const double* src, void* dst32, size_t count) override {
     bind();
     hipk::f64_to_f32(st_, src, (float*)dst32, count);

@@ -102,6 +102,12 @@ void lus_rankk(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0
                const double* U12);
 void lus_finish(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l);
 
+// ---- lsqr_dev.hip: IterativeSolvers.lsqr's vector updates with device-resident scalars ----
+size_t lsqr_work_doubles();
+void lsqr_begin(hipStream_t st, int64_t n, const double* w, double* work);
+void lsqr_step_u(hipStream_t st, int64_t m, const double* t, double* u, double* work);
+void lsqr_step_v(hipStream_t st, int64_t n, const double* t, double* v, double* w, double* x, double* work);
+
 // ---- panel_qr.hip ----
 constexpr int QR_NB = 16;
 struct QrWork {

@@ -11,6 +11,7 @@
 //   final Q      TSQR: local Householder QR, AllGather of the l x l R factors, replicated
 //                QR of the stack, local fix-up Q_g <- Q_g * Q2_g
 #include "pipeline.hpp"
+#include "lsqr_state.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -516,79 +517,50 @@ void eig_nystrom(const Operator& A, const double* Q, int64_t j, double* U, doubl
 
 // ---- IterativeSolvers.lsqr (third-party, Project.toml:21; not under the reference tree): Paige & Saunders' LSQR
 //      with that package's defaults, restated from the published algorithm exactly as oracle/oracle.py:lsqr does
-//      (same order of operations, same stopping rules); vectors live in backend memory, the scalar recurrences on
-//      the host (two norms per iteration cross the bus).
+//      (same order of operations, same stopping rules).  Vectors AND the scalar recurrences live in backend memory
+//      (lsqr_state.hpp): an iteration is the two operator products plus two fused launch groups, nothing waits for the
+//      host; the host polls {stopped, iterations} every LSQR_POLL iterations (iterations enqueued past the stopping point
+//      are no-ops on the device, so x and the iteration count are exactly those of the one-scalar-at-a-time loop).
 int64_t lsqr(Context& c, const LsqrOperator& A, const double* b, double* x, int64_t maxiter) {
+  using namespace lsqrst;
   Backend* be = c.be.get();
   const int64_t m = A.nrows, n = A.ncols;
   const double tol = std::sqrt(2.220446049250313e-16);
-  const double atol = tol, btol = tol, conlim = 1e8;
-  const double ctol = 1.0 / conlim;
+  const double conlim = 1e8;
   if (maxiter < 0) maxiter = std::max(m, n);
   Buf u(be, (size_t)m), v(be, (size_t)n), w(be, (size_t)n), t(be, (size_t)std::max(m, n));
   be->fill_zero(x, (size_t)n);
   be->copy2d(u.p, m, b, m, m, 1);
-  double beta = be->nrm2(m, u.p);
+  const double beta = be->nrm2(m, u.p);                // the two start-up norms are read by the host: once per solve
   if (beta == 0.0) return 0;
   be->scal(m, 1.0 / beta, u.p);
   A.mul_t(u.p, v.p);
-  double alpha = be->nrm2(n, v.p);
+  const double alpha = be->nrm2(n, v.p);
   if (alpha == 0.0) return 0;
   be->scal(n, 1.0 / alpha, v.p);
   be->copy2d(w.p, n, v.p, n, n, 1);
-  double rhobar = alpha, phibar = beta;
-  const double bnorm = beta;
-  double Anorm = 0.0, ddnorm = 0.0, xxnorm = 0.0, res2 = 0.0, z = 0.0, cs2 = -1.0, sn2 = 0.0;
-  int64_t it = 0;
-  while (it < maxiter) {
-    ++it;
-    A.mul(v.p, t.p);                                   // u = A v - alpha u
-    be->scal(m, -alpha, u.p);
-    be->axpy(m, 1.0, t.p, u.p);
-    beta = be->nrm2(m, u.p);
-    if (beta > 0.0) {
-      be->scal(m, 1.0 / beta, u.p);
-      Anorm = std::sqrt(Anorm * Anorm + alpha * alpha + beta * beta);
-      A.mul_t(u.p, t.p);                               // v = A' u - beta v
-      be->scal(n, -beta, v.p);
-      be->axpy(n, 1.0, t.p, v.p);
-      alpha = be->nrm2(n, v.p);
-      if (alpha > 0.0) be->scal(n, 1.0 / alpha, v.p);
+  double st[COUNT] = {0.0};
+  st[ALPHA] = alpha; st[BETA] = beta; st[RHOBAR] = alpha; st[PHIBAR] = beta; st[BNORM] = beta;
+  st[CS2] = -1.0; st[SN2] = 0.0; st[MAXITER] = (double)maxiter;
+  st[ATOL] = tol; st[BTOL] = tol; st[CTOL] = 1.0 / conlim;
+  Buf work(be, be->lsqr_work_doubles());
+  be->upload2d(work.p, COUNT, st, COUNT, COUNT, 1);
+  be->lsqr_begin(n, w.p, work.p);
+  static const int64_t poll = getenv("GSI_LSQR_POLL") ? std::max(1, atoi(getenv("GSI_LSQR_POLL"))) : 8;
+  int64_t enq = 0;
+  while (enq < maxiter) {
+    const int64_t burst = std::min<int64_t>(poll, maxiter - enq);
+    for (int64_t k = 0; k < burst; ++k) {
+      A.mul(v.p, t.p);                                 // u = A v - alpha u; beta = |u|; u /= beta
+      be->lsqr_step_u(m, t.p, u.p, work.p);
+      A.mul_t(u.p, t.p);                               // v = A' u - beta v; alpha = |v|; v /= alpha; x, w updates
+      be->lsqr_step_v(n, t.p, v.p, w.p, x, work.p);
     }
-    const double rhobar1 = rhobar;                     // damp = 0
-    const double rho = std::sqrt(rhobar1 * rhobar1 + beta * beta);
-    const double cs = rhobar1 / rho, sn = beta / rho;
-    const double theta = sn * alpha;
-    rhobar = -cs * alpha;
-    const double phi = cs * phibar;
-    phibar = sn * phibar;
-    const double tau = sn * phi;
-    const double t1 = phi / rho, t2 = -theta / rho;
-    const double wn = be->nrm2(n, w.p);
-    ddnorm += (wn / rho) * (wn / rho);
-    be->axpy(n, t1, w.p, x);                           // x = x + t1 w
-    be->scal(n, t2, w.p);                              // w = v + t2 w
-    be->axpy(n, 1.0, v.p, w.p);
-    const double delta = sn2 * rho, gambar = -cs2 * rho, rhs = phi - delta * z;
-    const double zbar = rhs / gambar;
-    const double xnorm = std::sqrt(xxnorm + zbar * zbar);
-    const double gamma = std::sqrt(gambar * gambar + theta * theta);
-    cs2 = gambar / gamma;
-    sn2 = theta / gamma;
-    z = rhs / gamma;
-    xxnorm += z * z;
-    const double Acond = Anorm * std::sqrt(ddnorm);
-    const double rnorm = std::sqrt(phibar * phibar + res2);
-    const double Arnorm = alpha * std::fabs(tau);
-    const double test1 = rnorm / bnorm;
-    const double test2 = (Anorm * rnorm > 0.0) ? Arnorm / (Anorm * rnorm) : 0.0;
-    const double test3 = (Acond > 0.0) ? 1.0 / Acond : 0.0;
-    const double t1c = test1 / (1.0 + Anorm * xnorm / bnorm);
-    const double rtol = btol + atol * Anorm * xnorm / bnorm;
-    if (1.0 + test3 <= 1.0 || 1.0 + test2 <= 1.0 || 1.0 + t1c <= 1.0) break;
-    if (test3 <= ctol || test2 <= atol || test1 <= rtol) break;
+    enq += burst;
+    be->download2d(st, COUNT, work.p, COUNT, COUNT, 1);
+    if (st[STOPPED] != 0.0) break;
   }
-  return it;
+  return (int64_t)st[ITERS];
 }
 
 int64_t lowrank_solve(const Operator& A, const double* b, double* x) {

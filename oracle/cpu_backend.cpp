@@ -14,6 +14,7 @@
 #include <vector>
 #include "../include/gsi_hip.h"
 #include "../geostatinversion.jl_amd/csrc/backend.hpp"
+#include "../geostatinversion.jl_amd/csrc/lsqr_state.hpp"
 
 extern "C" {
 void gsio_gemm_nn(int64_t, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, double, double*, int64_t);
@@ -350,6 +351,38 @@ class CpuBackend : public Backend {
   }
   void scal(int64_t n, double a, double* x) override { for (int64_t i = 0; i < n; ++i) x[i] *= a; }
   void diag_mul_add(int64_t n, const double* d, const double* x, double* y) override { for (int64_t i = 0; i < n; ++i) y[i] += d[i] * x[i]; }
+  // lsqr with the scalars in the state block (lsqr_state.hpp): the same functions the device kernels call
+  size_t lsqr_work_doubles() override { return (size_t)lsqrst::COUNT + 3; }
+  void lsqr_begin(int64_t n, const double* w, double* work) override { work[lsqrst::COUNT + 2] = dot(n, w, w); }
+  void lsqr_step_u(int64_t m, const double* t, double* u, double* work) override {
+    using namespace lsqrst;
+    double* s = work;
+    double usq = 0.0;
+    if (s[STOPPED] == 0.0 && s[ITERS] < s[MAXITER]) {
+      for (int64_t i = 0; i < m; ++i) { u[i] = t[i] - s[ALPHA] * u[i]; usq += u[i] * u[i]; }
+    }
+    after_u(s, usq);
+    if (s[APPLY] != 0.0 && s[BETA] > 0.0) { const double inv = 1.0 / s[BETA]; for (int64_t i = 0; i < m; ++i) u[i] *= inv; }
+  }
+  void lsqr_step_v(int64_t n, const double* t, double* v, double* w, double* x, double* work) override {
+    using namespace lsqrst;
+    double* s = work;
+    double vsq = 0.0;
+    if (s[APPLY] != 0.0 && s[BETA] > 0.0)
+      for (int64_t i = 0; i < n; ++i) { v[i] = t[i] - s[BETA] * v[i]; vsq += v[i] * v[i]; }
+    after_v(s, vsq, work[COUNT + 2]);
+    if (s[APPLY] == 0.0) return;
+    const bool rescale = (s[BETA] > 0.0 && s[ALPHA] > 0.0);
+    const double inv = rescale ? 1.0 / s[ALPHA] : 1.0;
+    double wsq = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      if (rescale) v[i] *= inv;
+      x[i] += s[T1] * w[i];
+      w[i] = v[i] + s[T2] * w[i];
+      wsq += w[i] * w[i];
+    }
+    work[COUNT + 2] = wsq;
+  }
   void f64_to_f32(const double* src, void* dst32, size_t count) override {
     float* d = (float*)dst32;
     for (size_t i = 0; i < count; ++i) d[i] = (float)src[i];
