@@ -59,6 +59,7 @@ SIGNATURES = {
     "gsi_op_mul_dev": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp]),
     "gsi_rangefinder_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "gsi_randsvd_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "gsi_randsvd_rows": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsi_lu_L": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_dp, C.POINTER(C.c_int32)]),
     "gsi_lu_L_sharded": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_dp, C.POINTER(C.c_int32)]),
     "gsi_lu_L_sharded_virtual": (C.c_int, [c_vp, c_dp, c_i64, c_i64, C.c_int, c_dp, C.POINTER(C.c_int32)]),

@@ -291,7 +291,6 @@ static void make_fft_powerlaw(gsi_ctx* ctx, gsi_op** op, int ndims, const int64_
   REQUIRE(ctx && op && N, "NULL argument");
   *op = nullptr;
   REQUIRE(ndims >= 1 && ndims <= 3, "fft covariance: 1, 2 or 3 grid dimensions");
-  REQUIRE(ctx->c.nranks() == 1, "fft covariance operator: single rank only (the transform needs whole columns)");
   int64_t N3[3] = {1, 1, 1};
   int64_t n = 1;
   for (int a = 0; a < ndims; ++a) {
@@ -302,7 +301,10 @@ static void make_fft_powerlaw(gsi_ctx* ctx, gsi_op** op, int ndims, const int64_
   REQUIRE(n >= 2, "fft covariance: need at least two grid points");
   std::unique_ptr<gsi_op> o(new gsi_op());
   Operator& A = o->op;
-  A.ctx = &ctx->c; A.kind = OP_FFT_COV; A.m = n; A.n = n; A.row0 = 0; A.mloc = n; A.ld = 0;
+  A.ctx = &ctx->c; A.kind = OP_FFT_COV; A.m = n; A.n = n; A.ld = 0;
+  // several ranks: every rank holds the plan (spectrum + work array) and transforms ITS columns of a panel; panels are
+  // row-sharded between the products (pipeline.cpp: rows_to_cols / cols_to_rows), so row0 / mloc = the block-row layout
+  default_shard(n, ctx->c.nranks(), ctx->c.rank(), &A.row0, &A.mloc);
   A.plan = ctx->c.be->fftcov_create(N3, beta, fftrf);
   *op = o.release();
 }
@@ -517,6 +519,36 @@ int gsi_randsvd_dev(gsi_ctx* ctx, const gsi_op* op, const gsi_mat* Omega, int64_
     }
     with_retry(ctx->c, [&] {
       randsvd(A, Omega->buf.p, K, p, q, Z->buf.p, Sp);
+      check_async_errors(ctx->c);
+    });
+  });
+}
+
+int gsi_randsvd_rows(gsi_ctx* ctx, const gsi_op* op, const gsi_mat* Omega_rows, int64_t K, int64_t p, int64_t q,
+                     gsi_mat* Z_rows, gsi_mat* S) {
+  return guarded([&] {
+    REQUIRE(ctx && op && Omega_rows && Z_rows, "NULL argument");
+    REQUIRE(op->op.ctx == &ctx->c && Omega_rows->ctx == ctx && Z_rows->ctx == ctx, "objects belong to another context");
+    REQUIRE(K >= 0 && p >= 0 && K + p >= 1, "need K >= 0, p >= 0, K + p >= 1");
+    const Operator& A = op->op;
+    const int64_t l = K + p;
+    int64_t r0, nloc;
+    default_shard(A.n, ctx->c.nranks(), ctx->c.rank(), &r0, &nloc);
+    REQUIRE(nloc >= 1, "this rank holds no rows of the panel");
+    REQUIRE(Omega_rows->rows == nloc && Omega_rows->cols == l, "Omega_rows must be (this rank's rows of size(A,2)) x (K+p)");
+    REQUIRE(Z_rows->rows == nloc && Z_rows->cols == l, "Z_rows must be (this rank's rows of size(A,2)) x (K+p)");
+    Backend* be = ctx->c.be.get();
+    Buf Stmp;
+    double* Sp;
+    if (S) {
+      REQUIRE(S->ctx == ctx && S->rows * S->cols == l, "S must hold K+p values");
+      Sp = S->buf.p;
+    } else {
+      Stmp = Buf(be, (size_t)l);
+      Sp = Stmp.p;
+    }
+    with_retry(ctx->c, [&] {
+      randsvd_rows(A, Omega_rows->buf.p, K, p, q, Z_rows->buf.p, Sp);
       check_async_errors(ctx->c);
     });
   });

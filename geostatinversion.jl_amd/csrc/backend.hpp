@@ -184,6 +184,8 @@ class Comm {
   // send holds nranks blocks of `count` doubles (block g is destined for rank g); recv (count) = sum over ranks
   // of their block `rank`
   virtual void reduce_scatter_sum(const double* send, double* recv, size_t count) = 0;
+  // send holds nranks blocks of `count` doubles, block g for rank g; recv block s = what rank s sent to this rank
+  virtual void alltoall(const double* send, double* recv, size_t count) = 0;
 };
 
 // Provided by whichever backend is linked into the library.

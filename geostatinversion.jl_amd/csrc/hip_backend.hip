@@ -853,6 +853,10 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
 };
 RcclApi& rccl() {
   static RcclApi api;
@@ -868,6 +872,10 @@ RcclApi& rccl() {
     api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
     api.ReduceScatter = (decltype(api.ReduceScatter))dlsym(api.h, "ncclReduceScatter");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+    api.Send = (decltype(api.Send))dlsym(api.h, "ncclSend");
+    api.Recv = (decltype(api.Recv))dlsym(api.h, "ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))dlsym(api.h, "ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.h, "ncclGroupEnd");
   });
   if (!api.h || !api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.AllGather || !api.ReduceScatter)
     throw Error(GSI_ERR_RCCL, "librccl.so could not be loaded: multi-GPU needs RCCL");
@@ -910,6 +918,18 @@ class RcclComm : public Comm {
   void reduce_scatter_sum(const double* send, double* recv, size_t count) override {
     be_->bind();
     RCCL_CHECK(rccl().ReduceScatter(send, recv, count, ncclDouble, ncclSum, comm_, be_->stream()));
+  }
+  // point-to-point xGMI: every pair of GPUs has a direct link, so the grouped sends / receives use all 7 links at once
+  void alltoall(const double* send, double* recv, size_t count) override {
+    be_->bind();
+    RcclApi& r = rccl();
+    if (!r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) throw Error(GSI_ERR_RCCL, "librccl has no ncclSend / ncclRecv");
+    RCCL_CHECK(r.GroupStart());
+    for (int g = 0; g < nranks; ++g) {
+      RCCL_CHECK(r.Send(send + (size_t)g * count, count, ncclDouble, g, comm_, be_->stream()));
+      RCCL_CHECK(r.Recv(recv + (size_t)g * count, count, ncclDouble, g, comm_, be_->stream()));
+    }
+    RCCL_CHECK(r.GroupEnd());
   }
 
  private:

@@ -42,10 +42,22 @@ void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* 
   Backend* be = c.be.get();
   // a rank without rows (m < rank * ceil(m / G)) has nothing to compute, but it still takes part in every
   // collective below: only the collective-free operator kinds may leave early
-  if (A.mloc == 0 && A.kind != OP_LOWRANK) return;
-  if (A.kind == OP_FFT_COV) {     // matrix-free: pad, FFT passes, spectrum, inverse passes, restrict (single rank)
-    ScopedPhase ph(be, PH_GEMM_N);
-    be->fftcov_apply(A.plan, l, X, ldx, Yloc, ldy);
+  if (A.mloc == 0 && A.kind != OP_LOWRANK && !(A.kind == OP_FFT_COV && c.comm)) return;
+  if (A.kind == OP_FFT_COV) {     // matrix-free: pad, FFT passes, spectrum, inverse passes, restrict
+    if (!c.comm) {
+      ScopedPhase ph(be, PH_GEMM_N);
+      be->fftcov_apply(A.plan, l, X, ldx, Yloc, ldy);
+      return;
+    }
+    // several ranks, X replicated: every rank transforms its own columns, then columns -> rows
+    int64_t c0, lloc;
+    default_shard(l, c.nranks(), c.rank(), &c0, &lloc);
+    Buf YC(be, (size_t)A.n * std::max<int64_t>(lloc, 1));
+    if (lloc > 0) {
+      ScopedPhase ph(be, PH_GEMM_N);
+      be->fftcov_apply(A.plan, lloc, X + c0 * ldx, ldx, YC.p, A.n);
+    }
+    cols_to_rows(c, A.n, l, YC.p, Yloc, ldy);
     return;
   }
   if (A.kind == OP_DENSE) {
@@ -97,12 +109,128 @@ void gather_rows(Context& c, const Operator& A, const double* Yloc, int64_t ldy,
   }
 }
 
+// ---- panel layouts over the ranks --------------------------------------------------------------------------------------
+// ROWS: this rank's rows [r0, r0 + nloc) of default_shard(n), all l columns (ld given).  COLS: all n rows, this rank's
+// columns [c0, c0 + lloc) of default_shard(l), ld = n.  A matrix-free operator that acts column by column (the FFT
+// covariance) wants COLS, the panel factorizations (row-sharded LU, TSQR) want ROWS; the change of layout is an
+// all-to-all of rows_s x cols_d blocks -- on xGMI every pair of GPUs has its own link, so all of them carry traffic at
+// once.  Chunked over columns so that the staging buffers stay ~1 GB whatever n is (512^3: one column per chunk).
+static int64_t a2a_chunk_cols(int64_t n, int64_t pad_l) {
+  int64_t cc = ((int64_t)1 << 27) / std::max<int64_t>(n, 1);
+  return std::max<int64_t>(1, std::min(cc, pad_l));
+}
+void rows_to_cols(Context& c, int64_t n, int64_t l, const double* Rloc, int64_t ldr, double* Cloc) {
+  Backend* be = c.be.get();
+  const int G = c.nranks(), rank = c.rank();
+  if (!c.comm) { be->copy2d(Cloc, n, Rloc, ldr, n, l); return; }   // (a 1-rank communicator still goes through the all-to-all)
+  const int64_t pad_n = (n + G - 1) / G, pad_l = (l + G - 1) / G;
+  int64_t r0, nloc, c0, lloc;
+  default_shard(n, G, rank, &r0, &nloc);
+  default_shard(l, G, rank, &c0, &lloc);
+  const int64_t cc = a2a_chunk_cols(n, pad_l), blk = pad_n * cc;
+  Buf send(be, (size_t)blk * G), recv(be, (size_t)blk * G);
+  be->fill_zero(send.p, (size_t)blk * G);
+  for (int64_t j = 0; j < pad_l; j += cc) {
+    const int64_t w = std::min(cc, pad_l - j);
+    for (int d = 0; d < G; ++d) {                        // to rank d: my rows of ITS columns j .. j + w
+      int64_t c0d, ld_;
+      default_shard(l, G, d, &c0d, &ld_);
+      const int64_t valid = std::max<int64_t>(0, std::min(w, ld_ - j));
+      if (valid > 0 && nloc > 0) be->copy2d(send.p + (size_t)d * blk, pad_n, Rloc + (c0d + j) * ldr, ldr, nloc, valid);
+    }
+    {
+      ScopedPhase ph(be, PH_COMM);
+      c.comm->alltoall(send.p, recv.p, (size_t)blk);
+    }
+    const int64_t mine = std::max<int64_t>(0, std::min(w, lloc - j));
+    for (int s2 = 0; s2 < G && mine > 0; ++s2) {          // from rank s2: its rows of my columns
+      int64_t r0s, ns;
+      default_shard(n, G, s2, &r0s, &ns);
+      if (ns > 0) be->copy2d(Cloc + r0s + j * n, n, recv.p + (size_t)s2 * blk, pad_n, ns, mine);
+    }
+  }
+}
+void cols_to_rows(Context& c, int64_t n, int64_t l, const double* Cloc, double* Rloc, int64_t ldr) {
+  Backend* be = c.be.get();
+  const int G = c.nranks(), rank = c.rank();
+  if (!c.comm) { be->copy2d(Rloc, ldr, Cloc, n, n, l); return; }
+  const int64_t pad_n = (n + G - 1) / G, pad_l = (l + G - 1) / G;
+  int64_t r0, nloc, c0, lloc;
+  default_shard(n, G, rank, &r0, &nloc);
+  default_shard(l, G, rank, &c0, &lloc);
+  const int64_t cc = a2a_chunk_cols(n, pad_l), blk = pad_n * cc;
+  Buf send(be, (size_t)blk * G), recv(be, (size_t)blk * G);
+  be->fill_zero(send.p, (size_t)blk * G);
+  for (int64_t j = 0; j < pad_l; j += cc) {
+    const int64_t w = std::min(cc, pad_l - j);
+    const int64_t mine = std::max<int64_t>(0, std::min(w, lloc - j));
+    for (int d = 0; d < G && mine > 0; ++d) {             // to rank d: ITS rows of my columns j .. j + w
+      int64_t r0d, nd;
+      default_shard(n, G, d, &r0d, &nd);
+      if (nd > 0) be->copy2d(send.p + (size_t)d * blk, pad_n, Cloc + r0d + j * n, n, nd, mine);
+    }
+    {
+      ScopedPhase ph(be, PH_COMM);
+      c.comm->alltoall(send.p, recv.p, (size_t)blk);
+    }
+    for (int s2 = 0; s2 < G; ++s2) {                      // from rank s2: my rows of its columns
+      int64_t c0s, ls;
+      default_shard(l, G, s2, &c0s, &ls);
+      const int64_t valid = std::max<int64_t>(0, std::min(w, ls - j));
+      if (valid > 0 && nloc > 0) be->copy2d(Rloc + (c0s + j) * ldr, ldr, recv.p + (size_t)s2 * blk, pad_n, nloc, valid);
+    }
+  }
+}
+
+// The matrix-free FFT covariance on several ranks: every rank holds the (replicated) plan and transforms ITS columns.
+// Rows in, rows out: rows -> columns (all-to-all), the column-wise transforms, columns -> rows (all-to-all).
+static void fft_mul_rows(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, double* Yloc, int64_t ldy) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  int64_t c0, lloc;
+  default_shard(l, c.nranks(), c.rank(), &c0, &lloc);
+  Buf XC(be, (size_t)A.n * std::max<int64_t>(lloc, 1));
+  rows_to_cols(c, A.n, l, Xloc, ldx, XC.p);
+  Buf YC(be, (size_t)A.n * std::max<int64_t>(lloc, 1));
+  if (lloc > 0) {
+    ScopedPhase ph(be, PH_GEMM_N);
+    be->fftcov_apply(A.plan, lloc, XC.p, A.n, YC.p, A.n);
+  }
+  XC.reset();
+  cols_to_rows(c, A.n, l, YC.p, Yloc, ldy);
+}
+
 void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, double* Z, int64_t ldz) {
   Context& c = *A.ctx;
   Backend* be = c.be.get();
   if (A.kind == OP_FFT_COV) {     // symmetric: A' X = A X
-    ScopedPhase ph(be, PH_GEMM_T);
-    be->fftcov_apply(A.plan, l, Xloc, ldx, Z, ldz);
+    if (!c.comm) {
+      ScopedPhase ph(be, PH_GEMM_T);
+      be->fftcov_apply(A.plan, l, Xloc, ldx, Z, ldz);
+      return;
+    }
+    // several ranks: rows -> columns, transform the own columns, all-gather the column blocks into the replicated Z
+    if (ldz != A.n) throw Error(GSI_ERR_INTERNAL, "op_mul_t: strided output with a communicator");
+    const int G = c.nranks();
+    const int64_t pad_l = (l + G - 1) / G;
+    int64_t c0, lloc;
+    default_shard(l, G, c.rank(), &c0, &lloc);
+    Buf XC(be, (size_t)A.n * pad_l), YC(be, (size_t)A.n * pad_l), all(be, (size_t)A.n * pad_l * G);
+    rows_to_cols(c, A.n, l, Xloc, ldx, XC.p);
+    be->fill_zero(YC.p, (size_t)A.n * pad_l);
+    if (lloc > 0) {
+      ScopedPhase ph(be, PH_GEMM_T);
+      be->fftcov_apply(A.plan, lloc, XC.p, A.n, YC.p, A.n);
+    }
+    {
+      ScopedPhase ph(be, PH_COMM);
+      c.comm->allgather(YC.p, all.p, (size_t)A.n * pad_l);
+    }
+    for (int g = 0; g < G; ++g) {
+      int64_t c0g, lg;
+      default_shard(l, G, g, &c0g, &lg);
+      if (lg > 0) be->copy2d(Z + c0g * ldz, ldz, all.p + (size_t)g * A.n * pad_l, A.n, A.n, lg);
+    }
     return;
   }
   if (A.kind == OP_DENSE) {
@@ -185,6 +313,11 @@ static Buf op_mul_t_sharded(const Operator& A, const double* Xloc, int64_t ldx, 
     be->gemm_nn(A.mloc, l, A.N, 1.0 / (double)(A.N - 1), A.data.p, A.ld, T.p, A.N, 0.0, Wloc.p, A.mloc);
     return Wloc;
   }
+  if (A.kind == OP_FFT_COV) {              // symmetric, row shards in and out: nothing n x l exists on any rank
+    Buf Wloc(be, (size_t)std::max<int64_t>(nloc, 1) * l);
+    fft_mul_rows(A, Xloc, ldx, l, Wloc.p, std::max<int64_t>(nloc, 1));
+    return Wloc;
+  }
   Buf P(be, (size_t)n * l);
   {
     ScopedPhase ph(be, PH_GEMM_T);
@@ -192,8 +325,6 @@ static Buf op_mul_t_sharded(const Operator& A, const double* Xloc, int64_t ldx, 
       be->fill_zero(P.p, (size_t)n * l);
     else if (A.kind == OP_DENSE)
       be->gemm_tn(n, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, P.p, n);       // RandMatFact.jl:85
-    else if (A.kind == OP_FFT_COV)
-      be->fftcov_apply(A.plan, l, Xloc, ldx, P.p, n);                                // one rank holds everything
     else
       be->gemm_nn_gridcov(n, l, A.mloc, A.data.p, A.gx, A.gy, 0, A.row0, Xloc, ldx, P.p, n);
   }
@@ -372,6 +503,39 @@ static void tsqr(Context& c, int64_t m, int64_t row0, int64_t mloc, Buf& Yloc, i
 }
 static void tsqr(Context& c, const Operator& A, Buf& Yloc, int64_t l) { tsqr(c, A.m, A.row0, A.mloc, Yloc, l, nullptr); }
 
+// The range finder with EVERY panel a row shard from the sketch to the TSQR (square operators whose adjoint is the
+// operator itself and whose products take and give row shards): LowRankCovMatrix -- S (S'X), only the N x l sums cross
+// ranks, adjoint(A) === A (lowrank.jl:38-40) -- and the FFT covariance -- rows -> columns, column-wise transforms,
+// columns -> rows.  LU row-sharded (bit-identical to the single-rank factorization), final Q by TSQR.  Nothing of size
+// n x l exists on any rank.  Omega_loc: this rank's rows of Omega (ld ldo).
+static bool rows_path_ok(Context& c, const Operator& A, int64_t l) {
+  return c.comm && (A.kind == OP_LOWRANK || A.kind == OP_FFT_COV) && A.m == A.n && all_shards_tall(A.m, c.nranks(), l);
+}
+static Buf rangefinder_rows(const Operator& A, const double* Omega_loc, int64_t ldo, int64_t l, int64_t q) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  const int64_t m = A.m, ldl = std::max<int64_t>(A.mloc, 1);
+  Buf Yloc(be, (size_t)ldl * l), Zloc;
+  auto mul_rows = [&](const double* Xloc, int64_t ldx, double* Out) {
+    if (A.kind == OP_FFT_COV) fft_mul_rows(A, Xloc, ldx, l, Out, ldl);
+    else op_mul(A, Xloc - A.row0, ldx, l, Out, A.mloc);     // op_mul reads rows [row0, row0 + mloc) of its X argument only
+  };
+  mul_rows(Omega_loc, ldo, Yloc.p);                         // Y = A*Omega            :55
+  if (q > 0) {
+    Zloc = Buf(be, (size_t)ldl * l);
+    lu_panel_sharded(c, Yloc.p, m, A.row0, A.mloc, l);      // Q = lu(Y).L            :60-61
+  }
+  for (int64_t i = 1; i <= q; ++i) {
+    mul_rows(Yloc.p, ldl, Zloc.p);                          // Q = A'*Q               :67
+    lu_panel_sharded(c, Zloc.p, m, A.row0, A.mloc, l);      //                        :68-69
+    mul_rows(Zloc.p, ldl, Yloc.p);                          // Q = A*Q                :70
+    if (i < q) lu_panel_sharded(c, Yloc.p, m, A.row0, A.mloc, l);   //                :72-73
+  }
+  Zloc.reset();
+  tsqr(c, A, Yloc, l);                                      //                        :57-58, 75-76
+  return Yloc;
+}
+
 Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
   Context& c = *A.ctx;
   Backend* be = c.be.get();
@@ -387,24 +551,9 @@ Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
     tsqr(c, A, Yloc, l);                                    //                        :57-58
     return Yloc;
   }
-  if (!single && A.kind == OP_LOWRANK && A.m == A.n && use_sharded_lu(c, A, m, l)) {
-    // LowRankCovMatrix with the row-sharded LU: every panel stays a row shard from the sketch to the TSQR -- products
-    // take and give local rows (S (S'X): only the N x l sums cross ranks), adjoint(A) === A (lowrank.jl:38-40)
-    Buf Yloc(be, (size_t)std::max<int64_t>(A.mloc, 1) * l), Zloc(be, (size_t)std::max<int64_t>(A.mloc, 1) * l);
-    auto mul_local = [&](const double* Xloc, int64_t ldx, double* Out) {
-      op_mul(A, Xloc - A.row0, ldx, l, Out, A.mloc);       // op_mul reads rows [row0, row0 + mloc) of its X argument only
-    };
-    mul_local(Omega + A.row0, n, Yloc.p);                   // Y = A*Omega            :55
-    lu_panel_sharded(c, Yloc.p, m, A.row0, A.mloc, l);      // Q = lu(Y).L            :60-61
-    for (int64_t i = 1; i <= q; ++i) {
-      mul_local(Yloc.p, A.mloc, Zloc.p);                    // Q = A'*Q               :67
-      lu_panel_sharded(c, Zloc.p, m, A.row0, A.mloc, l);    //                        :68-69
-      mul_local(Zloc.p, A.mloc, Yloc.p);                    // Q = A*Q                :70
-      if (i < q) lu_panel_sharded(c, Yloc.p, m, A.row0, A.mloc, l);   //              :72-73
-    }
-    tsqr(c, A, Yloc, l);                                    //                        :75-76
-    return Yloc;
-  }
+  if (!single && A.m == A.n && ((A.kind == OP_LOWRANK && use_sharded_lu(c, A, m, l)) ||
+                                (A.kind == OP_FFT_COV && rows_path_ok(c, A, l))))
+    return rangefinder_rows(A, Omega + A.row0, n, l, q);    // every panel stays a row shard (Omega is replicated here)
   Buf Yfull(be, (size_t)m * l);                              // replicated m x l
   Buf Z(be, (size_t)n * l);                                  // replicated n x l
   Buf Yloc;                                                  // this rank's rows (multi-rank only)
@@ -457,6 +606,28 @@ void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, doub
   }
 }
 
+// (), S, V = svd(B), Z = V*Sh with B = Q'A never formed whole (RandMatFact.jl:85-88): this rank's rows of W = B' = A'Q,
+// TSQR of the row blocks (the l x l factor everywhere), replicated small SVD, the local rows of Z.  Needs every row block
+// of n to be at least l tall.  Zloc: nloc x l, ld max(nloc, 1).
+static void svd_rows(const Operator& A, Buf& Q, int64_t K, int64_t l, double* Zloc, double* S) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  const int G = c.nranks();
+  int64_t r0n, nloc;
+  default_shard(A.n, G, c.rank(), &r0n, &nloc);
+  Buf Wloc = op_mul_t_sharded(A, Q.p, std::max<int64_t>(A.mloc, 1), l, nloc);   // B = Q'*A (rows of B')          :85
+  Q.reset();
+  Buf R(be, (size_t)l * l), U(be, (size_t)l * l);
+  tsqr(c, A.n, r0n, nloc, Wloc, l, R.p);
+  {
+    ScopedPhase ph(be, PH_SVD);
+    be->svd_small(R.p, l, U.p, S);                         // (), S, V = svd(B)                    :86
+    be->scale_cols_sqrt(U.p, l, S, K);                     // Sh = sqrt([S[1:K]; zeros(p)])        :87
+  }
+  ScopedPhase ph(be, PH_SMALL_GEMM);
+  be->gemm_nn(nloc, l, l, 1.0, Wloc.p, std::max<int64_t>(nloc, 1), U.p, l, 0.0, Zloc, std::max<int64_t>(nloc, 1));   // Z = V*Sh  :88
+}
+
 void randsvd(const Operator& A, const double* Omega, int64_t K, int64_t p, int64_t q, double* Z, double* S) {
   Context& c = *A.ctx;
   Backend* be = c.be.get();
@@ -465,33 +636,51 @@ void randsvd(const Operator& A, const double* Omega, int64_t K, int64_t p, int64
   Buf Q = rangefinder(A, Omega, l, q);                      // Q = rangefinder(A, K+p, q)     :84
   const int G = c.nranks();
   if (c.comm && all_shards_tall(A.n, G, l) && (A.kind != OP_LOWRANK || A.m == A.n)) {   // any communicator, also 1 rank
-    // svd(B) row-sharded: W = B' = A'Q never exists whole.  TSQR of its row blocks gives the l x l factor
-    // everywhere; the small SVD is replicated; each rank forms its rows of Z and the blocks are gathered.
     int64_t r0n, nloc;
     default_shard(A.n, G, c.rank(), &r0n, &nloc);
-    Buf Wloc = op_mul_t_sharded(A, Q.p, A.mloc, l, nloc);    // B = Q'*A (rows of B')                :85
-    Q.reset();
-    Buf R(be, (size_t)l * l), U(be, (size_t)l * l);
-    tsqr(c, A.n, r0n, nloc, Wloc, l, R.p);
-    {
-      ScopedPhase ph(be, PH_SVD);
-      be->svd_small(R.p, l, U.p, S);                         // (), S, V = svd(B)                    :86
-      be->scale_cols_sqrt(U.p, l, S, K);                     // Sh = sqrt([S[1:K]; zeros(p)])        :87
-    }
-    Buf Zloc(be, (size_t)nloc * l);
-    {
-      ScopedPhase ph(be, PH_SMALL_GEMM);
-      be->gemm_nn(nloc, l, l, 1.0, Wloc.p, nloc, U.p, l, 0.0, Zloc.p, nloc);   // Z = V*Sh            :88
-    }
+    Buf Zloc(be, (size_t)std::max<int64_t>(nloc, 1) * l);
+    svd_rows(A, Q, K, l, Zloc.p, S);
     Operator shape;
     shape.m = A.n; shape.row0 = r0n; shape.mloc = nloc;
-    gather_rows(c, shape, Zloc.p, nloc, l, Z);
+    gather_rows(c, shape, Zloc.p, std::max<int64_t>(nloc, 1), l, Z);
     return;
   }
   Buf W(be, (size_t)A.n * l);
   op_mul_t(A, Q.p, A.mloc, l, W.p, A.n);                    // B = Q'*A  (held as B' = A'Q)   :85
   Q.reset();
   svd_tall(c, W.p, A.n, l, K, Z, S);                        // (), S, V = svd(B); Z = V*Sh    :86-88
+}
+
+// randsvd with Omega given and Z returned as ROW SHARDS (this rank's rows of default_shard(n); ld = max(nloc, 1)): the
+// form for panels that must never exist whole on one GPU (BASELINE configs[2] at 512^3 / rank 256: 275 GB per panel) and
+// for consumers that keep the xi-basis sharded (configs[4]).  LowRankCovMatrix and FFT operators never gather anything of
+// size n x l; dense / implicit operators need X replicated for their products, so Omega is all-gathered for them (their
+// n is bounded by the stored / generated operator anyway) and only the output stays sharded.
+void randsvd_rows(const Operator& A, const double* Omega_loc, int64_t K, int64_t p, int64_t q, double* Zloc, double* S) {
+  Context& c = *A.ctx;
+  Backend* be = c.be.get();
+  if (K < 0 || p < 0 || K + p < 1) throw Error(GSI_ERR_ARG, "randsvd: need K >= 0, p >= 0, K + p >= 1");
+  const int64_t l = K + p, n = A.n;
+  if (!c.comm) { randsvd(A, Omega_loc, K, p, q, Zloc, S); return; }
+  if (q < 0)
+    throw Error(GSI_ERR_NEG_ITERS, "parameter numiterations should be positive, but numiterations=" + std::to_string(q));
+  if (l > A.m || l > A.n) throw Error(GSI_ERR_ARG, "rangefinder: need 1 <= l <= min(size(A))");
+  const int G = c.nranks();
+  if (!all_shards_tall(n, G, l))
+    throw Error(GSI_ERR_ARG, "randsvd_rows: every rank's row block must be at least K + p rows tall");
+  int64_t r0n, nloc;
+  default_shard(n, G, c.rank(), &r0n, &nloc);
+  Buf Q;
+  if (rows_path_ok(c, A, l)) {
+    Q = rangefinder_rows(A, Omega_loc, std::max<int64_t>(nloc, 1), l, q);
+  } else {
+    Buf Om(be, (size_t)n * l);
+    Operator shape;
+    shape.m = n; shape.row0 = r0n; shape.mloc = nloc;
+    gather_rows(c, shape, Omega_loc, std::max<int64_t>(nloc, 1), l, Om.p);
+    Q = rangefinder(A, Om.p, l, q);
+  }
+  svd_rows(A, Q, K, l, Zloc, S);
 }
 
 void eig_nystrom(const Operator& A, const double* Q, int64_t j, double* U, double* Sigma) {

@@ -75,6 +75,12 @@ bool use_sharded_lu(Context& c, const Operator& A, int64_t rows, int64_t l);
 Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q);
 // randsvd(A, K, p, q)  RandMatFact.jl:83-90.  Z (n x (K+p), ld n) and S (K+p) replicated.
 void randsvd(const Operator& A, const double* Omega, int64_t K, int64_t p, int64_t q, double* Z, double* S);
+// The same with Omega given and Z returned as this rank's ROWS (block layout of default_shard(n), ld = max(nloc, 1)):
+// nothing n x l is gathered for LowRankCovMatrix / FFT operators.  S replicated.
+void randsvd_rows(const Operator& A, const double* Omega_loc, int64_t K, int64_t p, int64_t q, double* Zloc, double* S);
+// layout changes of an n x l panel over the ranks: ROWS (own rows, all columns, ld ldr) <-> COLS (all rows, own columns, ld n)
+void rows_to_cols(Context& c, int64_t n, int64_t l, const double* Rloc, int64_t ldr, double* Cloc);
+void cols_to_rows(Context& c, int64_t n, int64_t l, const double* Cloc, double* Rloc, int64_t ldr);
 // eig_nystrom(A, Q)  RandMatFact.jl:92-102.  Q replicated n x j; U (m x j), Sigma (j) replicated.
 void eig_nystrom(const Operator& A, const double* Q, int64_t j, double* U, double* Sigma);
 // thin SVD of a replicated tall W (n x l, destroyed): V (n x l, may alias W) = left singular

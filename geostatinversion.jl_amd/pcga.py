@@ -76,6 +76,18 @@ class DeviceBasis:
         return out
 
 
+class ShardedDeviceBasis(DeviceBasis):
+    """A ROW-SHARDED xi-basis (BASELINE configs[4]): this rank's rows of Z as `gsi_randsvd_rows` left them,
+    one process per GPU.  `params` / `update` act on this rank's rows of s, X and paramstorun (nothing of size n x K is
+    replicated); `gather(rows) -> whole` is the host-side all-gather of row blocks the caller's launcher provides
+    (torch.distributed, MPI, Julia's Distributed ...), used only to hand whole parameter vectors to the forward model
+    (user code on the host, as the reference's pmap does) and for the convergence norm."""
+
+    def __init__(self, Zmat_rows, K, gather, precision=64):
+        super().__init__(Zmat_rows, K, precision=precision)
+        self.gather = gather
+
+
 class _Basis:
     """xis given on the host (the reference's Vector{Vector{Float64}}) as one n x K column-major block."""
 
@@ -113,12 +125,21 @@ def _iteration_head(forwardmodel, basis, s, X, delta):
     """direct.jl:38-46 / lsqr.jl:36-51."""
     K = basis.K
     P = basis.params(s, X, delta)                                     # paramstorun
+    if getattr(basis, "gather", None) is not None:                    # row-sharded basis: whole vectors for the forward model
+        P = basis.gather(P)
     results = [np.asarray(forwardmodel(np.ascontiguousarray(P[:, i])), dtype=np.float64) for i in range(K + 3)]
     hs = results[K + 2]
     etas = [(results[i] - hs) / delta for i in range(K)]
     HX = (results[K] - hs) / delta
     Hs = (results[K + 1] - hs) / delta
     return etas, HX, Hs, hs
+
+
+def _global_norm(basis, d):
+    """norm(s - olds) (direct.jl:29, lsqr.jl:27); over all ranks' rows when the basis is row-sharded"""
+    if getattr(basis, "gather", None) is not None:
+        d = basis.gather(d)
+    return float(np.linalg.norm(d))
 
 
 def pcgadirect(forwardmodel, s0, X, xis, R, y, *, maxiters=5, delta=SQRT_EPS, xtol=1e-6,
@@ -141,7 +162,7 @@ def pcgadirect(forwardmodel, s0, X, xis, R, y, *, maxiters=5, delta=SQRT_EPS, xt
         bigA = np.block([[HQH + Rd, HX[:, None]], [HX[None, :], np.zeros((1, 1))]])   # :57
         x = np.linalg.pinv(bigA) @ b                                  # :58
         s = basis.update(X, x[-1], etas, x[:-1])                      # :59-65
-        if np.linalg.norm(s - olds) < xtol:
+        if _global_norm(basis, s - olds) < xtol:
             converged = True
         it += 1
     return s
@@ -163,7 +184,7 @@ def pcgalsqr(forwardmodel, s0, X, xis, R, y, *, maxiters=5, delta=SQRT_EPS, xtol
         x = bigA.lsqr(b)                                              # :54  (LSQR on the device)
         bigA.close()
         s = basis.update(X, x[-1], etas, x[:-1])                      # :55-61
-        if np.linalg.norm(s - olds) < xtol:
+        if _global_norm(basis, s - olds) < xtol:
             converged = True
         it += 1
     return s

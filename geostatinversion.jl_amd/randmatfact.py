@@ -112,6 +112,24 @@ def randsvd(A, K, p, q, *, Omega=None, return_S=False, ctx=None):
             op.close()
 
 
+def randsvd_rows(op, K, p, q, Omega_rows, *, return_S=False):
+    """`randsvd` with row-sharded panels over the ranks of `op`'s communicator (`gsi_randsvd_rows`): `Omega_rows` = this
+    rank's rows of Omega (host array or DeviceMatrix, nloc x (K+p)); returns this rank's rows of Z as a DeviceMatrix
+    (nothing n x (K+p) is gathered), optionally S (host)."""
+    from .context import DeviceMatrix
+    cx = op.ctx
+    l = int(K) + int(p)
+    Om = Omega_rows if isinstance(Omega_rows, DeviceMatrix) else DeviceMatrix.from_host(cx, Omega_rows)
+    Z = DeviceMatrix(cx, Om.shape[0], l)
+    S = DeviceMatrix(cx, l, 1)
+    L.check(cx.lib.gsi_randsvd_rows(cx.h, op.h, Om.h, int(K), int(p), int(q), Z.h, S.h), cx.lib)
+    Sh = S.to_host()[:, 0].copy()
+    S.close()
+    if Om is not Omega_rows:
+        Om.close()
+    return (Z, Sh) if return_S else Z
+
+
 def eig_nystrom(A, Q, *, ctx=None):
     """`eig_nystrom(A, Q)`  (RandMatFact.jl:92-102) -> (U, Sigmavec); eigenvalues are Sigmavec**2."""
     op, owned = _as_operator(A, ctx)

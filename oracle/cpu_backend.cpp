@@ -449,6 +449,13 @@ class CallbackComm : public Comm {
     g_allreduce(tmp.data(), (int64_t)tmp.size());
     std::memcpy(recv, tmp.data() + count * (size_t)rank, count * sizeof(double));
   }
+  void alltoall(const double* send, double* recv, size_t count) override {             // all-gather, keep the blocks meant for me
+    if (!g_allgather) throw Error(GSI_ERR_RCCL, "cpuref: collectives not registered");
+    std::vector<double> all(count * (size_t)nranks * (size_t)nranks);
+    g_allgather(send, all.data(), (int64_t)(count * (size_t)nranks));
+    for (int s = 0; s < nranks; ++s)
+      std::memcpy(recv + count * (size_t)s, all.data() + count * ((size_t)s * nranks + (size_t)rank), count * sizeof(double));
+  }
 };
 }  // namespace
 

@@ -137,6 +137,80 @@ def _worker(rank, world, port, q):
         results["implicit_sv"] = rel_sv_err(S, Sr, 8)
         results["implicit_xis"] = orc.xis_error_up_to_sign(Z, Zr, 8)
         gop.close()
+        # ---- matrix-free FFT covariance on several ranks (BASELINE configs[2] as configured needs the panels spread over
+        #      GPUs): every rank transforms its own columns, panels are row shards between the products (all-to-all)
+        Ns, beta = [12, 9], -3.0                                     # n = 108; FFTRF convention, 2N not a power of two on axis 1
+        nf = 108
+        Af = orc.fft_powerlaw_apply(np.eye(nf), Ns, beta, fftrf=True)
+        fop = gsi.fft_powerlaw_operator(ctx, Ns, beta, fftrf=True)
+        X = rng.standard_normal((nf, 7))
+        results["fft_mul"] = float(np.abs(fop.matmul(X) - Af @ X).max())
+        results["fft_mul_t"] = float(np.abs(fop.rmatmul_t(X) - Af @ X).max())
+        K, p, qq = 9, 5, 2
+        Om = rng.standard_normal((nf, K + p))
+        Zf, Sf = gsi.randsvd(fop, K, p, qq, Omega=Om, return_S=True)          # Omega replicated, Z gathered
+        Zr, Sr, _ = orc.randsvd_full(Af, K, p, qq, Om)
+        results["fft_sv"] = rel_sv_err(Sf, Sr, K)
+        results["fft_xis"] = orc.xis_error_up_to_sign(Zf, Zr, K)
+
+        def gather_rows(loc):                                         # host-side all-gather of row blocks (test harness)
+            parts = [None] * world
+            dist.all_gather_object(parts, np.ascontiguousarray(loc))
+            return np.concatenate(parts, axis=0)
+
+        def my_rows(full):
+            r0, nl = ctx.shard(full.shape[0])
+            return np.asfortranarray(full[r0:r0 + nl])
+
+        # gsi_randsvd_rows: Omega and Z as row shards, nothing n x l on any rank (FFT, LowRankCovMatrix); dense gathers Omega
+        Zrows, S2 = gsi.randsvd_rows(fop, K, p, qq, my_rows(Om), return_S=True)
+        Zfull = gather_rows(Zrows.to_host())
+        results["fft_rows_sv"] = rel_sv_err(S2, Sr, K)
+        results["fft_rows_xis"] = orc.xis_error_up_to_sign(Zfull, Zr, K)
+        Zrows.close()
+        Z0 = gather_rows(gsi.randsvd_rows(fop, K, p, 0, my_rows(Om)).to_host())   # q = 0: sketch + TSQR only
+        Zr0, Sr0, _ = orc.randsvd_full(Af, K, p, 0, Om)
+        results["fft_rows_q0_xis"] = orc.xis_error_up_to_sign(Z0, Zr0, K)
+        fop.close()
+        fields = powerlaw_fields(rng, (10, 9), 25)
+        Om = rng.standard_normal((90, 12))
+        lr = gsi.LowRankCovMatrix(fields, ctx=ctx)
+        Zl = gather_rows(gsi.randsvd_rows(lr._device_operator(), 8, 4, 3, my_rows(Om)).to_host())
+        xr, _ = orc.getxis_fields(fields, 8, 4, 3, Om)
+        results["lowrank_rows_xis"] = orc.xis_error_up_to_sign(Zl, np.array(xr).T, 8)
+        lr.close()
+        Om = rng.standard_normal((143, 16))
+        dop = gsi.dense_operator(ctx, A)
+        Zd, Sd = gsi.randsvd_rows(dop, 10, 6, 2, my_rows(Om), return_S=True)
+        Zr, Sr, _ = orc.randsvd_full(A, 10, 6, 2, Om)
+        results["dense_rows_sv"] = rel_sv_err(Sd, Sr, 10)
+        results["dense_rows_xis"] = orc.xis_error_up_to_sign(gather_rows(Zd.to_host()), Zr, 10)
+        dop.close()
+        # ---- BASELINE configs[4]: pcgalsqr over a ROW-SHARDED xi-basis (every rank keeps its rows of Z, s, X and of the
+        #      perturbation batch; the forward model is host code and sees gathered vectors) against the oracle's pcgalsqr
+        Np, Mp = 96, 6
+        xs = rng.standard_normal(Np)
+        Q0 = rng.standard_normal((Mp, Np))
+        Qc = Q0.T @ Q0
+        truep = np.real(np.linalg.cholesky(Qc + 1e-9 * np.eye(Np)) @ rng.standard_normal(Np)) + 1.0
+        forward = lambda pv: pv * xs
+        noise = 1e-4
+        yobs = forward(truep) + noise * rng.standard_normal(Np)
+        import scipy.sparse as sp
+        Rn = noise ** 2 * sp.identity(Np, format="csc")
+        Omp = rng.standard_normal((Np, Mp + 2))
+        qop = gsi.dense_operator(ctx, Qc)
+        Zp = gsi.randsvd_rows(qop, Mp, 2, 3, my_rows(Omp))
+        basis = gsi.ShardedDeviceBasis(Zp, Mp, gather_rows)
+        X0 = np.full(Np, 1.0)
+        r0p, nlp = ctx.shard(Np)
+        s_loc = gsi.pcgalsqr(forward, X0[r0p:r0p + nlp], X0[r0p:r0p + nlp], basis, Rn, yobs, ctx=ctx)
+        s_full = gather_rows(s_loc)
+        xis_ref = orc.getxis_dense(Qc, Mp, 2, 3, Omp)
+        s_ref = orc.pcgalsqr(forward, X0, X0, xis_ref, Rn, yobs)
+        results["pcgalsqr_sharded_basis"] = float(np.linalg.norm(s_full - s_ref) / np.linalg.norm(s_ref))
+        results["pcgalsqr_sharded_fit"] = 0.0 if np.linalg.norm(s_full - truep) / np.linalg.norm(truep) < 2e-2 else 1.0
+        basis.close(); Zp.close(); qop.close()
         ctx.close()
         dist.barrier()
         dist.destroy_process_group()
@@ -170,8 +244,11 @@ def test_sharded_pipeline_gloo(world):
     for rank, _, res in out:
         for k, v in res.items():
             tol = 1e-6 if k.endswith("xis") else 1e-9
-            if k.endswith("orth") or k in ("mul", "mul_t", "lowrank_mul", "lowrank_empty_rank_mul", "implicit_mul", "implicit_mul_t"):
+            if k.endswith("orth") or k in ("mul", "mul_t", "lowrank_mul", "lowrank_empty_rank_mul", "implicit_mul", "implicit_mul_t",
+                                            "fft_mul", "fft_mul_t"):
                 tol = 1e-11
+            if k == "pcgalsqr_sharded_basis":
+                tol = 1e-6
             assert v < tol, (rank, k, v)
     # every rank computed the same replicated result
     r0 = out[0][2]

@@ -396,8 +396,19 @@ Z1, S1 = gsi.randsvd(A, 14, 6, 2, Omega=Om, return_S=True, ctx=ctx)
 fields = powerlaw_fields(rng, (12, 12), 30); Om2 = rng.standard_normal((144, 12))
 lr = gsi.LowRankCovMatrix(fields, ctx=ctx); Z3 = gsi.randsvd(lr, 8, 4, 3, Omega=Om2)
 gi = gsi.gridcov_implicit_operator(ctx, 20, 15, 3.0); Z5 = gsi.randsvd(gi, 14, 6, 2, Omega=Om)
+# the FFT covariance behind a communicator: rows <-> columns all-to-alls (ncclSend / ncclRecv groups), row-sharded LU, TSQR;
+# and the row-sharded entry point (Omega rows in, Z rows out: with one rank the shard is the whole panel)
+fo = gsi.fft_powerlaw_operator(ctx, [25, 12], -3.5, fftrf=True)
+Z6, S6 = gsi.randsvd(fo, 14, 6, 2, Omega=Om, return_S=True)
+Z7m, S7 = gsi.randsvd_rows(fo, 14, 6, 2, Om, return_S=True); Z7 = Z7m.to_host()
+Xf = rng.standard_normal((300, 5)); Yf = fo.matmul(Xf); Yft = fo.rmatmul_t(Xf)
 del os.environ["GSI_FORCE_COMM"]
 ctx2 = gsi.Context(0)
+fo2 = gsi.fft_powerlaw_operator(ctx2, [25, 12], -3.5, fftrf=True)
+Z8, S8 = gsi.randsvd(fo2, 14, 6, 2, Omega=Om, return_S=True)
+assert np.abs(S6 - S8).max() < 1e-12 * S8[0] and np.abs(S7 - S8).max() < 1e-12 * S8[0]
+assert np.abs(Z6 @ Z6.T - Z8 @ Z8.T).max() < 1e-9 and np.abs(Z7 @ Z7.T - Z8 @ Z8.T).max() < 1e-9
+assert np.abs(Yf - fo2.matmul(Xf)).max() < 1e-12 and np.abs(Yft - Yf).max() < 1e-12
 Z2, S2 = gsi.randsvd(A, 14, 6, 2, Omega=Om, return_S=True, ctx=ctx2)
 lr2 = gsi.LowRankCovMatrix(fields, ctx=ctx2); Z4 = gsi.randsvd(lr2, 8, 4, 3, Omega=Om2)
 assert np.abs(S1 - S2).max() < 1e-12 * S2[0], np.abs(S1 - S2).max()
