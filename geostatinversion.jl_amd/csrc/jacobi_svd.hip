@@ -105,6 +105,57 @@ __device__ __forceinline__ int jacobi_pair(double* __restrict__ gp, double* __re
   return l16 == 0 ? 1 : 0;
 }
 
+// The same pair step with column p RESIDENT in the quarter wave's registers (xr, loaded once per launch): in the bipartite
+// (cross-block) tournament pair slot `pairidx` keeps column p = pairidx for all SVD_W rounds and only its partner q walks,
+// so p's 2 NI LDS reads and NI writes per round go away -- the round is LDS-bandwidth and LDS-latency bound (a round moved
+// 160 KB through LDS per workgroup; now 100 KB).  Same operations on the same values in the same order: bit-identical.
+template <int NI>
+__device__ __forceinline__ int jacobi_pair_resident(double (&xr)[NI], double* __restrict__ gq, int l16, bool active, double tol2) {
+  double a = 0.0, b = 0.0, c = 0.0;
+  double yr[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) yr[k] = gq[l16 + 16 * k];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) { a += xr[k] * xr[k]; b += yr[k] * yr[k]; c += xr[k] * yr[k]; }
+  a = quarter_allsum(a); b = quarter_allsum(b); c = quarter_allsum(c);
+  if (!(active && a > 0.0 && b > 0.0 && c * c > tol2 * (a * b))) return 0;
+  const double d = b - a, e = 2.0 * c;
+  const double q2 = d * d + e * e;
+  const double r = q2 * __builtin_amdgcn_rsq(q2);
+  const double t = copysign(fabs(e), d * e) * __builtin_amdgcn_rcp(fabs(d) + r);
+  const double w = 1.0 + t * t;
+  double cs = __builtin_amdgcn_rsq(w);
+  cs = cs * (1.5 - 0.5 * w * cs * cs);
+  cs = cs * (1.5 - 0.5 * w * cs * cs);
+  const double sn = cs * t;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const double x = xr[k], y = yr[k];
+    xr[k] = cs * x - sn * y;
+    gq[l16 + 16 * k] = sn * x + cs * y;
+  }
+  return l16 == 0 ? 1 : 0;
+}
+template <int NI, int SVD_W>
+__device__ __forceinline__ int jacobi_cross_rounds(double* __restrict__ cols, int lp, int pairidx, bool active, int l16, double tol2) {
+  const int p = active ? pairidx : 0;
+  double* gp = cols + p * lp;
+  double xr[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) xr[k] = gp[l16 + 16 * k];
+  int rots = 0;
+  for (int r = 0; r < SVD_W; ++r) {
+    const int q = SVD_W + (p + r) % SVD_W;
+    rots += jacobi_pair_resident<NI>(xr, cols + q * lp, l16, active, tol2);
+    __syncthreads();
+  }
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) gp[l16 + 16 * k] = xr[k];
+  }
+  return rots;
+}
+
 // grid.x = number of block pairs in this round; SVD_W = columns per block (16, or 8 for l > 600)
 template <int SVD_W>
 __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __restrict__ G, int l, int lp,
@@ -145,6 +196,14 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   __syncthreads();
   int rots = 0;
   const int ni = ((l & 15) == 0) ? (l >> 4) : 0;      // elements per lane when the columns divide evenly
+  const bool resident_ok = cross_only && inner_sweeps == 1 && (ni == 20 || ni == 16 || ni == 10) && SVD_W <= SVD_THREADS / 16;
+  if (resident_ok) {
+    const int pairidx = 4 * wave + quarter;
+    const bool active = pairidx < SVD_W;
+    if (ni == 20) rots += jacobi_cross_rounds<20, SVD_W>(cols, lp, pairidx, active, l16, tol2);
+    else if (ni == 16) rots += jacobi_cross_rounds<16, SVD_W>(cols, lp, pairidx, active, l16, tol2);
+    else rots += jacobi_cross_rounds<10, SVD_W>(cols, lp, pairidx, active, l16, tol2);
+  } else
   for (int sw = 0; sw < inner_sweeps; ++sw) {
     // cross_only: only pairs (column of block a, column of block b) -- SVD_W rounds of a bipartite
     // tournament; otherwise all pairs of the 2*SVD_W resident columns (2*SVD_W - 1 rounds).  The pairs

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void lu_u12_kernel(const double* __restrict__ 
 // MFMA operands swapped like the big contraction kernel: lane (jl = lane & 15, kk = lane >> 4) holds, for C row
 // jl (+16 h), the columns kk + 4 reg of a 16-column tile.
 constexpr int RK_CHUNK = 128;
-template <int K>
+template <int K, int DEPTH>
 __global__ __launch_bounds__(256) void lu_rankk_kernel(double* __restrict__ Y, int64_t ld, int64_t m, int64_t r_begin,
                                                        int64_t jb, int64_t c0, int64_t t,
                                                        const double* __restrict__ U12) {
@@ -667,11 +667,19 @@ __global__ __launch_bounds__(256) void lu_rankk_kernel(double* __restrict__ Y, i
       }
     };
     load_tile(0, cin);
+    double cin2[2][4];                                // DEPTH == 2: two tiles of C in flight
+    if (DEPTH == 2 && ntile > 1) load_tile(1, cin2);
     for (int tt = 0; tt < ntile; ++tt) {
       double4_t acc[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[h] = (double4_t){cin[h][0], cin[h][1], cin[h][2], cin[h][3]};
-      if (tt + 1 < ntile) load_tile(tt + 1, cin);     // next tile's C in flight behind this tile's MFMAs
+      if (DEPTH == 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) cin[h][reg] = cin2[h][reg];
+        if (tt + 2 < ntile) load_tile(tt + 2, cin2);
+      } else if (tt + 1 < ntile) load_tile(tt + 1, cin);     // next tile's C in flight behind this tile's MFMAs
 #pragma unroll
       for (int s = 0; s < K / 4; ++s) {
         const double fb = -us[(16 * tt + jl) * KP + 4 * s + kk];
@@ -695,10 +703,14 @@ template <int K>
 static void launch_rankk(hipStream_t st, unsigned grid, double* Y, int64_t ld, int64_t m, int64_t r_begin, int64_t jb,
                          int64_t c0, int64_t t, const double* U12) {
   constexpr size_t shmem = (size_t)RK_CHUNK * (K + 2) * sizeof(double);
+  static const int depth = getenv("GSI_LU_RK_DEPTH") ? atoi(getenv("GSI_LU_RK_DEPTH")) : 1;   // A/B knob: C tiles in flight per wave
   static std::atomic<uint64_t> attr_mask{0};
-  if (first_use_on_this_device(attr_mask))
-    (void)hipFuncSetAttribute((const void*)lu_rankk_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  hipLaunchKernelGGL((lu_rankk_kernel<K>), dim3(grid), dim3(256), shmem, st, Y, ld, m, r_begin, jb, c0, t, U12);
+  if (first_use_on_this_device(attr_mask)) {
+    (void)hipFuncSetAttribute((const void*)lu_rankk_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void*)lu_rankk_kernel<K, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  }
+  if (depth == 2) hipLaunchKernelGGL((lu_rankk_kernel<K, 2>), dim3(grid), dim3(256), shmem, st, Y, ld, m, r_begin, jb, c0, t, U12);
+  else hipLaunchKernelGGL((lu_rankk_kernel<K, 1>), dim3(grid), dim3(256), shmem, st, Y, ld, m, r_begin, jb, c0, t, U12);
 }
 
 // top l x l: unit diagonal, zero strict upper triangle (what Julia's F.L returns)

@@ -122,11 +122,14 @@ class PCGALowRankMatrix:
         L.check(lib.gsi_pcgamat_create(self.ctx.h, C.byref(h), L.dptr(E), self.nobs, self.K, hx.ctypes.data_as(L.c_dp),
                                        Rv.ctypes.data_as(L.c_dp), diag), lib)
         self.h = h
+        self.ctx._children.append(self)       # destroyed before the context is (its buffers belong to the context)
 
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.gsi_pcgamat_destroy(self.h)
             self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
 
     def __del__(self):
         try:

@@ -32,6 +32,7 @@ class DeviceBasis:
         h = C.c_void_p()
         L.check(self.ctx.lib.gsi_basis_create(self.ctx.h, C.byref(h), Zmat.h, self.K, self.precision), self.ctx.lib)
         self.h = h
+        self.ctx._children.append(self)   # destroyed before the context is
         if self.precision == 32:
             self.Zmat = None            # the fp64 matrix is no longer needed by this basis
 
@@ -39,6 +40,8 @@ class DeviceBasis:
         if getattr(self, "h", None):
             self.ctx.lib.gsi_basis_destroy(self.h)
             self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
 
     def __del__(self):
         try:

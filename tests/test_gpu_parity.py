@@ -715,8 +715,16 @@ def test_pcga_lowrank_matrix_gpu(gsi, ctx, nobs, K):
     b = np.concatenate([rng.standard_normal(nobs), [0.0]])
     sol, it = A.lsqr(b, return_iterations=True)
     solr, itr = orc.lsqr(ref.matvec, ref.matvec, b, nobs + 1)
+    # The stopping rules fire on sqrt(eps)-sized quantities: rounding-level differences (summation order of the norms)
+    # can move the stop by an iteration, and LSQR iterates of this saddle-point system carry 1e-16 noise amplified to
+    # ~1e-5 (the oracle itself with 1e-16 noise injected into its products moves by 6e-6).  So: the same iteration count
+    # up to 2, the iterate at that count, and a residual as small as the oracle's.
     assert abs(it - itr) <= 2
-    assert np.linalg.norm(sol - solr) < 1e-6 * np.linalg.norm(solr)
+    sol_at, _ = orc.lsqr(ref.matvec, ref.matvec, b, nobs + 1, maxiter=it, atol=0.0, btol=0.0, conlim=0.0)
+    assert np.linalg.norm(sol - sol_at) < 1e-4 * np.linalg.norm(sol_at)
+    assert np.linalg.norm(sol - solr) < 1e-4 * np.linalg.norm(solr)
+    rg, rr = np.linalg.norm(ref.matvec(sol) - b), np.linalg.norm(ref.matvec(solr) - b)
+    assert abs(rg - rr) < 1e-6 * np.linalg.norm(b) + 0.05 * rr
     A.close()
 
 
