@@ -12,7 +12,7 @@ The directory name contains a dot, so import it through the `gsi_amd` alias at t
 from . import _lib
 from ._lib import GsiError, load, LIB_PATH
 from .context import (Context, Operator, DeviceMatrix, dense_operator, gridcov_operator,
-                      gridcov_implicit_operator, fft_powerlaw_operator, lowrank_synthetic_operator,
+                      gridcov_implicit_operator, pointcov_implicit_operator, fft_powerlaw_operator, lowrank_synthetic_operator,
                       default_context)
 from . import randmatfact as RandMatFact
 from .randmatfact import rangefinder, randsvd, randsvd_rows, eig_nystrom, colnorms, lu_L, lu_L_sharded, lu_L_sharded_virtual, qr_thinQ, svd_tall, gemm
@@ -22,7 +22,7 @@ from .pcga import pcgadirect, pcgalsqr, rga, pcga, DeviceBasis, ShardedDeviceBas
 
 __all__ = [
     "GsiError", "load", "LIB_PATH", "Context", "Operator", "DeviceMatrix", "dense_operator",
-    "gridcov_operator", "gridcov_implicit_operator", "fft_powerlaw_operator", "lowrank_synthetic_operator", "default_context", "RandMatFact", "rangefinder", "randsvd", "randsvd_rows", "eig_nystrom",
+    "gridcov_operator", "gridcov_implicit_operator", "pointcov_implicit_operator", "fft_powerlaw_operator", "lowrank_synthetic_operator", "default_context", "RandMatFact", "rangefinder", "randsvd", "randsvd_rows", "eig_nystrom",
     "colnorms", "lu_L", "lu_L_sharded", "lu_L_sharded_virtual", "qr_thinQ", "svd_tall", "gemm", "LowRankCovMatrix", "PCGALowRankMatrix", "device_samples",
     "getxis", "getxis_iwantfields", "getxis_device", "randsvdwithseed", "pcgadirect", "pcgalsqr", "rga", "pcga",
     "DeviceBasis", "ShardedDeviceBasis",

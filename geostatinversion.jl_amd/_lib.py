@@ -42,6 +42,8 @@ SIGNATURES = {
     "gsi_op_gridcov_implicit": (C.c_int, [c_vp, C.POINTER(c_vp), c_i64, c_i64, C.c_double, c_i64, c_i64]),
     "gsi_op_gridcov_implicit_kind": (C.c_int, [c_vp, C.POINTER(c_vp), c_i64, c_i64, C.c_double, C.c_int, c_i64, c_i64]),
     "gsi_op_gridcov_implicit_table": (C.c_int, [c_vp, C.POINTER(c_vp), c_i64, c_i64, c_dp, c_i64, c_i64]),
+    "gsi_op_pointcov_implicit": (C.c_int, [c_vp, C.POINTER(c_vp), c_dp, c_i64, C.c_int, C.c_int, C.c_double, C.c_double,
+                                           C.c_double, c_i64, c_i64]),
     "gsi_op_fft_powerlaw": (C.c_int, [c_vp, C.POINTER(c_vp), C.c_int, C.POINTER(c_i64), C.c_double]),
     "gsi_op_fft_powerlaw_fftrf": (C.c_int, [c_vp, C.POINTER(c_vp), C.c_int, C.POINTER(c_i64), C.c_double]),
     "gsi_op_destroy": (C.c_int, [c_vp]),

@@ -190,6 +190,26 @@ def gridcov_implicit_operator(ctx, nx, ny, ell, kind=0, table=None):
     return Operator(ctx, h)
 
 
+POINTCOV_KINDS = {"gaussian": 0, "exponential": 1, "matern32": 2, "matern52": 3}
+
+
+def pointcov_implicit_operator(ctx, points, kind="exponential", ell=1.0, sigma2=1.0, nugget=0.0):
+    """The covariance of scattered points, A[i, j] = sigma2 * k(|x_i - x_j| / ell) (+ nugget on the diagonal), as an
+    implicit operator (`gsi_op_pointcov_implicit`): `points` is d x n (point i = column i, d = 1..3 -- the layout of the
+    reference's `points::Matrix`, FFTRF.jl:102); kind in "gaussian", "exponential", "matern32", "matern52".  Row panels of
+    A are generated on a second stream while the MFMA contraction consumes the previous one; nothing n x n is stored."""
+    P = np.asfortranarray(np.asarray(points, dtype=np.float64))
+    if P.ndim != 2 or not 1 <= P.shape[0] <= 3:
+        raise ValueError("points must be d x n with d = 1, 2 or 3")
+    d, n = P.shape
+    k = POINTCOV_KINDS[kind] if isinstance(kind, str) else int(kind)
+    row0, mloc = ctx.shard(n)
+    h = C.c_void_p()
+    L.check(ctx.lib.gsi_op_pointcov_implicit(ctx.h, C.byref(h), P.ctypes.data_as(L.c_dp), n, d, k, float(ell), float(sigma2),
+                                             float(nugget), row0, mloc), ctx.lib)
+    return Operator(ctx, h)
+
+
 def fft_powerlaw_operator(ctx, Ns, beta, fftrf=False):
     """Matrix-free power-law covariance on a structured grid (circulant embedding, spectrum |k|^beta, unit diagonal).
     `Ns` = grid points per axis (1 to 3 axes); the operator acts on vec(field) in Julia's (column-major) order.

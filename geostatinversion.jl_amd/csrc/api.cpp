@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../include/gsi_hip.h"
 #include "pipeline.hpp"
+#include "pointcov.hpp"
 
 using namespace gsi;
 
@@ -284,6 +285,25 @@ int gsi_op_gridcov_implicit_table(gsi_ctx* ctx, gsi_op** op, int64_t nx, int64_t
     REQUIRE(ctx && op && table, "NULL argument");
     *op = nullptr;
     make_gridcov_table(ctx, op, nx, ny, table, row0, m_local);
+  });
+}
+
+int gsi_op_pointcov_implicit(gsi_ctx* ctx, gsi_op** op, const double* points, int64_t n, int d, int kind, double ell,
+                             double sigma2, double nugget, int64_t row0, int64_t m_local) {
+  return guarded([&] {
+    REQUIRE(ctx && op && points, "NULL argument");
+    *op = nullptr;
+    REQUIRE(n >= 1 && d >= 1 && d <= 3, "point covariance: need n >= 1 points in 1, 2 or 3 dimensions");
+    REQUIRE(kind >= 0 && kind < pointcov::NUM_KINDS, "point covariance: kind 0 Gaussian, 1 exponential, 2 Matern 3/2, 3 Matern 5/2");
+    REQUIRE(ell > 0.0 && sigma2 > 0.0 && nugget >= 0.0, "point covariance: need ell > 0, sigma2 > 0, nugget >= 0");
+    check_shard(ctx->c, n, row0, m_local);
+    std::unique_ptr<gsi_op> o(new gsi_op());
+    Operator& A = o->op;
+    A.ctx = &ctx->c; A.kind = OP_POINTCOV; A.m = n; A.n = n; A.row0 = row0; A.mloc = m_local; A.ld = 0;
+    A.pc_d = d; A.pc_kind = kind; A.pc_ell = ell; A.pc_sigma2 = sigma2; A.pc_nugget = nugget;
+    A.data = Buf(ctx->c.be.get(), (size_t)n * d);
+    ctx->c.be->upload2d(A.data.p, d, points, d, d, n);       // every rank holds all coordinates (8 d n bytes)
+    *op = o.release();
   });
 }
 

@@ -54,6 +54,13 @@ class Backend {
                                int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
                                int64_t ldc) = 0;
 
+  // C (m x l) = G * B(k x l) for the covariance of SCATTERED points, G(i, j) = sigma2 kfun(|p_i - p_j| / ell) (+ nugget if
+  // i == j), rows roff.., reduction indices koff..; pts = d x npts coordinates (point i = column i) in backend memory;
+  // kind / params: pointcov.hpp.  G is generated panel by panel, never stored whole (the "row-streamed" operator).
+  virtual void gemm_nn_pointcov(int64_t m, int64_t l, int64_t k, const double* pts, int d, int kind, double ell,
+                                double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb,
+                                double* C, int64_t ldc) = 0;
+
   // Matrix-free stationary covariance on an N[0] x N[1] x N[2] grid (column-major point index) by circulant
   // embedding: A = R F^-1 diag(lambda) F R', lambda(k) = |k|^beta, unit diagonal (fft_cov.hip).  Opaque plan.
   // fftrf != 0: FFTRF.jl's own convention -- embedding of exactly 2 N[a] points, integer wavenumbers (FFTRF.jl:83-90)

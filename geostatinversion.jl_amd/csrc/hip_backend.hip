@@ -81,6 +81,11 @@ class HipBackend : public Backend {
     for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     hipFree(flags_);
     hipFree(scal_);
+    if (st2_) {
+      hipStreamSynchronize(st2_);
+      for (int i = 0; i < 2; ++i) { hipEventDestroy(ev_gen_[i]); hipEventDestroy(ev_used_[i]); }
+      hipStreamDestroy(st2_);
+    }
     hipStreamDestroy(st_);
   }
   const char* name() const override { return "hip-gfx950"; }
@@ -216,6 +221,45 @@ class HipBackend : public Backend {
     double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, k));
     hipk::gemm_f64_gridcov(st_, m, l, k, tab, nx, ny, roff, koff, B, ldb, C, ldc, ws);
     check_launch("gemm_nn_gridcov");
+  }
+
+  // Scattered-point covariance, row-streamed: panels of `pr` rows of G are generated on a second stream (pointcov.hip)
+  // while the stored-operand contraction consumes the previous one; two panels ping-pong, events order them.
+  void gemm_nn_pointcov(int64_t m, int64_t l, int64_t k, const double* pts, int d, int kind, double ell, double sigma2,
+                        double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
+                        int64_t ldc) override {
+    bind();
+    if (m <= 0 || l <= 0 || k <= 0) return;
+    pointcov::Params prm{d, kind, 1.0 / ell, sigma2, nugget};
+    // panel height: a multiple of 128 rows (the contraction's row block), ~4 GB per panel (GSI_POINTCOV_PANEL_MB), <= m
+    static const int64_t panel_mb = getenv("GSI_POINTCOV_PANEL_MB") ? atoll(getenv("GSI_POINTCOV_PANEL_MB")) : 4096;
+    int64_t pr = (panel_mb << 20) / (8 * k);
+    pr = std::max<int64_t>(128, (pr / 128) * 128);
+    if (pr > m) pr = ((m + 1) / 2) * 2;                      // even leading dimension: 16-byte loads in the contraction
+    const int64_t npan = (m + pr - 1) / pr;
+    if (!st2_) {
+      HIP_CHECK(hipStreamCreate(&st2_));
+      for (int i = 0; i < 2; ++i) { HIP_CHECK(hipEventCreateWithFlags(&ev_gen_[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_used_[i], hipEventDisableTiming)); }
+    }
+    double* P[2] = {alloc((size_t)pr * k), nullptr};
+    try { P[1] = (npan > 1) ? alloc((size_t)pr * k) : nullptr; } catch (...) { release(P[0]); throw; }
+    double* ws = gemm_ws(hipk::gemm_workspace_doubles(std::min(pr, m), l, k));
+    // the generator must not overwrite a panel buffer that earlier work on st_ may still read (pooled memory)
+    HIP_CHECK(hipEventRecord(ev_used_[0], st_));
+    HIP_CHECK(hipEventRecord(ev_used_[1], st_));
+    for (int64_t p = 0; p < npan; ++p) {
+      const int b = (int)(p & 1);
+      const int64_t r0 = p * pr, rows = std::min(pr, m - r0);
+      HIP_CHECK(hipStreamWaitEvent(st2_, ev_used_[b], 0));   // the contraction that read this buffer two panels ago is done
+      hipk::pointcov_panel(st2_, P[b], pr, rows, k, pts, prm, roff + r0, koff);
+      HIP_CHECK(hipEventRecord(ev_gen_[b], st2_));
+      HIP_CHECK(hipStreamWaitEvent(st_, ev_gen_[b], 0));
+      hipk::gemm_f64(st_, false, rows, l, k, 1.0, P[b], pr, B, ldb, 0.0, C + r0, ldc, ws);
+      HIP_CHECK(hipEventRecord(ev_used_[b], st_));
+    }
+    check_launch("gemm_nn_pointcov");
+    release(P[0]);                                          // stream-ordered pool: the next user is ordered after st_'s work
+    if (P[1]) release(P[1]);
   }
 
   // ---- matrix-free FFT covariance ----
@@ -823,6 +867,8 @@ class HipBackend : public Backend {
   int ncus_ = 0;
   std::string arch_;
   hipStream_t st_ = nullptr;
+  hipStream_t st2_ = nullptr;                 // the panel generator of the scattered-point operator
+  hipEvent_t ev_gen_[2] = {nullptr, nullptr}, ev_used_[2] = {nullptr, nullptr};
   int32_t* flags_ = nullptr;  // [0] lu info, [1] chol info, [8] jacobi rotation counter
   double* scal_ = nullptr;
   DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_, ws_blas2_, ws_lus_, ws_svdf_, ws_qr_hh_;

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstddef>
+#include "pointcov.hpp"
 
 namespace gsi { namespace hipk {
 
@@ -36,6 +37,10 @@ void gemm_f64_trmm_upper(hipStream_t st, int64_t M, int64_t L, int64_t K, const 
 // C = G * B, G(i,k) = tab[|x_i-x_k| * ny + |y_i-y_k|] generated in registers (tab: nx * ny kernel table)
 void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* tab, int64_t nx, int64_t ny,
                       int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws);
+
+// ---- pointcov.hip: row panels of a scattered-point covariance ----
+void pointcov_panel(hipStream_t st, double* P, int64_t ldp, int64_t rows, int64_t cols, const double* pts,
+                    const pointcov::Params& prm, int64_t roff, int64_t koff);
 
 // ---- fft_cov.hip ----
 int64_t fft_embed_size(int64_t N);   // next power of two >= 2 N (1 for a singleton axis)

@@ -37,6 +37,15 @@ Operator::~Operator() {
   if (plan && ctx && ctx->be) ctx->be->fftcov_destroy(plan);
 }
 
+// C (m x l) = G[roff .. roff + m, koff .. koff + k) * B for the two generated (never stored) symmetric covariances: a table
+// over grid offsets (OP_GRIDCOV_IMPLICIT) or a kernel function of scattered coordinates (OP_POINTCOV)
+static void implicit_mul(Backend* be, const Operator& A, int64_t m, int64_t l, int64_t k, int64_t roff, int64_t koff,
+                         const double* B, int64_t ldb, double* C, int64_t ldc) {
+  if (A.kind == OP_GRIDCOV_IMPLICIT) be->gemm_nn_gridcov(m, l, k, A.data.p, A.gx, A.gy, roff, koff, B, ldb, C, ldc);
+  else be->gemm_nn_pointcov(m, l, k, A.data.p, A.pc_d, A.pc_kind, A.pc_ell, A.pc_sigma2, A.pc_nugget, roff, koff, B, ldb, C, ldc);
+}
+static bool is_implicit(const Operator& A) { return A.kind == OP_GRIDCOV_IMPLICIT || A.kind == OP_POINTCOV; }
+
 void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* Yloc, int64_t ldy) {
   Context& c = *A.ctx;
   Backend* be = c.be.get();
@@ -65,9 +74,9 @@ void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* 
     be->gemm_nn(A.mloc, l, A.n, 1.0, A.data.p, A.ld, X, ldx, 0.0, Yloc, ldy);   // RandMatFact.jl:55,70
     return;
   }
-  if (A.kind == OP_GRIDCOV_IMPLICIT) {
+  if (is_implicit(A)) {
     ScopedPhase ph(be, PH_GEMM_N);
-    be->gemm_nn_gridcov(A.mloc, l, A.n, A.data.p, A.gx, A.gy, A.row0, 0, X, ldx, Yloc, ldy);
+    implicit_mul(be, A, A.mloc, l, A.n, A.row0, 0, X, ldx, Yloc, ldy);
     return;
   }
   // LowRankCovMatrix: A*X = S (S'X) / (N-1)   (lowrank.jl:115-121 as two tall-skinny products)
@@ -248,13 +257,13 @@ void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, dou
     }
     return;
   }
-  if (A.kind == OP_GRIDCOV_IMPLICIT) {
+  if (is_implicit(A)) {
     // A symmetric: (A_loc)' X_loc = G[:, row0 .. row0+mloc) * X_loc -- the same generated NN product with
     // the roles of the row and reduction offsets exchanged; partial sums over the ranks' row blocks
     {
       ScopedPhase ph(be, PH_GEMM_T);
       if (A.mloc > 0)
-        be->gemm_nn_gridcov(A.n, l, A.mloc, A.data.p, A.gx, A.gy, 0, A.row0, Xloc, ldx, Z, ldz);
+        implicit_mul(be, A, A.n, l, A.mloc, 0, A.row0, Xloc, ldx, Z, ldz);
       else
         for (int64_t cidx = 0; cidx < l; ++cidx) be->fill_zero(Z + cidx * ldz, (size_t)A.n);
     }
@@ -326,7 +335,7 @@ static Buf op_mul_t_sharded(const Operator& A, const double* Xloc, int64_t ldx, 
     else if (A.kind == OP_DENSE)
       be->gemm_tn(n, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, P.p, n);       // RandMatFact.jl:85
     else
-      be->gemm_nn_gridcov(n, l, A.mloc, A.data.p, A.gx, A.gy, 0, A.row0, Xloc, ldx, P.p, n);
+      implicit_mul(be, A, n, l, A.mloc, 0, A.row0, Xloc, ldx, P.p, n);
   }
   Buf send(be, (size_t)pad * l * G), recv(be, (size_t)pad * l);
   if (pad * G != n) be->fill_zero(send.p, (size_t)pad * l * G);

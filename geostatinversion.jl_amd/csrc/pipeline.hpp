@@ -34,7 +34,7 @@ struct Context {
   int nranks() const { return comm ? comm->nranks : 1; }
 };
 
-enum OpKind { OP_DENSE = 0, OP_LOWRANK = 1, OP_GRIDCOV_IMPLICIT = 2, OP_FFT_COV = 3 };
+enum OpKind { OP_DENSE = 0, OP_LOWRANK = 1, OP_GRIDCOV_IMPLICIT = 2, OP_FFT_COV = 3, OP_POINTCOV = 4 };
 
 // A linear operator m x n; this rank holds rows [row0, row0 + mloc).
 struct Operator {
@@ -45,6 +45,9 @@ struct Operator {
   int64_t ld = 0;
   int64_t N = 0;   // lowrank: number of samples
   int64_t gx = 0, gy = 0;   // implicit grid covariance: data = the gx * gy table of the kernel over grid offsets; never stored
+  // OP_POINTCOV (scattered points): data = the d x n coordinates; entries generated panel by panel, never stored whole
+  int pc_d = 0, pc_kind = 0;
+  double pc_ell = 1.0, pc_sigma2 = 1.0, pc_nugget = 0.0;
   void* plan = nullptr;     // OP_FFT_COV: the backend's circulant-embedding plan (owned; single rank)
   Operator() = default;
   Operator(const Operator&) = delete;

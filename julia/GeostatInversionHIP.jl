@@ -152,6 +152,23 @@ function GridCovImplicit(table::Matrix{Float64}; c::Context=ctx())
 	return op
 end
 
+"The covariance of scattered points as an implicit operator: `A[i, j] = sigma2 * k(|x_i - x_j| / ell)` (+ `nugget` on the
+diagonal), `points` d x n as `FFTRF.powerlaw_unstructuredgrid` takes them (FFTRF.jl:102), `kind` in `:gaussian`,
+`:exponential`, `:matern32`, `:matern52` (`gsi_op_pointcov_implicit`).  Nothing n x n is stored: row panels of A are
+generated on a second stream while the MFMA contraction consumes the previous one.  Usable wherever a Matrix is."
+function PointCovImplicit(points::Matrix{Float64}, kind::Symbol=:exponential; ell::Float64=1.0, sigma2::Float64=1.0,
+		nugget::Float64=0.0, c::Context=ctx())
+	k = Dict(:gaussian=>0, :exponential=>1, :matern32=>2, :matern52=>3)[kind]
+	d, n = size(points)
+	r = Ref{Ptr{Cvoid}}(C_NULL)
+	check(ccall((:gsi_op_pointcov_implicit, libgsi), Cint,
+		(Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ptr{Float64}, Int64, Cint, Cint, Cdouble, Cdouble, Cdouble, Int64, Int64),
+		c.h, r, points, n, d, k, ell, sigma2, nugget, 0, n))
+	op = DeviceOperator(r[], c, n, n)
+	finalizer(finalize_op!, op)
+	return op
+end
+
 "The covariance of `FFTRF.powerlaw_structuredgrid(Ns, k0, dk, beta)` fields themselves (up to dk^2 and the per-sample
 mean / std normalisation, FFTRF.jl:94-98): FFTRF's own embedding of exactly 2N points per axis and its integer
 wavenumbers (FFTRF.jl:83-90, computesqrtS_f :40-72), `gsi_op_fft_powerlaw_fftrf`.  Acts on `vec(field)`; every grid

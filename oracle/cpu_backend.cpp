@@ -15,6 +15,7 @@
 #include "../include/gsi_hip.h"
 #include "../geostatinversion.jl_amd/csrc/backend.hpp"
 #include "../geostatinversion.jl_amd/csrc/lsqr_state.hpp"
+#include "../geostatinversion.jl_amd/csrc/pointcov.hpp"
 
 extern "C" {
 void gsio_gemm_nn(int64_t, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, double, double*, int64_t);
@@ -83,6 +84,23 @@ class CpuBackend : public Backend {
         for (int64_t kk = 0; kk < k; ++kk) {
           const int64_t gj = koff + kk;
           s += tab[std::llabs(gi / ny - gj / ny) * ny + std::llabs(gi % ny - gj % ny)] * B[kk + c * ldb];
+        }
+        C[r + c * ldc] = s;
+      }
+  }
+  void gemm_nn_pointcov(int64_t m, int64_t l, int64_t k, const double* pts, int d, int kind, double ell, double sigma2,
+                        double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
+                        int64_t ldc) override {
+    const pointcov::Params prm{d, kind, 1.0 / ell, sigma2, nugget};
+    for (int64_t c = 0; c < l; ++c)
+      for (int64_t r = 0; r < m; ++r) {
+        const int64_t gi = roff + r;
+        double s = 0.0;
+        for (int64_t kk = 0; kk < k; ++kk) {
+          const int64_t gj = koff + kk;
+          double d2 = 0.0;
+          for (int a = 0; a < d; ++a) { const double t = pts[gi * d + a] - pts[gj * d + a]; d2 += t * t; }
+          s += pointcov::kernel(prm, d2, gi == gj) * B[kk + c * ldb];
         }
         C[r + c * ldc] = s;
       }

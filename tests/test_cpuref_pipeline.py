@@ -360,3 +360,28 @@ def test_lu_sharded_virtual_ranks(gsi, cx, m, l, G):
     L1, p1 = gsi.lu_L(Y, return_pivots=True, ctx=cx)
     assert np.array_equal(pv, orc.lu_pivots(Y)) and np.array_equal(pv, p1)
     assert np.array_equal(Lv, L1)
+
+
+@pytest.mark.parametrize("d,kind", [(1, "gaussian"), (2, "exponential"), (3, "matern32"), (2, "matern52")])
+def test_pointcov_implicit_cpuref(gsi, cx, d, kind):
+    """gsi_op_pointcov_implicit through api.cpp / pipeline.cpp on the CPU reference backend (pointcov.hpp's kernel
+    definitions, shared with the device generator) against the dense kernel matrix numpy builds from the coordinates."""
+    rng = np.random.default_rng(17 + d)
+    n = 90
+    P = rng.uniform(0.0, 10.0, size=(d, n))
+    r = np.sqrt(((P[:, :, None] - P[:, None, :]) ** 2).sum(axis=0)) / 3.0
+    Kd = {"gaussian": np.exp(-0.5 * r * r), "exponential": np.exp(-r),
+          "matern32": (1 + np.sqrt(3) * r) * np.exp(-np.sqrt(3) * r),
+          "matern52": (1 + np.sqrt(5) * r + 5 * r * r / 3) * np.exp(-np.sqrt(5) * r)}[kind]
+    A = 1.5 * Kd + 0.2 * np.eye(n)
+    op = gsi.pointcov_implicit_operator(cx, P, kind, ell=3.0, sigma2=1.5, nugget=0.2)
+    X = rng.standard_normal((n, 6))
+    assert np.abs(op.matmul(X) - A @ X).max() < 1e-12 * np.abs(A @ X).max()
+    assert np.abs(op.rmatmul_t(X) - A @ X).max() < 1e-12 * np.abs(A @ X).max()
+    Om = rng.standard_normal((n, 14))
+    Z, S = gsi.randsvd(op, 10, 4, 2, Omega=Om, return_S=True)
+    Zr, Sr, _ = orc.randsvd_full(A, 10, 4, 2, Om)
+    assert rel_sv_err(S, Sr, 10) < 1e-9 and orc.xis_error_up_to_sign(Z, Zr, 10) < 1e-6
+    op.close()
+    with pytest.raises(gsi.GsiError):
+        gsi.pointcov_implicit_operator(cx, rng.uniform(size=(4, 10)).reshape(4, 10)[:3], 9)

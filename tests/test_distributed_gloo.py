@@ -137,6 +137,20 @@ def _worker(rank, world, port, q):
         results["implicit_sv"] = rel_sv_err(S, Sr, 8)
         results["implicit_xis"] = orc.xis_error_up_to_sign(Z, Zr, 8)
         gop.close()
+        # scattered-point covariance (entries generated panel by panel): sharded products and randsvd against the dense matrix
+        Pp = rng.uniform(0.0, 20.0, size=(2, 70))
+        dd = np.sqrt(((Pp[:, :, None] - Pp[:, None, :]) ** 2).sum(axis=0)) / 5.0
+        Ap = (1.0 + np.sqrt(3.0) * dd) * np.exp(-np.sqrt(3.0) * dd)
+        pop = gsi.pointcov_implicit_operator(ctx, Pp, "matern32", ell=5.0)
+        X = rng.standard_normal((70, 4))
+        results["pointcov_mul"] = float(np.abs(pop.matmul(X) - Ap @ X).max())
+        results["pointcov_mul_t"] = float(np.abs(pop.rmatmul_t(X) - Ap @ X).max())
+        Om = rng.standard_normal((70, 12))
+        Z, S = gsi.randsvd(pop, 8, 4, 2, Omega=Om, return_S=True)
+        Zr, Sr, _ = orc.randsvd_full(Ap, 8, 4, 2, Om)
+        results["pointcov_sv"] = rel_sv_err(S, Sr, 8)
+        results["pointcov_xis"] = orc.xis_error_up_to_sign(Z, Zr, 8)
+        pop.close()
         # ---- matrix-free FFT covariance on several ranks (BASELINE configs[2] as configured needs the panels spread over
         #      GPUs): every rank transforms its own columns, panels are row shards between the products (all-to-all)
         Ns, beta = [12, 9], -3.0                                     # n = 108; FFTRF convention, 2N not a power of two on axis 1
@@ -245,7 +259,7 @@ def test_sharded_pipeline_gloo(world):
         for k, v in res.items():
             tol = 1e-6 if k.endswith("xis") else 1e-9
             if k.endswith("orth") or k in ("mul", "mul_t", "lowrank_mul", "lowrank_empty_rank_mul", "implicit_mul", "implicit_mul_t",
-                                            "fft_mul", "fft_mul_t"):
+                                            "fft_mul", "fft_mul_t", "pointcov_mul", "pointcov_mul_t"):
                 tol = 1e-11
             if k == "pcgalsqr_sharded_basis":
                 tol = 1e-6
