@@ -23,7 +23,11 @@ struct gsi_mat {
   gsi_ctx* ctx;
   Buf buf;
   int64_t rows, cols;
+  int refs = 1;            // the caller's handle + one per gsi_basis that points into buf (precision 64: no copy)
 };
+static void mat_unref(gsi_mat* m) {
+  if (m && --m->refs <= 0) delete m;
+}
 struct gsi_pcgamat {
   gsi_ctx* ctx;
   PcgaLowRank A;
@@ -34,6 +38,7 @@ struct gsi_basis {
   int precision;          // 64: Z64 points into the gsi_mat; 32: own fp32 copy in buf32
   const double* Z64;
   Buf buf32;
+  gsi_mat* owner = nullptr;   // precision 64: the matrix whose buffer Z64 points into, kept alive by this basis
 };
 
 namespace {
@@ -455,7 +460,7 @@ int gsi_mat_create(gsi_ctx* ctx, gsi_mat** mat, int64_t rows, int64_t cols) {
   });
 }
 int gsi_mat_destroy(gsi_mat* mat) {
-  return guarded([&] { delete mat; });
+  return guarded([&] { mat_unref(mat); });     // the buffer lives on while a 64-bit gsi_basis still points into it
 }
 int gsi_mat_upload(gsi_ctx* ctx, gsi_mat* mat, const double* host, int64_t ldh) {
   return guarded([&] {
@@ -848,12 +853,20 @@ int gsi_basis_create(gsi_ctx* ctx, gsi_basis** basis, const gsi_mat* Z, int64_t 
       b->buf32 = Buf(ctx->c.be.get(), (count + 1) / 2);               // fp32 elements in a double-typed allocation
       ctx->c.be->f64_to_f32(Z->buf.p, b->buf32.p, count);
       b->Z64 = nullptr;
+    } else {
+      b->owner = const_cast<gsi_mat*>(Z);      // shared ownership: gsi_mat_destroy before gsi_basis_destroy is safe
+      b->owner->refs += 1;
     }
     *basis = b.release();
   });
 }
 int gsi_basis_destroy(gsi_basis* basis) {
-  return guarded([&] { delete basis; });
+  return guarded([&] {
+    if (!basis) return;
+    gsi_mat* owner = basis->owner;
+    delete basis;
+    mat_unref(owner);
+  });
 }
 int gsi_pcga_params_basis(gsi_ctx* ctx, const gsi_basis* basis, const double* s, const double* X, double delta,
                           double* out) {

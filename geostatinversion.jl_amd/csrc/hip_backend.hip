@@ -238,17 +238,28 @@ class HipBackend : public Backend {
     int64_t pr = (panel_mb << 20) / (8 * k);
     pr = std::max<int64_t>(128, (pr / 128) * 128);
     if (pr > m) pr = ((m + 1) / 2) * 2;                      // even leading dimension: 16-byte loads in the contraction
-    const int64_t npan = (m + pr - 1) / pr;
     if (!st2_) {
       HIP_CHECK(hipStreamCreate(&st2_));
       for (int i = 0; i < 2; ++i) { HIP_CHECK(hipEventCreateWithFlags(&ev_gen_[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_used_[i], hipEventDisableTiming)); }
     }
-    double* P[2] = {alloc((size_t)pr * k), nullptr};
-    try { P[1] = (npan > 1) ? alloc((size_t)pr * k) : nullptr; } catch (...) { release(P[0]); throw; }
+    double* P[2] = {nullptr, nullptr};
+    for (;;) {                                               // memory is the operator's to use, but never a reason to fail
+      try {
+        P[0] = alloc((size_t)pr * k);
+        P[1] = (m > pr) ? alloc((size_t)pr * k) : nullptr;
+        break;
+      } catch (const Error&) {
+        if (P[0]) { release(P[0]); P[0] = nullptr; }
+        trim_pool(0);
+        if (pr <= 128) throw;
+        pr = std::max<int64_t>(128, ((pr / 2) / 128) * 128);
+      }
+    }
     double* ws = gemm_ws(hipk::gemm_workspace_doubles(std::min(pr, m), l, k));
     // the generator must not overwrite a panel buffer that earlier work on st_ may still read (pooled memory)
     HIP_CHECK(hipEventRecord(ev_used_[0], st_));
     HIP_CHECK(hipEventRecord(ev_used_[1], st_));
+    const int64_t npan = (m + pr - 1) / pr;
     for (int64_t p = 0; p < npan; ++p) {
       const int b = (int)(p & 1);
       const int64_t r0 = p * pr, rows = std::min(pr, m - r0);

@@ -385,3 +385,18 @@ def test_pointcov_implicit_cpuref(gsi, cx, d, kind):
     op.close()
     with pytest.raises(gsi.GsiError):
         gsi.pointcov_implicit_operator(cx, rng.uniform(size=(4, 10)).reshape(4, 10)[:3], 9)
+
+
+def test_basis_outlives_its_matrix(gsi, cx):
+    """a 64-bit gsi_basis points into the gsi_mat's buffer -- it shares ownership, so destroying the matrix
+    first is safe (under `make -C oracle asan` + tools/asan_cpu_suite.sh this is a use-after-free check)."""
+    rng = np.random.default_rng(3)
+    Zh = np.asfortranarray(rng.standard_normal((50, 6)))
+    Zm = gsi.DeviceMatrix.from_host(cx, Zh)
+    basis = gsi.DeviceBasis(Zm, 4)
+    Zm.close()                                        # gsi_mat_destroy before the basis is used
+    s0, X0 = rng.standard_normal(50), rng.standard_normal(50)
+    P = basis.params(s0, X0, 0.5)
+    assert np.abs(P[:, :4] - (s0[:, None] + 0.5 * Zh[:, :4])).max() < 1e-14
+    assert np.abs(basis[2] - Zh[:, 2]).max() == 0.0
+    basis.close()
