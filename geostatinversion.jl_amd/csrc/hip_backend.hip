@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <map>
@@ -996,16 +998,109 @@ class RcclComm : public Comm {
   ncclComm_t comm_ = nullptr;
 };
 
+// ---- ranks as THREADS of one process (GSI_LOCAL_COMM=1): one context per thread, on different GPUs with peer access or --
+//      what makes the whole multi-rank pipeline runnable on a one-GPU box -- on the SAME GPU.  RCCL refuses two ranks on one
+//      device; this communicator needs nothing but HIP: every rank's device pointers are valid in every thread of the
+//      process, so a collective is "synchronise my stream, meet at a host barrier, read the peers' buffers with kernels /
+//      copies on my own stream, synchronise, meet again".  Rank-ordered sums (deterministic).  Not a performance path.
+struct LocalGroup {
+  int nranks = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  std::vector<const double*> src;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t gen = generation;
+    if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
+    else cv.wait(lk, [&] { return generation != gen; });
+  }
+};
+static std::mutex g_local_mu;
+static std::map<std::string, std::shared_ptr<LocalGroup>> g_local_groups;
+
+class LocalComm : public Comm {
+ public:
+  LocalComm(HipBackend* be, int n, int r, const void* id) : be_(be) {
+    nranks = n;
+    rank = r;
+    const std::string key((const char*)id, 32);
+    std::lock_guard<std::mutex> g(g_local_mu);
+    auto& grp = g_local_groups[key];
+    if (!grp) { grp = std::make_shared<LocalGroup>(); grp->nranks = n; grp->src.assign((size_t)n, nullptr); }
+    if (grp->nranks != n) throw Error(GSI_ERR_ARG, "local communicator: ranks disagree on nranks");
+    grp_ = grp;
+    for (int d = 0, cnt = 0; hipGetDeviceCount(&cnt) == hipSuccess && d < cnt; ++d)      // best effort: peers on other GPUs
+      if (d != be_->device()) { (void)hipDeviceEnablePeerAccess(d, 0); (void)hipGetLastError(); }
+  }
+  // publish my buffer, wait until every rank has published and its producing work is complete
+  void publish(const double* p) {
+    be_->bind();
+    HIP_CHECK(hipStreamSynchronize(be_->stream()));
+    { std::lock_guard<std::mutex> g(grp_->mu); grp_->src[(size_t)rank] = p; }
+    grp_->barrier();
+  }
+  void finish() {                       // my reads of the peers' buffers are done; nobody may reuse a buffer before all are
+    HIP_CHECK(hipStreamSynchronize(be_->stream()));
+    grp_->barrier();
+  }
+  void allreduce_sum(double* buf, size_t count) override {
+    publish(buf);
+    double* tmp = be_->alloc(count);
+    hipStream_t st = be_->stream();
+    HIP_CHECK(hipMemcpyAsync(tmp, grp_->src[0], count * sizeof(double), hipMemcpyDeviceToDevice, st));
+    for (int g = 1; g < nranks; ++g) hipk::axpy(st, (int64_t)count, 1.0, grp_->src[(size_t)g], tmp);
+    finish();                           // every rank has summed the ORIGINAL buffers
+    HIP_CHECK(hipMemcpyAsync(buf, tmp, count * sizeof(double), hipMemcpyDeviceToDevice, st));
+    be_->release(tmp);
+  }
+  void allgather(const double* send, double* recv, size_t count) override {
+    publish(send);
+    for (int g = 0; g < nranks; ++g)
+      HIP_CHECK(hipMemcpyAsync(recv + (size_t)g * count, grp_->src[(size_t)g], count * sizeof(double), hipMemcpyDeviceToDevice,
+                               be_->stream()));
+    finish();
+  }
+  void reduce_scatter_sum(const double* send, double* recv, size_t count) override {
+    publish(send);
+    hipStream_t st = be_->stream();
+    HIP_CHECK(hipMemcpyAsync(recv, grp_->src[0] + (size_t)rank * count, count * sizeof(double), hipMemcpyDeviceToDevice, st));
+    for (int g = 1; g < nranks; ++g) hipk::axpy(st, (int64_t)count, 1.0, grp_->src[(size_t)g] + (size_t)rank * count, recv);
+    finish();
+  }
+  void alltoall(const double* send, double* recv, size_t count) override {
+    publish(send);
+    for (int g = 0; g < nranks; ++g)
+      HIP_CHECK(hipMemcpyAsync(recv + (size_t)g * count, grp_->src[(size_t)g] + (size_t)rank * count, count * sizeof(double),
+                               hipMemcpyDeviceToDevice, be_->stream()));
+    finish();
+  }
+
+ private:
+  HipBackend* be_;
+  std::shared_ptr<LocalGroup> grp_;
+};
+static bool local_comm_requested() { return getenv("GSI_LOCAL_COMM") != nullptr; }
+
 }  // namespace
 
 Backend* make_backend(int device_id) { return new HipBackend(device_id); }
 Comm* make_comm(Backend* be, int nranks, int rank, const void* unique_id) {
+  if (local_comm_requested()) return new LocalComm(static_cast<HipBackend*>(be), nranks, rank, unique_id);
   return new RcclComm(static_cast<HipBackend*>(be), nranks, rank, unique_id);
 }
 void comm_unique_id(void* id_out) {
+  std::memset(id_out, 0, GSI_UNIQUE_ID_BYTES);
+  if (local_comm_requested()) {         // ranks are threads of this process: any id that is unique within it
+    static std::atomic<uint64_t> counter{1};
+    const uint64_t c = counter.fetch_add(1);
+    std::memcpy(id_out, "gsi-local-comm", 14);
+    std::memcpy((char*)id_out + 16, &c, sizeof(c));
+    return;
+  }
   ncclUniqueId uid;
   RCCL_CHECK(rccl().GetUniqueId(&uid));
-  std::memset(id_out, 0, GSI_UNIQUE_ID_BYTES);
   std::memcpy(id_out, &uid, sizeof(uid));
 }
 const char* backend_name() { return "hip-gfx950"; }

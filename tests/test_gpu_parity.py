@@ -1195,3 +1195,145 @@ print("pointcov-ok")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "pointcov-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- the WHOLE multi-rank pipeline on the HIP backend, on one GPU: ranks as threads of one process, one context each, joined
+#      by the in-process communicator (GSI_LOCAL_COMM=1: RCCL refuses two ranks on one device).  Every kernel runs with real
+#      row offsets and real exchanges between the ranks' buffers: row-sharded products, the sharded LU, TSQR, the FFT
+#      operator's all-to-alls, gsi_randsvd_rows, the implicit operators' transposed products, a row-sharded xi-basis.
+#      (tests/test_distributed_gloo.py runs the same host code over the CPU reference backend.) ---------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_multirank_pipeline_on_one_gpu(gsi, world):
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, threading, traceback, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import gsi_amd as gsi
+from oracle import oracle as orc
+from helpers import gaussian_cov, powerlaw_fields, rel_sv_err
+world = int(sys.argv[1])
+ctx0 = gsi.Context(0)
+uid = ctx0.unique_id()
+res, errs = [dict() for _ in range(world)], []
+bar = threading.Barrier(world)
+box = {}
+
+def gather_rows(rank, key, loc):          # host-side all-gather of row blocks between the rank threads
+    box[(key, rank)] = np.ascontiguousarray(loc)
+    bar.wait()
+    full = np.concatenate([box[(key, r)] for r in range(world)], axis=0)
+    bar.wait()
+    return full
+
+def run(rank):
+    try:
+        ctx = ctx0 if rank == 0 else gsi.Context(0)
+        ctx.comm_init(world, rank, uid)
+        assert ctx.rank() == (rank, world)
+        out = res[rank]
+        rng = np.random.default_rng(7)
+        def my_rows(full):
+            r0, nl = ctx.shard(full.shape[0])
+            return np.asfortranarray(full[r0:r0 + nl])
+        A = gaussian_cov(23, 17, 3.0)                              # n = 391, not divisible by the world size
+        for qq in (0, 2):
+            K, p = 20, 12
+            Om = rng.standard_normal((391, K + p))
+            Z, S = gsi.randsvd(A, K, p, qq, Omega=Om, return_S=True, ctx=ctx)
+            Zr, Sr, _ = orc.randsvd_full(A, K, p, qq, Om)
+            out[f"dense_q{qq}_sv"] = rel_sv_err(S, Sr, K)
+            out[f"dense_q{qq}_xis"] = orc.xis_error_up_to_sign(Z, Zr, K)
+        fields = powerlaw_fields(rng, (21, 19), 40)                # n = 399
+        Om = rng.standard_normal((399, 24))
+        lr = gsi.LowRankCovMatrix(fields, ctx=ctx)
+        Z = gsi.randsvd(lr, 16, 8, 3, Omega=Om)                    # sharded LU + TSQR on the HIP kernels, row0 != 0
+        xr, _ = orc.getxis_fields(fields, 16, 8, 3, Om)
+        out["lowrank_xis"] = orc.xis_error_up_to_sign(Z, np.array(xr).T, 16)
+        Zrows = gsi.randsvd_rows(lr._device_operator(), 16, 8, 3, my_rows(Om))
+        out["lowrank_rows_xis"] = orc.xis_error_up_to_sign(gather_rows(rank, "lr", Zrows.to_host()), np.array(xr).T, 16)
+        Zrows.close(); lr.close()
+        Yp = rng.standard_normal((5000, 72)); Yp[3000:3100] = Yp[100:200]
+        Ls, ps = gsi.lu_L_sharded(Yp, return_pivots=True, ctx=ctx)
+        out["lu_pivots"] = 0.0 if np.array_equal(ps, orc.lu_pivots(Yp)) else 1.0
+        out["lu_L"] = float(np.abs(Ls - orc.lu_L(Yp)).max())
+        Ns, beta = [25, 18], -3.5                                  # FFTRF convention on a grid that is not a power of two
+        nf = 450
+        Af = orc.fft_powerlaw_apply(np.eye(nf), Ns, beta, fftrf=True)
+        fop = gsi.fft_powerlaw_operator(ctx, Ns, beta, fftrf=True)
+        X = rng.standard_normal((nf, 9))
+        out["fft_mul"] = float(np.abs(fop.matmul(X) - Af @ X).max())
+        out["fft_mul_t"] = float(np.abs(fop.rmatmul_t(X) - Af @ X).max())
+        K, p, qq = 20, 10, 2
+        Om = rng.standard_normal((nf, K + p))
+        Zr, Sr, _ = orc.randsvd_full(Af, K, p, qq, Om)
+        Zrows, S2 = gsi.randsvd_rows(fop, K, p, qq, my_rows(Om), return_S=True)
+        out["fft_rows_sv"] = rel_sv_err(S2, Sr, K)
+        out["fft_rows_xis"] = orc.xis_error_up_to_sign(gather_rows(rank, "fft", Zrows.to_host()), Zr, K)
+        Zrows.close(); fop.close()
+        G = gaussian_cov(19, 13, 2.5)                              # n = 247: implicit operators, transposed products sharded
+        gop = gsi.gridcov_implicit_operator(ctx, 19, 13, 2.5)
+        X = rng.standard_normal((247, 5))
+        out["implicit_mul"] = float(np.abs(gop.matmul(X) - G @ X).max())
+        out["implicit_mul_t"] = float(np.abs(gop.rmatmul_t(X) - G @ X).max())
+        gop.close()
+        Pp = rng.uniform(0.0, 20.0, size=(2, 333))
+        dd = np.sqrt(((Pp[:, :, None] - Pp[:, None, :]) ** 2).sum(axis=0)) / 5.0
+        Ap = np.exp(-dd)
+        pop = gsi.pointcov_implicit_operator(ctx, Pp, "exponential", ell=5.0)
+        X = rng.standard_normal((333, 4))
+        out["pointcov_mul"] = float(np.abs(pop.matmul(X) - Ap @ X).max())
+        out["pointcov_mul_t"] = float(np.abs(pop.rmatmul_t(X) - Ap @ X).max())
+        Om = rng.standard_normal((333, 24))
+        Z, S = gsi.randsvd(pop, 16, 8, 2, Omega=Om, return_S=True)
+        Zr, Sr, _ = orc.randsvd_full(Ap, 16, 8, 2, Om)
+        out["pointcov_sv"] = rel_sv_err(S, Sr, 16)
+        pop.close()
+        # BASELINE configs[4] on HIP kernels: pcgalsqr over a row-sharded xi-basis against the oracle
+        Np, Mp = 192, 8
+        xs = rng.standard_normal(Np); Q0 = rng.standard_normal((Mp, Np)); Qc = Q0.T @ Q0
+        truep = np.linalg.cholesky(Qc + 1e-9 * np.eye(Np)) @ rng.standard_normal(Np) + 1.0
+        forward = lambda pv: pv * xs
+        yobs = forward(truep) + 1e-4 * rng.standard_normal(Np)
+        import scipy.sparse as sp
+        Rn = 1e-8 * sp.identity(Np, format="csc")
+        Omp = rng.standard_normal((Np, Mp + 2))
+        qop = gsi.dense_operator(ctx, Qc)
+        Zp = gsi.randsvd_rows(qop, Mp, 2, 3, my_rows(Omp))
+        basis = gsi.ShardedDeviceBasis(Zp, Mp, lambda loc: gather_rows(rank, "pcga", loc))
+        X0 = np.full(Np, 1.0)
+        r0p, nlp = ctx.shard(Np)
+        s_loc = gsi.pcgalsqr(forward, X0[r0p:r0p + nlp], X0[r0p:r0p + nlp], basis, Rn, yobs, ctx=ctx)
+        s_full = gather_rows(rank, "s", s_loc)
+        s_ref = orc.pcgalsqr(forward, X0, X0, orc.getxis_dense(Qc, Mp, 2, 3, Omp), Rn, yobs)
+        out["pcgalsqr_sharded_basis"] = float(np.linalg.norm(s_full - s_ref) / np.linalg.norm(s_ref))
+        basis.close(); Zp.close(); qop.close()
+        if rank != 0:
+            ctx.close()
+    except Exception:
+        errs.append((rank, traceback.format_exc()))
+        try:
+            bar.abort()
+        except Exception:
+            pass
+
+ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+[t.start() for t in ts]; [t.join() for t in ts]
+if errs:
+    print(errs[0][1]); raise SystemExit(1)
+for r in range(world):
+    for k, v in res[r].items():
+        tol = 1e-6 if (k.endswith("xis") or k == "pcgalsqr_sharded_basis") else 1e-9
+        if k.endswith("mul") or k.endswith("mul_t") or k == "lu_L":
+            tol = 1e-10
+        assert v < tol, (r, k, v)
+    assert res[r].keys() == res[0].keys()
+print("multirank-one-gpu-ok", len(res[0]))
+'''
+    env = dict(os.environ)
+    env["GSI_LOCAL_COMM"] = "1"
+    r = subprocess.run([sys.executable, "-c", code, str(world)], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "multirank-one-gpu-ok" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
