@@ -91,16 +91,27 @@ def fft_pair_bytes(Ns, Ms):
     return 16.0 * units + 8.0 * M
 
 
-def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234, keep=None):
+def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234, keep=None, rows=False):
     """warmup + timed randsvd steps on device-resident inputs; returns (elapsed_s, phases, counters)."""
     l = K + p
-    Omega = gsi.DeviceMatrix(ctx, n, l).randn(seed)
-    Z = gsi.DeviceMatrix(ctx, n, l)
-    S = gsi.DeviceMatrix(ctx, l, 1)
     lib = ctx.lib
+    rank, world = ctx.rank()
+    if rows:
+        # several ranks: Omega and Z as ROW SHARDS (gsi_randsvd_rows) -- no GPU ever holds an n x l panel of them, and the
+        # result is not all-gathered (what a multi-GPU consumer wants: a row-sharded xi-basis)
+        _, nloc = ctx.shard(n)
+        Omega = gsi.DeviceMatrix(ctx, nloc, l).randn(seed + 7919 * rank)
+        Z = gsi.DeviceMatrix(ctx, nloc, l)
+    else:
+        Omega = gsi.DeviceMatrix(ctx, n, l).randn(seed)
+        Z = gsi.DeviceMatrix(ctx, n, l)
+    S = gsi.DeviceMatrix(ctx, l, 1)
 
     def step():
-        gsi._lib.check(lib.gsi_randsvd_dev(ctx.h, op.h, Omega.h, K, p, q, Z.h, S.h), lib)
+        if rows:
+            gsi._lib.check(lib.gsi_randsvd_rows(ctx.h, op.h, Omega.h, K, p, q, Z.h, S.h), lib)
+        else:
+            gsi._lib.check(lib.gsi_randsvd_dev(ctx.h, op.h, Omega.h, K, p, q, Z.h, S.h), lib)
 
     for _ in range(warmup):
         step()
@@ -332,7 +343,7 @@ def main():
     op = gsi.lowrank_synthetic_operator(ctx, n, Ns, seed=0, decay=args.decay)      # samples generated + centred in HBM
     full_parity = world == 1 and not args.no_cpu_baseline and not args.no_full_parity
     keep = {} if full_parity else None
-    elapsed, phases, Sv = run_steps(gsi, ctx, op, n, K, p, q, args.steps, args.warmup, barrier, keep=keep)
+    elapsed, phases, Sv = run_steps(gsi, ctx, op, n, K, p, q, args.steps, args.warmup, barrier, keep=keep, rows=use_dist)
     elapsed = max_over_ranks(elapsed)
     counters = ctx.counters()
     dev_bytes = ctx.device_bytes()
@@ -412,7 +423,7 @@ def main():
                                    f"(BASELINE.json metric config; SURVEY.md 8d C4-ii)"
                                    + ("" if world == 1 else (", same problem row-sharded" if args.scaling == "strong"
                                                               else ", 1e6 rows per GPU")),
-                       "n": n, "samples": Ns, "K": K, "p": p, "q": q, "parallelism": f"row-shard x{world}",
+                       "n": n, "samples": Ns, "K": K, "p": p, "q": q, "parallelism": f"row-shard x{world}" + (" (Omega and Z as row shards: gsi_randsvd_rows)" if use_dist else ""),
                        "operator_bytes_per_gpu": 8.0 * nloc * Ns, "device_bytes_in_use": dev_bytes},
             "roofline": roofline,
             "phases_hbm": phases_hbm,
