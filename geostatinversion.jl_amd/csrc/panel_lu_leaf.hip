@@ -625,8 +625,7 @@ __global__ __launch_bounds__(256) void lu_u12_kernel(const double* __restrict__ 
 // Workgroup = 4 waves x 32 rows; column chunk of <= RK_CHUNK columns per blockIdx.y (its U12 slice sits in LDS).
 // MFMA operands swapped like the big contraction kernel: lane (jl = lane & 15, kk = lane >> 4) holds, for C row
 // jl (+16 h), the columns kk + 4 reg of a 16-column tile.
-constexpr int RK_CHUNK = 128;
-template <int K, int DEPTH>
+template <int K, int DEPTH, int RK_CHUNK>
 __global__ __launch_bounds__(256) void lu_rankk_kernel(double* __restrict__ Y, int64_t ld, int64_t m, int64_t r_begin,
                                                        int64_t jb, int64_t c0, int64_t t,
                                                        const double* __restrict__ U12) {
@@ -699,18 +698,26 @@ __global__ __launch_bounds__(256) void lu_rankk_kernel(double* __restrict__ Y, i
   }
 }
 
+template <int K, int DEPTH, int CHUNK>
+static void launch_rankk_v(hipStream_t st, unsigned grid, double* Y, int64_t ld, int64_t m, int64_t r_begin, int64_t jb,
+                           int64_t c0, int64_t t, const double* U12) {
+  constexpr size_t shmem = (size_t)CHUNK * (K + 2) * sizeof(double);
+  static std::atomic<uint64_t> attr_mask{0};
+  if (first_use_on_this_device(attr_mask))
+    (void)hipFuncSetAttribute((const void*)lu_rankk_kernel<K, DEPTH, CHUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL((lu_rankk_kernel<K, DEPTH, CHUNK>), dim3(grid), dim3(256), shmem, st, Y, ld, m, r_begin, jb, c0, t, U12);
+}
+// U12 columns staged per pass (its LDS image bounds the workgroups per CU: 128 columns = 67 KB = 2 workgroups, 64 = 4) and C
+// tiles in flight per wave: A/B knobs GSI_LU_RK_CHUNK (64 | 128), GSI_LU_RK_DEPTH (1 | 2)
 template <int K>
 static void launch_rankk(hipStream_t st, unsigned grid, double* Y, int64_t ld, int64_t m, int64_t r_begin, int64_t jb,
                          int64_t c0, int64_t t, const double* U12) {
-  constexpr size_t shmem = (size_t)RK_CHUNK * (K + 2) * sizeof(double);
-  static const int depth = getenv("GSI_LU_RK_DEPTH") ? atoi(getenv("GSI_LU_RK_DEPTH")) : 1;   // A/B knob: C tiles in flight per wave
-  static std::atomic<uint64_t> attr_mask{0};
-  if (first_use_on_this_device(attr_mask)) {
-    (void)hipFuncSetAttribute((const void*)lu_rankk_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    (void)hipFuncSetAttribute((const void*)lu_rankk_kernel<K, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  }
-  if (depth == 2) hipLaunchKernelGGL((lu_rankk_kernel<K, 2>), dim3(grid), dim3(256), shmem, st, Y, ld, m, r_begin, jb, c0, t, U12);
-  else hipLaunchKernelGGL((lu_rankk_kernel<K, 1>), dim3(grid), dim3(256), shmem, st, Y, ld, m, r_begin, jb, c0, t, U12);
+  static const int depth = getenv("GSI_LU_RK_DEPTH") ? atoi(getenv("GSI_LU_RK_DEPTH")) : 1;
+  static const int chunk = getenv("GSI_LU_RK_CHUNK") ? atoi(getenv("GSI_LU_RK_CHUNK")) : 128;
+  if (chunk == 64 && depth == 2) launch_rankk_v<K, 2, 64>(st, grid, Y, ld, m, r_begin, jb, c0, t, U12);
+  else if (chunk == 64) launch_rankk_v<K, 1, 64>(st, grid, Y, ld, m, r_begin, jb, c0, t, U12);
+  else if (depth == 2) launch_rankk_v<K, 2, 128>(st, grid, Y, ld, m, r_begin, jb, c0, t, U12);
+  else launch_rankk_v<K, 1, 128>(st, grid, Y, ld, m, r_begin, jb, c0, t, U12);
 }
 
 // top l x l: unit diagonal, zero strict upper triangle (what Julia's F.L returns)
