@@ -449,15 +449,24 @@ class HipBackend : public Backend {
   void lus_candidate(const double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l, int64_t j, double* rec) override {
     bind();
     LusWs w = lus_ws(mloc, l);
-    hipk::lus_candidate(st_, Yloc, ld, mloc, row0, l, j, rec, w.pval, w.pidx);
+    // the previous pivot step's apply kernel may already have left this column's per-workgroup partials (same panel, same rows)
+    const bool ready = (lus_part_col_ == j && lus_part_Y_ == Yloc && lus_part_mloc_ == mloc);
+    lus_part_col_ = -1;
+    hipk::lus_candidate(st_, Yloc, ld, mloc, row0, l, j, rec, w.pval, w.pidx, ready);
     check_launch("lus_candidate");
   }
   void lus_apply(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t m, int64_t l, int64_t j0, int s, int w,
                  const double* recs, int nranks) override {
     bind();
     LusWs ws = lus_ws(mloc, l);
-    hipk::lus_apply(st_, Yloc, ld, mloc, row0, m, l, j0, s, w, recs, nranks, ws.ipiv, flags_ + 0);
+    static const bool fuse = (getenv("GSI_LUS_NO_FUSE") == nullptr);      // A/B knob
+    const bool next = fuse && (s + 1 < w) && mloc > 0;
+    hipk::lus_apply(st_, Yloc, ld, mloc, row0, m, l, j0, s, w, recs, nranks, ws.ipiv, flags_ + 0, next ? ws.pval : nullptr,
+                    next ? ws.pidx : nullptr);
     check_launch("lus_apply");
+    lus_part_col_ = next ? j0 + s + 1 : -1;
+    lus_part_Y_ = Yloc;
+    lus_part_mloc_ = mloc;
   }
   void lus_u12_block(const double* Yloc, int64_t ld, int64_t row0, int64_t jb, int b, int64_t c0, int64_t c1,
                      double* U12) override {
@@ -902,6 +911,8 @@ class HipBackend : public Backend {
   std::map<std::pair<int64_t, bool>, int> skip_tier1_by_height_;
   std::map<int, int> lu2_resident_;   // (bs, rpt) -> resident workgroups per CU of that leaf instantiation
   bool lu2_lost_ = false, lu2_retry_ = false;
+  int64_t lus_part_col_ = -1, lus_part_mloc_ = 0;     // sharded LU: column whose arg-max partials the last apply kernel left
+  const double* lus_part_Y_ = nullptr;
 };
 
 // ---- RCCL, bound lazily so a single-GPU user never needs librccl to resolve -----------------

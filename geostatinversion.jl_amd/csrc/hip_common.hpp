@@ -95,9 +95,9 @@ void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu
 // row-sharded form (the exchange between ranks is pipeline.cpp's): primitives on this rank's rows [row0, row0 + mloc)
 int lus_grid(int64_t mloc);
 void lus_candidate(hipStream_t st, const double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j, double* rec,
-                   double* pval, int64_t* pidx);
+                   double* pval, int64_t* pidx, bool partials_ready);
 void lus_apply(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l, int64_t j0, int s, int w,
-               const double* recs, int nranks, int32_t* ipiv, int32_t* info);
+               const double* recs, int nranks, int32_t* ipiv, int32_t* info, double* next_pval, int64_t* next_pidx);
 void lus_u12_leaf(hipStream_t st, const double* Y, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w, double* U12);
 void lus_pending(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t jb, int64_t j0, int w,
                  const double* U12);

@@ -913,7 +913,12 @@ __global__ __launch_bounds__(256) void lus_cand_final_kernel(const double* __res
 __global__ __launch_bounds__(256) void lus_apply_kernel(double* __restrict__ Y, int64_t ld, int64_t mloc, int64_t row0,
                                                         int64_t m, int64_t l, int64_t j0, int s, int w,
                                                         const double* __restrict__ recs, int nranks,
-                                                        int32_t* __restrict__ ipiv, int32_t* __restrict__ info) {
+                                                        int32_t* __restrict__ ipiv, int32_t* __restrict__ info,
+                                                        double* __restrict__ pval, int64_t* __restrict__ pidx) {
+  // pval / pidx != null: this launch also leaves the per-workgroup arg-max partials of the NEXT leaf column (s + 1, over the
+  // values it has just updated) where lus_cand_final_kernel expects them -- one launch less per pivot step
+  __shared__ double s_v4[4];
+  __shared__ int32_t s_i4[4];
   __shared__ double s_u[LW], s_old[LW];
   __shared__ int32_t s_r;
   __shared__ int s_gw, s_go;
@@ -961,6 +966,8 @@ __global__ __launch_bounds__(256) void lus_apply_kernel(double* __restrict__ Y, 
       }
     }
   }
+  double nbest = -1.0;
+  int32_t nbesti = -1;
   for (int64_t li = (int64_t)blockIdx.x * 256 + threadIdx.x; li < mloc; li += (int64_t)gridDim.x * 256) {
     const int64_t gi = row0 + li;
     if (gi <= j) continue;
@@ -978,6 +985,24 @@ __global__ __launch_bounds__(256) void lus_apply_kernel(double* __restrict__ Y, 
 #pragma unroll
     for (int k = 0; k < LW; ++k)
       if (k < w && (k >= s || moved)) row[k * ld] = x[k];
+    if (pval != nullptr) {                        // candidate of column s + 1: ascending rows per thread, the first maximum stays
+      double nv = 0.0;
+#pragma unroll
+      for (int k = 0; k < LW; ++k)
+        if (k == s + 1) nv = fabs(x[k]);
+      if (nv > nbest) { nbest = nv; nbesti = (int32_t)gi; }
+    }
+  }
+  if (pval != nullptr) {                          // the reduction of lus_cand_partial_kernel, same order
+    wave_argmax(nbest, nbesti);
+    if ((threadIdx.x & 63) == 0) { s_v4[threadIdx.x >> 6] = nbest; s_i4[threadIdx.x >> 6] = nbesti; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      double v = (threadIdx.x < 4) ? s_v4[threadIdx.x] : -1.0;
+      int32_t i = (threadIdx.x < 4) ? s_i4[threadIdx.x] : -1;
+      wave_argmax8(v, i);
+      if (threadIdx.x == 0) { pval[blockIdx.x] = v; pidx[blockIdx.x] = i; }
+    }
   }
 }
 
@@ -1039,15 +1064,16 @@ int lus_grid(int64_t mloc) {
   return (int)g;
 }
 void lus_candidate(hipStream_t st, const double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j, double* rec,
-                   double* pval, int64_t* pidx) {
+                   double* pval, int64_t* pidx, bool partials_ready) {
   const int g = lus_grid(mloc);
-  hipLaunchKernelGGL(lus_cand_partial_kernel, dim3(g), dim3(256), 0, st, Y, ld, mloc, row0, j, pval, pidx);
+  if (!partials_ready) hipLaunchKernelGGL(lus_cand_partial_kernel, dim3(g), dim3(256), 0, st, Y, ld, mloc, row0, j, pval, pidx);
   hipLaunchKernelGGL(lus_cand_final_kernel, dim3(1), dim3(256), 0, st, Y, ld, mloc, row0, l, j, g, pval, pidx, rec);
 }
+// next_pval / next_pidx (may be null): leave the partials of leaf column s + 1 for the next lus_candidate
 void lus_apply(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l, int64_t j0, int s, int w,
-               const double* recs, int nranks, int32_t* ipiv, int32_t* info) {
+               const double* recs, int nranks, int32_t* ipiv, int32_t* info, double* next_pval, int64_t* next_pidx) {
   hipLaunchKernelGGL(lus_apply_kernel, dim3(lus_grid(mloc)), dim3(256), 0, st, Y, ld, mloc, row0, m, l, j0, s, w, recs, nranks,
-                     ipiv, info);
+                     ipiv, info, next_pval, next_pidx);
 }
 void lus_u12_leaf(hipStream_t st, const double* Y, int64_t ld, int64_t row0, int64_t jb, int64_t j0, int w, double* U12) {
   hipLaunchKernelGGL(lus_u12_leaf_kernel, dim3(1), dim3(512), 0, st, Y, ld, jb - row0, (int)(j0 - jb), j0, w, U12);

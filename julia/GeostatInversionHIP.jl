@@ -457,6 +457,22 @@ function getxis_device(A::DeviceOperator, numxis::Int, p::Int, q::Int=3, seed=no
 	return DeviceBasis(Z, numxis; precision=precision)
 end
 
+"`randsvd` with ROW-SHARDED panels over the ranks of `A.c`'s communicator (`gsi_randsvd_rows`): `Omega_rows` = this rank's rows
+of Omega (`nloc x (K+p)`, the block layout `row0 = rank*ceil(n/nranks)`); returns this rank's rows of Z as a `DeviceMatrix`
+-- nothing n x (K+p) is gathered for LowRankCovMatrix / FFT operators -- and S.  `DeviceBasis(Zrows, K)` over the result is a
+row-sharded xi-basis: `paramstorun` / `update` then act on this rank's rows of s and X."
+function randsvd_rows(A::DeviceOperator, Omega_rows::Matrix{Float64}, K::Int, p::Int, q::Int)
+	Om = DeviceMatrix(Omega_rows; c=A.c)
+	Z = DeviceMatrix(size(Omega_rows, 1), K + p; c=A.c)
+	S = DeviceMatrix(K + p, 1; c=A.c)
+	check(ccall((:gsi_randsvd_rows, libgsi), Cint,
+		(Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+		A.c.h, A.h, Om.h, K, p, q, Z.h, S.h))
+	Sh = Matrix{Float64}(undef, K + p, 1)
+	check(ccall((:gsi_mat_download, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64), A.c.h, S.h, Sh, K + p))
+	return Z, vec(Sh)
+end
+
 # ---- pcgadirect / pcgalsqr with a device-resident basis (same positional / keyword shape as direct.jl:21, lsqr.jl:20) ----
 function iterationhead(forwardmodel::Function, s::Vector, X::Vector, xis::DeviceBasis, delta)
 	K = length(xis)
