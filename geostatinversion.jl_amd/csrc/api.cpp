@@ -73,7 +73,9 @@ void with_retry(Context& c, F&& f) {
   try {
     f();
   } catch (const Error&) {
-    if (!c.be->retryable_failure() || getenv("GSI_NO_RETRY") != nullptr) throw;   // GSI_NO_RETRY: tests of the error path
+    // GSI_NO_RETRY: tests of the error path.  With a communicator the ranks must agree on what runs next: no silent re-run
+    // (every rank saw the same time-out and has switched paths; the caller repeats the collective call)
+    if (!c.be->retryable_failure() || c.comm || getenv("GSI_NO_RETRY") != nullptr) throw;
     f();
   }
 }

@@ -92,6 +92,16 @@ class Backend {
                          const double* U12) = 0;
   virtual void lus_finish(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l) = 0;
   virtual void lus_pivots(int32_t* host, int64_t l) = 0;      // the pivot rows of the last sharded factorization
+  // ---- the sharded factorization with ONE persistent launch per 8-column leaf and rank: the 8 pivot exchanges of a leaf
+  //      run inside the kernels, through records every rank writes into every rank's peer-mapped buffer (no collective per
+  //      pivot step).  lus_mr_begin: can this backend do it over this communicator for an m x l panel (sets up and exchanges
+  //      the record buffers on first use)?  false: pipeline.cpp falls back to the per-step form above.  U12 (kp x 8) of the
+  //      leaf's pending update comes from lus_u12_leaf + all-reduce as before; lus_swap_pack / _apply move the rows the
+  //      leaf's pivots exchange in the columns OUTSIDE the leaf (table: 16 x l doubles, all-reduced in between).
+  virtual bool lus_mr_begin(class Comm* comm, int64_t m, int64_t l) { (void)comm; (void)m; (void)l; return false; }
+  virtual void lus_leaf_mr(double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, const double*) {}
+  virtual void lus_swap_pack(const double*, int64_t, int64_t, int64_t, int64_t, int64_t, int, double*) {}
+  virtual void lus_swap_apply(double*, int64_t, int64_t, int64_t, int64_t, int64_t, int, const double*) {}
   // Y (m x l) <- thin Q; R (l x l, ld l) <- upper triangular factor if R != null.
   // replicated: the same panel is factored by every rank and the results must be bit-identical everywhere
   // (stacked R factors of the TSQR, gathered panels): the backend must then not let anything rank-local
@@ -193,6 +203,9 @@ class Comm {
   virtual void reduce_scatter_sum(const double* send, double* recv, size_t count) = 0;
   // send holds nranks blocks of `count` doubles, block g for rank g; recv block s = what rank s sent to this rank
   virtual void alltoall(const double* send, double* recv, size_t count) = 0;
+  // every rank hands in a device buffer; all[g] = rank g's buffer as THIS rank can address it (same process: the pointer
+  // itself; other processes: an IPC mapping).  false: not supported by this communicator.  Collective.
+  virtual bool share_pointers(void* mine, size_t bytes, void** all) { (void)mine; (void)bytes; (void)all; return false; }
 };
 
 // Provided by whichever backend is linked into the library.

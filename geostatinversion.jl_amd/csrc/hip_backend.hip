@@ -83,6 +83,7 @@ class HipBackend : public Backend {
     for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     hipFree(flags_);
     hipFree(scal_);
+    if (mr_recs_) hipFree(mr_recs_);
     if (st2_) {
       hipStreamSynchronize(st2_);
       for (int i = 0; i < 2; ++i) { hipEventDestroy(ev_gen_[i]); hipEventDestroy(ev_used_[i]); }
@@ -484,6 +485,62 @@ class HipBackend : public Backend {
     bind();
     hipk::lus_finish(st_, Yloc, ld, mloc, row0, l);
   }
+  bool lus_mr_begin(Comm* comm, int64_t m, int64_t l) override {
+    bind();
+    static const bool off = (getenv("GSI_LU_NO_MR") != nullptr);
+    if (off || mr_disabled_ || comm == nullptr || comm->nranks > hipk::LU2_MAX_RANKS || m >= ((int64_t)1 << 28)) return false;
+    const int G = comm->nranks;
+    const int64_t pad = (m + G - 1) / G;
+    hipk::Lu2MrWork w{};
+    if (!hipk::lu2_mr_config(pad, G, ncus_, &w.bs, &w.rpt, &w.grid)) return false;
+    const int key = 1000000 + w.bs * 16 + w.rpt;
+    auto it = lu2_resident_.find(key);
+    if (it == lu2_resident_.end()) it = lu2_resident_.emplace(key, hipk::lu2_mr_resident_per_cu(w.bs, w.rpt)).first;
+    if ((int64_t)it->second * ncus_ < w.grid) return false;
+    if (mr_comm_ != comm) {                                 // first use over this communicator: record buffer, exchanged once
+      if (mr_recs_ == nullptr) {
+        const size_t bytes = sizeof(unsigned long long) * hipk::lu2_mr_record_granules(1, 256);   // room for 256 records
+        if (hipExtMallocWithFlags((void**)&mr_recs_, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+          (void)hipGetLastError();
+          HIP_CHECK(hipMalloc((void**)&mr_recs_, bytes));
+        }
+        HIP_CHECK(hipMemsetAsync(mr_recs_, 0, bytes, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        mr_epoch_ = 0;
+      }
+      void* all[hipk::LU2_MAX_RANKS] = {nullptr};
+      if (!comm->share_pointers(mr_recs_, 0, all)) { mr_disabled_ = true; return false; }
+      for (int g = 0; g < G; ++g) mr_peer_[g] = (unsigned long long*)all[g];
+      mr_comm_ = comm;
+    }
+    (void)l;
+    w.rank = comm->rank; w.nranks = G;
+    for (int g = 0; g < G; ++g) w.peer[g] = mr_peer_[g];
+    w.info = flags_ + 0;
+    if (const char* e = getenv("GSI_LU_POLL_LIMIT")) w.poll_limit = atoi(e);
+    mr_work_ = w;
+    return true;
+  }
+  void lus_leaf_mr(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t m, int64_t l, int64_t jb, int64_t j0, int w,
+                   const double* U12) override {
+    bind();
+    mr_work_.ipiv = lus_ws(mloc, l).ipiv;
+    hipk::lu2_leaf_mr(st_, mr_work_, Yloc, ld, mloc, row0, m, l, jb, j0, w, U12, mr_epoch_);
+    mr_epoch_ += (uint32_t)hipk::LU2_LEAF;
+    check_launch("lu2_leaf_mr");
+  }
+  void lus_swap_pack(const double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l, int64_t j0, int w,
+                     double* table) override {
+    bind();
+    hipk::lus_swap_pack(st_, Yloc, ld, mloc, row0, l, j0, w, lus_ws(mloc, l).ipiv, table);
+    check_launch("lus_swap_pack");
+  }
+  void lus_swap_apply(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l, int64_t j0, int w,
+                      const double* table) override {
+    bind();
+    if (mloc > 0) hipk::lus_swap_apply(st_, Yloc, ld, mloc, row0, l, j0, w, lus_ws(mloc, l).ipiv, table);
+    check_launch("lus_swap_apply");
+  }
   void lus_pivots(int32_t* host, int64_t l) override {
     bind();
     LusWs w = lus_ws(1, l);
@@ -785,6 +842,7 @@ class HipBackend : public Backend {
         // sweeps (no spin-waits between workgroups) from now on, and the entry point may be re-run on its inputs.
         lu2_lost_ = true;
         lu2_retry_ = true;
+        mr_disabled_ = true;
         if (msg) *msg = "lu(): the pivot exchange between workgroups timed out (GPU shared with another job?); "
                         "this context now uses the per-column sweeps";
         return GSI_ERR_INTERNAL;
@@ -911,6 +969,13 @@ class HipBackend : public Backend {
   std::map<std::pair<int64_t, bool>, int> skip_tier1_by_height_;
   std::map<int, int> lu2_resident_;   // (bs, rpt) -> resident workgroups per CU of that leaf instantiation
   bool lu2_lost_ = false, lu2_retry_ = false;
+  // multi-rank persistent leaves: this rank's record buffer, the peers' (as this rank addresses them), the running epoch
+  unsigned long long* mr_recs_ = nullptr;
+  unsigned long long* mr_peer_[hipk::LU2_MAX_RANKS] = {nullptr};
+  Comm* mr_comm_ = nullptr;
+  uint32_t mr_epoch_ = 0;
+  bool mr_disabled_ = false;
+  hipk::Lu2MrWork mr_work_{};
   int64_t lus_part_col_ = -1, lus_part_mloc_ = 0;     // sharded LU: column whose arg-max partials the last apply kernel left
   const double* lus_part_Y_ = nullptr;
 };
@@ -1003,6 +1068,33 @@ class RcclComm : public Comm {
     }
     RCCL_CHECK(r.GroupEnd());
   }
+  // one process per GPU: IPC handles travel through an all-gather, every rank maps its peers' buffers.  NOT exercised on
+  // the one-GPU build box (RCCL refuses two ranks on one device): opt-in, GSI_LU_PEER=1.
+  bool share_pointers(void* mine, size_t bytes, void** all) override {
+    (void)bytes;
+    static const bool on = (getenv("GSI_LU_PEER") != nullptr);
+    if (!on) return false;
+    be_->bind();
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hipIpcMemHandle_t h;
+    HIP_CHECK(hipIpcGetMemHandle(&h, mine));
+    double* send = be_->alloc(8);
+    double* recv = be_->alloc((size_t)8 * nranks);
+    HIP_CHECK(hipMemcpyAsync(send, &h, 64, hipMemcpyHostToDevice, be_->stream()));
+    allgather(send, recv, 8);
+    std::vector<hipIpcMemHandle_t> hs((size_t)nranks);
+    HIP_CHECK(hipMemcpyAsync(hs.data(), recv, (size_t)64 * nranks, hipMemcpyDeviceToHost, be_->stream()));
+    HIP_CHECK(hipStreamSynchronize(be_->stream()));
+    be_->release(send);
+    be_->release(recv);
+    for (int g = 0; g < nranks; ++g) {
+      if (g == rank) { all[g] = mine; continue; }
+      void* p = nullptr;
+      HIP_CHECK(hipIpcOpenMemHandle(&p, hs[(size_t)g], hipIpcMemLazyEnablePeerAccess));
+      all[g] = p;
+    }
+    return true;
+  }
 
  private:
   HipBackend* be_;
@@ -1086,6 +1178,12 @@ class LocalComm : public Comm {
       HIP_CHECK(hipMemcpyAsync(recv + (size_t)g * count, grp_->src[(size_t)g] + (size_t)rank * count, count * sizeof(double),
                                hipMemcpyDeviceToDevice, be_->stream()));
     finish();
+  }
+  bool share_pointers(void* mine, size_t, void** all) override {       // one process: the pointers themselves
+    publish((const double*)mine);
+    for (int g = 0; g < nranks; ++g) all[g] = const_cast<double*>(grp_->src[(size_t)g]);
+    finish();
+    return true;
   }
 
  private:

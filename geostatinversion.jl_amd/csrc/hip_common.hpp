@@ -88,6 +88,24 @@ struct Lu2Work {
 };
 // workgroups of the (bs, rpt) leaf kernel that fit one CU (occupancy query); 0 if the query fails
 int lu2_resident_per_cu(int bs, int rpt);
+// the same leaf kernel across RANKS (one launch per rank, records written into every rank's peer-mapped buffer)
+constexpr int LU2_MAX_RANKS = 16;
+struct Lu2MrWork {
+  unsigned long long* peer[LU2_MAX_RANKS];   // every rank's record buffer: [2][nranks * grid][LU2_REC_GRANULES]
+  int32_t* ipiv;                             // [l] this rank's copy of the pivot rows (identical on every rank)
+  int32_t* info;
+  int rank, nranks, bs, rpt, grid;
+  int poll_limit = 0;
+};
+bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid);
+int lu2_mr_resident_per_cu(int bs, int rpt);
+size_t lu2_mr_record_granules(int nranks, int grid);
+void lu2_leaf_mr(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l,
+                 int64_t jb, int64_t j0, int wd, const double* us, uint32_t epoch_base);
+void lus_swap_pack(hipStream_t st, const double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j0, int w,
+                   const int32_t* ipiv, double* table);
+void lus_swap_apply(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j0, int w,
+                    const int32_t* ipiv, const double* table);
 // launch geometry for an m-row panel on a chip with `ncus` CUs; false: the panel does not fit the register file
 bool lu2_config(int64_t m, int ncus, int* bs, int* rpt, int* grid);
 void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu2Work& w);

@@ -98,6 +98,13 @@ __device__ inline void wave_argmax8(double& v, int32_t& i) {
   i = (int32_t)__builtin_amdgcn_readlane((int)key, 7);
 }
 
+// a record granule as a poller reads it: agent scope within one GPU, system scope when peers on other GPUs wrote it
+template <bool MR>
+__device__ inline unsigned long long poll_granule(const unsigned long long* p) {
+  if constexpr (MR) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #ifdef GSI_LU_TRACE
 // debug build only (hipcc -DGSI_LU_TRACE): 100 MHz wall-clock stamps of the phases of every pivot step of the kp = 0
 // leaves, for 4 workgroups; dumped by lu2_L to $GSI_LU_TRACE
@@ -135,12 +142,23 @@ __device__ unsigned long long g_lu_trace[4 * 8 * 8];
 // per step and measured slower.)
 // A leaf narrower than 8 columns (the panel's last) still runs 8 steps; steps s >= w see zero columns and are
 // gated: no pivot is recorded, nothing is interchanged, the update multiplies zeros.
-template <int BS, int R>
+// MR (several ranks, one launch per rank): this rank holds rows [gbase, gbase + m) of the mtot-row panel in Y
+// (local indices), its workgroups are records [rank * G, (rank + 1) * G) of the exchange, and every record is written
+// into EVERY rank's record buffer (peer-mapped memory, system-scope stores; pollers read their own memory only).  Rank 0
+// owns the diagonal block.  U12 of the pending update comes ready-made (rank 0 solved it, the host sequenced an
+// all-reduce); the interchange of the columns outside the leaf is done after the launch (lus_swaps_*).
+struct LuMrArgs {
+  int rank, nranks;
+  int32_t gbase, mtot;
+  const double* us;                          // kp x LW, [c * LW + k]
+  unsigned long long* peer[LU2_MAX_RANKS];   // every rank's record buffer (peer[rank] == recs)
+};
+template <int BS, int R, bool MR>
 __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int64_t ld, int32_t m, int32_t l,
                                                      int32_t jb, int32_t j0, int w, unsigned long long* __restrict__ recs,
                                                      uint32_t epoch_base, int32_t* __restrict__ ipiv,
                                                      int32_t* __restrict__ info, int onehop, int poll_limit,
-                                                     uint32_t mute_epoch) {
+                                                     uint32_t mute_epoch, LuMrArgs mr) {
   constexpr int NW = BS / 64;
   constexpr int LPR = BS / 256;               // leader: consumer lanes per record (G <= 256 records)
   constexpr int GPL = (2 * (2 + LW)) / LPR;   // leader: granules per consumer lane
@@ -159,7 +177,12 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
   __shared__ int32_t c_slot[NW];
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.x, G = gridDim.x;
+  const int g = blockIdx.x;
+  const int Gl = gridDim.x;                                 // this rank's workgroups
+  const int G = MR ? Gl * mr.nranks : Gl;                   // records in the exchange
+  const int gslot = MR ? mr.rank * Gl + g : g;              // this workgroup's record
+  const int32_t gbase = MR ? mr.gbase : 0;                  // global index of local row 0
+  const int32_t mtot = MR ? mr.mtot : m;
   const int kp = j0 - jb;
   // a launch that follows a timed-out one (info < 0, same stream) drains without polling: one time-out per factorization
   if (tid == 0) s_abort = (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) ? 1 : 0;
@@ -168,8 +191,10 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
   // address stays live in VGPRs between the load at the top and the store at the bottom (m < 2^28 rows)
   auto colbase = [&](int32_t c) -> char* { return reinterpret_cast<char*>(Y + (int64_t)c * ld); };
   auto elem = [&](char* base, int32_t i) -> double* { return reinterpret_cast<double*>(base + (uint32_t)i * 8u); };
-  const int32_t row0 = j0 + LW + g * (R * BS) + tid;       // regular rows: row0 + rr BS
-  const bool isdiag = (g == 0 && tid < LW);                // holds row j0 + tid of the diagonal block in d
+  // regular rows: local row0 + rr BS (global gbase + that); on a rank > 0 every local row is below the diagonal block
+  const int32_t row0 = ((gbase == 0) ? j0 + LW : 0) + g * (R * BS) + tid;
+  const int32_t grow0 = gbase + row0;
+  const bool isdiag = (g == 0 && tid < LW && gbase == 0);  // holds row j0 + tid of the diagonal block in d
   const int32_t drow = j0 + tid;
   double a[R][LW];
   double d[LW];
@@ -186,6 +211,10 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
 
   // ---- pending update of the block's earlier columns: a -= L[:, jb:j0] * (L11^-1 A12) ----------------------
   if (kp > 0) {
+    if constexpr (MR) {
+      for (int e = tid; e < kp * LW; e += BS) Us[e] = mr.us[e];
+      __syncthreads();
+    } else {
     {
       // all of a thread's elements of the kp x kp block are requested before the first one is used: as a plain loop this
       // was one HBM / L2 round trip per iteration (up to KPMAX^2 / BS of them) at the head of every leaf
@@ -214,6 +243,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
       if (lane < kp) Us[lane * LW + v] = x;
     }
     __syncthreads();
+    }
     for (int c = 0; c < kp; c += 2) {              // kp is a multiple of the leaf width
       double lv[2][R];
 #pragma unroll
@@ -249,8 +279,8 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
   // c % G, thread c / G.  Pipelined one step behind: the two loads of step s are issued when its pivot is known and
   // stored swapped at step s + 1, so their latency hides behind the next exchange (same thread, program order:
   // a later load of the same element sees the earlier store).
-  const int32_t swc = g + G * tid;
-  const bool has_col = swc < l && !(swc >= j0 && swc < j0 + w);
+  const int32_t swc = g + Gl * tid;
+  const bool has_col = !MR && swc < l && !(swc >= j0 && swc < j0 + w);
   double* const swcol = Y + (int64_t)(has_col ? swc : 0) * ld;
   bool pend = false;
   double pa0 = 0.0, pa1 = 0.0;
@@ -262,7 +292,8 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
     const bool live = s < w;
     const int32_t j = j0 + s;
     const uint32_t epoch = epoch_base + (uint32_t)s + 1u;
-    unsigned long long* rec_set = recs + (size_t)(epoch & 1u) * (size_t)G * REC;
+    const size_t set_off = (size_t)(epoch & 1u) * (size_t)G * REC;
+    unsigned long long* rec_set = recs + set_off;
     LU_STAMP(0);
     // (a) this thread's, this wave's, this workgroup's candidate for column s; lowest rows first, strict >
     double best = -1.0;
@@ -271,7 +302,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
       const double av = fabs(a[rr][s]);
-      if (av > best) { best = av; besti = row0 + rr * BS; }
+      if (av > best && (!MR || row0 + rr * BS < m)) { best = av; besti = grow0 + rr * BS; }   // MR: rows beyond the shard are no candidates
     }
     double wv = best;
     int32_t wi = besti;
@@ -284,7 +315,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
       }
 #pragma unroll
       for (int rr = 0; rr < R; ++rr)
-        if (row0 + rr * BS == besti) {
+        if (grow0 + rr * BS == besti) {
 #pragma unroll
           for (int k = 0; k < LW; ++k) s_cand[wave][k] = a[rr][k];
         }
@@ -307,16 +338,22 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
       const int unit = lane >> 1;
       // mute_epoch != 0 (tests only): the last workgroup stays silent at that step, as a workgroup that never got a CU
       // would -- everyone else runs out of polls and the launch ends with info = -1
-      const bool muted = (mute_epoch != 0u && epoch == mute_epoch && g == G - 1);
-      if (!muted && (unit < 2 + LW || (g == 0 && unit < 2 + 2 * LW))) {
+      const bool muted = (mute_epoch != 0u && epoch == mute_epoch && gslot == G - 1);
+      if (!muted && (unit < 2 + LW || (gslot == 0 && unit < 2 + 2 * LW))) {
         unsigned long long bits;
         if (unit == 0) bits = (unsigned long long)__double_as_longlong(pv);
         else if (unit == 1) bits = (unsigned long long)(long long)pi;
         else if (unit < 2 + LW) bits = (unsigned long long)__double_as_longlong(s_cand[ww][unit - 2]);
         else bits = (unsigned long long)__double_as_longlong(s_oldpub[unit - 2 - LW]);
         const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
-        __hip_atomic_store(rec_set + (size_t)g * REC + lane, ((unsigned long long)epoch << 32) | half,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (MR) {
+          for (int q = 0; q < mr.nranks; ++q)      // one copy into every rank's buffer: remote stores, local polls
+            __hip_atomic_store(mr.peer[q] + set_off + (size_t)gslot * REC + lane, ((unsigned long long)epoch << 32) | half,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+          __hip_atomic_store(rec_set + (size_t)g * REC + lane, ((unsigned long long)epoch << 32) | half,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     // (c) the exchange.  Two protocols (GSI_LU_ONEHOP selects):
@@ -325,7 +362,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
     //            measured 5.6-6.5 us per step, LU 7.35 ms at n = 1e6, l = 320;
     //  two hops: a leader sweeps all WHOLE records, reduces, publishes the result; everyone else polls the result:
     //            6.5-7.5 us per step (7.7 ms).  (Every workgroup sweeping all whole records -- 40 KB each -- 14.7 us.)
-    const bool leader = (g == G - 1) && !onehop;
+    const bool leader = (g == G - 1) && !onehop;           // (MR launches always use the one-hop protocol)
     // the result is published in LU2_RES_COPIES copies on lines of their own; workgroup g polls copy g % LU2_RES_COPIES
     // (255 workgroups polling the same three lines serialise on one memory channel)
     unsigned long long* res = recs + (size_t)2 * (size_t)G * REC + (size_t)(epoch & 1u) * (size_t)LU2_RES_COPIES * REC;
@@ -341,11 +378,11 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
         bool ok;
         for (;;) {
           if (mine) {
-            g0 = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g0 = poll_granule<MR>(src + 0);
+            g1 = poll_granule<MR>(src + 1);
+            g2 = poll_granule<MR>(src + 2);
           }
-          if (extra) gx = __hip_atomic_load(xsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (extra) gx = poll_granule<MR>(xsrc);
           ok = !mine || ((uint32_t)(g0 >> 32) == epoch && (uint32_t)(g1 >> 32) == epoch && (uint32_t)(g2 >> 32) == epoch);
           if (extra) ok = ok && ((uint32_t)(gx >> 32) == epoch);
           if (__all(ok)) break;
@@ -383,7 +420,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
         int tries = s_abort ? poll_limit : 0;
         bool ok;
         for (;;) {
-          if (mine) gv = __hip_atomic_load(rsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (mine) gv = poll_granule<MR>(rsrc);
           ok = !mine || ((uint32_t)(gv >> 32) == epoch);
           if (__all(ok)) break;
           if (++tries > poll_limit) break;
@@ -501,7 +538,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
     // (d) the result: slot 0 of the LDS image
     const double bestv = c_val[0];
     int32_t r = c_idx[0];
-    const bool valid = live && (r >= j && r < m);
+    const bool valid = live && (r >= j && r < mtot);
     if (!valid) r = j;                           // all-NaN column (or a gated step): no interchange
     const double* c_old = reinterpret_cast<const double*>(c_oldbits);
     const double* c_row = reinterpret_cast<const double*>(c_rowbits[0]);
@@ -523,11 +560,11 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
     // (f) rank-1 update in registers: regular rows are all active, none is row j
     bool hit = false;
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) hit = hit || (row0 + rr * BS == r);
+    for (int rr = 0; rr < R; ++rr) hit = hit || (grow0 + rr * BS == r);
     if (hit) {                                   // (one thread of the whole grid) the old row j moves here
 #pragma unroll
       for (int rr = 0; rr < R; ++rr)
-        if (row0 + rr * BS == r) {
+        if (grow0 + rr * BS == r) {
 #pragma unroll
           for (int k = 0; k < LW; ++k) a[rr][k] = c_old[k];
         }
@@ -746,9 +783,10 @@ static void launch_leaf(hipStream_t st, int grid, double* Y, int64_t ld, int64_t
                         int w, const Lu2Work& wk, uint32_t epoch_base) {
   static const int onehop = getenv("GSI_LU_ONEHOP") ? atoi(getenv("GSI_LU_ONEHOP")) : 1;   // A/B knob; 0 = two hops via a leader
   const int poll_limit = wk.poll_limit > 0 ? wk.poll_limit : POLL_LIMIT;
+  LuMrArgs none{};
   if (!wk.cooperative) {
-    hipLaunchKernelGGL((lu_leaf_kernel<BS, R>), dim3(grid), dim3(BS), 0, st, Y, ld, (int32_t)m, (int32_t)l, (int32_t)jb,
-                       (int32_t)j0, w, wk.recs, epoch_base, wk.ipiv, wk.info, onehop, poll_limit, wk.mute_epoch);
+    hipLaunchKernelGGL((lu_leaf_kernel<BS, R, false>), dim3(grid), dim3(BS), 0, st, Y, ld, (int32_t)m, (int32_t)l, (int32_t)jb,
+                       (int32_t)j0, w, wk.recs, epoch_base, wk.ipiv, wk.info, onehop, poll_limit, wk.mute_epoch, none);
     return;
   }
   // cooperative launch: the runtime guarantees that all `grid` workgroups are resident together (and refuses the launch
@@ -759,14 +797,14 @@ static void launch_leaf(hipStream_t st, int grid, double* Y, int64_t ld, int64_t
   unsigned long long* recs = wk.recs;
   int32_t* ipiv = wk.ipiv;
   int32_t* info = wk.info;
-  void* args[] = {&Y, &ld, &m32, &l32, &jb32, &j032, &w, &recs, &eb, &ipiv, &info, &oh, &pl, &mute};
-  (void)hipLaunchCooperativeKernel((const void*)lu_leaf_kernel<BS, R>, dim3(grid), dim3(BS), args, 0, st);
+  void* args[] = {&Y, &ld, &m32, &l32, &jb32, &j032, &w, &recs, &eb, &ipiv, &info, &oh, &pl, &mute, &none};
+  (void)hipLaunchCooperativeKernel((const void*)lu_leaf_kernel<BS, R, false>, dim3(grid), dim3(BS), args, 0, st);
 }
 
 template <int BS, int R>
 static int leaf_resident_per_cu() {
   int nblk = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)lu_leaf_kernel<BS, R>, BS, 0) != hipSuccess) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)lu_leaf_kernel<BS, R, false>, BS, 0) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
@@ -779,6 +817,120 @@ int lu2_resident_per_cu(int bs, int rpt) {
   if (bs == 256) return leaf_resident_per_cu<256, 4>();
   if (rpt == 4) return leaf_resident_per_cu<512, 4>();
   return leaf_resident_per_cu<512, 8>();
+}
+
+// ---- the leaf launch of the MULTI-RANK factorization: this rank's rows, G = w.grid workgroups per rank, records exchanged
+//      through every rank's peer-mapped buffer.  Launch geometry for shards of at most `pad` rows on `nranks` ranks:
+//      nranks * grid <= 256 records, every rank the same (bs, rpt, grid).
+bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid) {
+  if (nranks < 1 || nranks > LU2_MAX_RANKS) return false;
+  const int gmax = std::min(256 / nranks, ncus);
+  static const int cfg[4][2] = {{256, 1}, {256, 4}, {512, 4}, {512, 8}};
+  for (int c = 0; c < 4; ++c) {
+    const int64_t per = (int64_t)cfg[c][0] * cfg[c][1];
+    const int64_t g = (pad + per - 1) / per;
+    if (g <= gmax) { *bs = cfg[c][0]; *rpt = cfg[c][1]; *grid = (int)std::max<int64_t>(g, 1); return true; }
+  }
+  return false;
+}
+template <int BS, int R>
+static void launch_leaf_mr_t(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m,
+                             int64_t l, int64_t jb, int64_t j0, int wd, const double* us, uint32_t epoch_base) {
+  LuMrArgs a{};
+  a.rank = w.rank; a.nranks = w.nranks; a.gbase = (int32_t)row0; a.mtot = (int32_t)m; a.us = us;
+  for (int q = 0; q < w.nranks; ++q) a.peer[q] = w.peer[q];
+  const int poll_limit = w.poll_limit > 0 ? w.poll_limit : POLL_LIMIT;
+  hipLaunchKernelGGL((lu_leaf_kernel<BS, R, true>), dim3(w.grid), dim3(BS), 0, st, Y, ld, (int32_t)mloc, (int32_t)l, (int32_t)jb,
+                     (int32_t)j0, wd, w.peer[w.rank], epoch_base, w.ipiv, w.info, 1, poll_limit, 0u, a);
+}
+void lu2_leaf_mr(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l,
+                 int64_t jb, int64_t j0, int wd, const double* us, uint32_t epoch_base) {
+  if (w.bs == 256 && w.rpt == 1) launch_leaf_mr_t<256, 1>(st, w, Y, ld, mloc, row0, m, l, jb, j0, wd, us, epoch_base);
+  else if (w.bs == 256) launch_leaf_mr_t<256, 4>(st, w, Y, ld, mloc, row0, m, l, jb, j0, wd, us, epoch_base);
+  else if (w.rpt == 4) launch_leaf_mr_t<512, 4>(st, w, Y, ld, mloc, row0, m, l, jb, j0, wd, us, epoch_base);
+  else launch_leaf_mr_t<512, 8>(st, w, Y, ld, mloc, row0, m, l, jb, j0, wd, us, epoch_base);
+}
+int lu2_mr_resident_per_cu(int bs, int rpt) {
+  int nblk = 0;
+  hipError_t e;
+  if (bs == 256 && rpt == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)lu_leaf_kernel<256, 1, true>, 256, 0);
+  else if (bs == 256) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)lu_leaf_kernel<256, 4, true>, 256, 0);
+  else if (rpt == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)lu_leaf_kernel<512, 4, true>, 512, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)lu_leaf_kernel<512, 8, true>, 512, 0);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return nblk;
+}
+size_t lu2_mr_record_granules(int nranks, int grid) { return (size_t)2 * (size_t)nranks * (size_t)grid * REC; }
+
+// ---- the row interchanges of one leaf's pivots on the columns OUTSIDE the leaf, across ranks (LAPACK swaps whole rows; the
+//      leaf kernel moved the leaf's own 8 columns in registers).  The <= 16 rows involved -- j0 .. j0 + w - 1 and the pivot
+//      rows r_s -- are collected into a table (every rank contributes the rows it owns, zeros elsewhere; the host
+//      all-reduces it), the w swaps are replayed on the table, every rank writes back the rows it owns.
+//      Slot t < w: row j0 + t; slot w + s: pivot row r_s unless that row already has a slot (then the slot stays zero).
+__device__ inline int lus_swap_slot(const int32_t* piv, int w, int32_t j0, int32_t row) {     // canonical slot of a row
+  if (row >= j0 && row < j0 + w) return row - j0;
+  for (int s2 = 0; s2 < w; ++s2)
+    if (piv[s2] == row) return w + s2;
+  return -1;
+}
+__global__ __launch_bounds__(256) void lus_swap_pack_kernel(const double* __restrict__ Y, int64_t ld, int64_t mloc, int64_t row0,
+                                                            int64_t l, int32_t j0, int w, const int32_t* __restrict__ ipiv,
+                                                            double* __restrict__ table) {
+  __shared__ int32_t piv[LW];
+  if (threadIdx.x < LW) piv[threadIdx.x] = (threadIdx.x < (unsigned)w) ? ipiv[j0 + threadIdx.x] : -1;
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)2 * LW * l; e += (int64_t)gridDim.x * 256) {
+    const int t = (int)(e / l);
+    const int64_t c = e % l;
+    double v = 0.0;
+    if (t < 2 * w) {
+      const int32_t row = (t < w) ? j0 + t : piv[t - w];
+      const bool canonical = (t < w) || (lus_swap_slot(piv, w, j0, row) == t);
+      if (canonical && row >= row0 && row < row0 + mloc && !(c >= j0 && c < j0 + w)) v = Y[(row - row0) + c * ld];
+    }
+    table[e] = v;
+  }
+}
+__global__ __launch_bounds__(256) void lus_swap_apply_kernel(double* __restrict__ Y, int64_t ld, int64_t mloc, int64_t row0,
+                                                             int64_t l, int32_t j0, int w, const int32_t* __restrict__ ipiv,
+                                                             const double* __restrict__ table) {
+  __shared__ int32_t piv[LW];
+  if (threadIdx.x < LW) piv[threadIdx.x] = (threadIdx.x < (unsigned)w) ? ipiv[j0 + threadIdx.x] : -1;
+  __syncthreads();
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < l; c += (int64_t)gridDim.x * 256) {
+    if (c >= j0 && c < j0 + w) continue;
+    double v[2 * LW];
+#pragma unroll
+    for (int t = 0; t < 2 * LW; ++t) v[t] = table[(int64_t)t * l + c];
+    for (int s2 = 0; s2 < w; ++s2) {                       // LAPACK's order: swap rows j0 + s and r_s
+      const int b = lus_swap_slot(piv, w, j0, piv[s2]);
+      if (b >= 0 && b != s2) {
+        double va = 0.0, vb = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2 * LW; ++t) { if (t == s2) va = v[t]; if (t == b) vb = v[t]; }
+#pragma unroll
+        for (int t = 0; t < 2 * LW; ++t) { if (t == s2) v[t] = vb; if (t == b) v[t] = va; }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * LW; ++t) {
+      if (t < 2 * w) {
+        const int32_t row = (t < w) ? j0 + t : piv[t - w];
+        const bool canonical = (t < w) || (lus_swap_slot(piv, w, j0, row) == t);
+        if (canonical && row >= row0 && row < row0 + mloc) Y[(row - row0) + c * ld] = v[t];
+      }
+    }
+  }
+}
+void lus_swap_pack(hipStream_t st, const double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j0, int w,
+                   const int32_t* ipiv, double* table) {
+  const int g = (int)std::min<int64_t>((2 * LW * l + 255) / 256, 256);
+  hipLaunchKernelGGL(lus_swap_pack_kernel, dim3(g), dim3(256), 0, st, Y, ld, mloc, row0, l, (int32_t)j0, w, ipiv, table);
+}
+void lus_swap_apply(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j0, int w,
+                    const int32_t* ipiv, const double* table) {
+  const int g = (int)std::min<int64_t>((l + 255) / 256, 64);
+  hipLaunchKernelGGL(lus_swap_apply_kernel, dim3(g), dim3(256), 0, st, Y, ld, mloc, row0, l, (int32_t)j0, w, ipiv, table);
 }
 
 void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu2Work& w) {

@@ -375,7 +375,25 @@ void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t
   ScopedPhase ph(be, PH_LU);
   const int64_t reclen = 4 + 2 * l, ld = std::max<int64_t>(mloc, 1);
   const int nb = be->lus_block();
+  // One persistent launch per leaf and rank, pivot exchange inside the kernels (peer-written records), when the backend
+  // and the communicator can do it -- decided by ALL ranks together (a rank that cannot would leave the others polling).
+  bool mr = false;
+  if (c.comm) {
+    auto it = c.lus_mr_ok.find(m);
+    if (it == c.lus_mr_ok.end()) {
+      const double mine = be->lus_mr_begin(c.comm.get(), m, l) ? 1.0 : 0.0;
+      Buf flag(be, 1);
+      be->upload2d(flag.p, 1, &mine, 1, 1, 1);
+      c.comm->allreduce_sum(flag.p, 1);
+      double all = 0.0;
+      be->download2d(&all, 1, flag.p, 1, 1, 1);
+      it = c.lus_mr_ok.emplace(m, all == (double)G).first;
+    }
+    mr = it->second && be->lus_mr_begin(c.comm.get(), m, l);
+  }
   Buf rec(be, (size_t)reclen), recs(be, (size_t)reclen * G), u12leaf(be, (size_t)nb * 8), u12blk(be, (size_t)nb * l);
+  Buf swaps;
+  if (mr) swaps = Buf(be, (size_t)16 * l);
   for (int64_t jb = 0; jb < l; jb += nb) {
     const int b = (int)std::min<int64_t>(nb, l - jb);
     for (int64_t j0 = jb; j0 < jb + b; j0 += 8) {
@@ -385,7 +403,14 @@ void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t
         if (rank == 0) be->lus_u12_leaf(Yloc, ld, row0, jb, j0, w, u12leaf.p);
         else be->fill_zero(u12leaf.p, (size_t)kp * 8);
         if (c.comm) c.comm->allreduce_sum(u12leaf.p, (size_t)kp * 8);
-        be->lus_pending(Yloc, mloc, ld, row0, jb, j0, w, u12leaf.p);
+        if (!mr) be->lus_pending(Yloc, mloc, ld, row0, jb, j0, w, u12leaf.p);
+      }
+      if (mr) {
+        be->lus_leaf_mr(Yloc, mloc, ld, row0, m, l, jb, j0, w, u12leaf.p);       // pending update + the 8 pivot steps
+        be->lus_swap_pack(Yloc, mloc, ld, row0, l, j0, w, swaps.p);               // rows the pivots exchange, other columns
+        c.comm->allreduce_sum(swaps.p, (size_t)16 * l);
+        be->lus_swap_apply(Yloc, mloc, ld, row0, l, j0, w, swaps.p);
+        continue;
       }
       for (int s = 0; s < w; ++s) {
         be->lus_candidate(Yloc, mloc, ld, row0, l, j0 + s, rec.p);

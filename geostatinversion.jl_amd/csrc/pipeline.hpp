@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <map>
 #include <memory>
 #include <vector>
 #include "backend.hpp"
@@ -30,6 +31,7 @@ struct Buf {
 struct Context {
   std::unique_ptr<Backend> be;
   std::unique_ptr<Comm> comm;  // null when single rank
+  std::map<int64_t, bool> lus_mr_ok;   // panel height -> all ranks can run the sharded LU with in-kernel pivot exchange
   int rank() const { return comm ? comm->rank : 0; }
   int nranks() const { return comm ? comm->nranks : 1; }
 };

@@ -1256,9 +1256,19 @@ def run(rank):
         out["lowrank_rows_xis"] = orc.xis_error_up_to_sign(gather_rows(rank, "lr", Zrows.to_host()), np.array(xr).T, 16)
         Zrows.close(); lr.close()
         Yp = rng.standard_normal((5000, 72)); Yp[3000:3100] = Yp[100:200]
-        Ls, ps = gsi.lu_L_sharded(Yp, return_pivots=True, ctx=ctx)
+        Ls, ps = gsi.lu_L_sharded(Yp, return_pivots=True, ctx=ctx)     # persistent leaves, pivot exchange between the ranks' kernels
         out["lu_pivots"] = 0.0 if np.array_equal(ps, orc.lu_pivots(Yp)) else 1.0
         out["lu_L"] = float(np.abs(Ls - orc.lu_L(Yp)).max())
+        Yq = rng.standard_normal((300000, 136))                        # <512, 4> leaves, three 64-column blocks, shards of 1e5+ rows
+        for jj in range(0, 136, 5):
+            rr = rng.choice(300000, size=3, replace=False)
+            Yq[rr, jj] = [9.5, -9.5, 9.5]
+        Lq, pq = gsi.lu_L_sharded(Yq, return_pivots=True, ctx=ctx)
+        out["lu_big_pivots"] = 0.0 if np.array_equal(pq, orc.lu_pivots(Yq)) else 1.0
+        out["lu_big_L"] = float(np.abs(Lq - orc.lu_L(Yq)).max())
+        box[("Lq", rank)] = Lq; bar.wait()
+        out["lu_big_same_on_all_ranks"] = 0.0 if all(np.array_equal(box[("Lq", r)], Lq) for r in range(world)) else 1.0
+        bar.wait()
         Ns, beta = [25, 18], -3.5                                  # FFTRF convention on a grid that is not a power of two
         nf = 450
         Af = orc.fft_powerlaw_apply(np.eye(nf), Ns, beta, fftrf=True)
@@ -1326,7 +1336,7 @@ if errs:
 for r in range(world):
     for k, v in res[r].items():
         tol = 1e-6 if (k.endswith("xis") or k == "pcgalsqr_sharded_basis") else 1e-9
-        if k.endswith("mul") or k.endswith("mul_t") or k == "lu_L":
+        if k.endswith("mul") or k.endswith("mul_t") or k in ("lu_L", "lu_big_L"):
             tol = 1e-10
         assert v < tol, (r, k, v)
     assert res[r].keys() == res[0].keys()
