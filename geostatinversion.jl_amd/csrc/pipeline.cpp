@@ -390,6 +390,8 @@ void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t
       it = c.lus_mr_ok.emplace(m, all == (double)G).first;
     }
     mr = it->second && be->lus_mr_begin(c.comm.get(), m, l);
+    if (!mr && getenv("GSI_LU_MR_REQUIRE") != nullptr)      // tests: the in-kernel exchange must be what runs
+      throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: the multi-rank persistent leaf path is not available (GSI_LU_MR_REQUIRE)");
   }
   Buf rec(be, (size_t)reclen), recs(be, (size_t)reclen * G), u12leaf(be, (size_t)nb * 8), u12blk(be, (size_t)nb * l);
   Buf swaps;

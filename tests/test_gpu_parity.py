@@ -1344,6 +1344,7 @@ print("multirank-one-gpu-ok", len(res[0]))
 '''
     env = dict(os.environ)
     env["GSI_LOCAL_COMM"] = "1"
+    env["GSI_LU_MR_REQUIRE"] = "1"       # the sharded LU must run its persistent leaves with the in-kernel exchange between ranks
     r = subprocess.run([sys.executable, "-c", code, str(world)], capture_output=True, text=True, timeout=900, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "multirank-one-gpu-ok" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
