@@ -488,7 +488,9 @@ class HipBackend : public Backend {
   bool lus_mr_begin(Comm* comm, int64_t m, int64_t l) override {
     bind();
     static const bool off = (getenv("GSI_LU_NO_MR") != nullptr);
-    if (off || mr_disabled_ || comm == nullptr || comm->nranks > hipk::LU2_MAX_RANKS || m >= ((int64_t)1 << 28)) return false;
+    if (off || mr_disabled_ || comm == nullptr || comm->nranks > hipk::LU2_MAX_RANKS || m >= ((int64_t)1 << 28) ||
+        l > hipk::LU2_MR_MAXL)
+      return false;
     const int G = comm->nranks;
     const int64_t pad = (m + G - 1) / G;
     hipk::Lu2MrWork w{};
@@ -499,7 +501,7 @@ class HipBackend : public Backend {
     if ((int64_t)it->second * ncus_ < w.grid) return false;
     if (mr_comm_ != comm) {                                 // first use over this communicator: record buffer, exchanged once
       if (mr_recs_ == nullptr) {
-        const size_t bytes = sizeof(unsigned long long) * hipk::lu2_mr_record_granules(1, 256);   // room for 256 records
+        const size_t bytes = sizeof(unsigned long long) * hipk::lu2_mr_record_granules(1, 256);   // 256 records + mailboxes
         if (hipExtMallocWithFlags((void**)&mr_recs_, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
           (void)hipGetLastError();
           HIP_CHECK(hipMalloc((void**)&mr_recs_, bytes));
@@ -513,7 +515,6 @@ class HipBackend : public Backend {
       for (int g = 0; g < G; ++g) mr_peer_[g] = (unsigned long long*)all[g];
       mr_comm_ = comm;
     }
-    (void)l;
     w.rank = comm->rank; w.nranks = G;
     for (int g = 0; g < G; ++g) w.peer[g] = mr_peer_[g];
     w.info = flags_ + 0;

@@ -90,6 +90,7 @@ struct Lu2Work {
 int lu2_resident_per_cu(int bs, int rpt);
 // the same leaf kernel across RANKS (one launch per rank, records written into every rank's peer-mapped buffer)
 constexpr int LU2_MAX_RANKS = 16;
+constexpr int LU2_MR_MAXL = 8192;        // widest panel of the multi-rank persistent-leaf path (row boxes)
 struct Lu2MrWork {
   unsigned long long* peer[LU2_MAX_RANKS];   // every rank's record buffer: [2][nranks * grid][LU2_REC_GRANULES]
   int32_t* ipiv;                             // [l] this rank's copy of the pivot rows (identical on every rank)

@@ -211,10 +211,11 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
 
   // ---- pending update of the block's earlier columns: a -= L[:, jb:j0] * (L11^-1 A12) ----------------------
   if (kp > 0) {
-    if constexpr (MR) {
-      for (int e = tid; e < kp * LW; e += BS) Us[e] = mr.us[e];
-      __syncthreads();
-    } else {
+    // U12 = L11^-1 A12 lives in rows jb .. j0 of the block: on rank 0 when the panel is sharded.  Rank 0 solves it like
+    // the single-rank kernel (every workgroup for itself) and its workgroup 0 pushes the kp x 8 values, tagged with this
+    // leaf's first epoch, into the other ranks' U mailboxes; they poll their own memory.
+    const bool solve_here = !MR || gbase == 0;
+    if (solve_here) {
     {
       // all of a thread's elements of the kp x kp block are requested before the first one is used: as a plain loop this
       // was one HBM / L2 round trip per iteration (up to KPMAX^2 / BS of them) at the head of every leaf
@@ -243,6 +244,39 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
       if (lane < kp) Us[lane * LW + v] = x;
     }
     __syncthreads();
+    }
+    if constexpr (MR) {
+      const uint32_t utag = epoch_base + 1u;
+      const size_t ubox = (size_t)2 * (size_t)G * REC + (size_t)((epoch_base >> 3) & 1u) * (size_t)(2 * KPMAX * LW);
+      if (gbase == 0) {
+        if (g == 0) {
+          for (int e = tid; e < kp * LW; e += BS) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(Us[e]);
+            for (int q = 0; q < mr.nranks; ++q) {
+              if (q == mr.rank) continue;
+              __hip_atomic_store(mr.peer[q] + ubox + 2 * e, ((unsigned long long)utag << 32) | (uint32_t)bits, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(mr.peer[q] + ubox + 2 * e + 1, ((unsigned long long)utag << 32) | (uint32_t)(bits >> 32),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+          }
+        }
+      } else {
+        __syncthreads();                          // s_abort (set by thread 0 at the top) is read below
+        for (int e = tid; e < kp * LW; e += BS) {
+          unsigned long long lo = 0, hi = 0;
+          int tries = s_abort ? poll_limit : 0;
+          for (;;) {
+            lo = poll_granule<true>(recs + ubox + 2 * e);
+            hi = poll_granule<true>(recs + ubox + 2 * e + 1);
+            if ((uint32_t)(lo >> 32) == utag && (uint32_t)(hi >> 32) == utag) break;
+            if (++tries > poll_limit) { s_abort = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          Us[e] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+        }
+        __syncthreads();
+      }
     }
     for (int c = 0; c < kp; c += 2) {              // kp is a multiple of the leaf width
       double lv[2][R];
@@ -860,7 +894,11 @@ int lu2_mr_resident_per_cu(int bs, int rpt) {
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return nblk;
 }
-size_t lu2_mr_record_granules(int nranks, int grid) { return (size_t)2 * (size_t)nranks * (size_t)grid * REC; }
+// a rank's exchange buffer: two parity sets of records, two U mailboxes (kp x 8 doubles as granule pairs), two row boxes
+// (one granule pair per panel column, l <= LU2_MR_MAXL) for the rows a pivot step exchanges between ranks
+size_t lu2_mr_record_granules(int nranks, int grid) {
+  return (size_t)2 * (size_t)nranks * (size_t)grid * REC + (size_t)2 * (2 * KPMAX * LW) + (size_t)2 * (2 * LU2_MR_MAXL);
+}
 
 // ---- the row interchanges of one leaf's pivots on the columns OUTSIDE the leaf, across ranks (LAPACK swaps whole rows; the
 //      leaf kernel moved the leaf's own 8 columns in registers).  The <= 16 rows involved -- j0 .. j0 + w - 1 and the pivot

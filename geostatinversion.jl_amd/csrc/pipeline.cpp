@@ -401,14 +401,15 @@ void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t
     for (int64_t j0 = jb; j0 < jb + b; j0 += 8) {
       const int w = (int)std::min<int64_t>(8, jb + b - j0);
       const int64_t kp = j0 - jb;
-      if (kp > 0) {
+      if (kp > 0 && !mr) {
         if (rank == 0) be->lus_u12_leaf(Yloc, ld, row0, jb, j0, w, u12leaf.p);
         else be->fill_zero(u12leaf.p, (size_t)kp * 8);
         if (c.comm) c.comm->allreduce_sum(u12leaf.p, (size_t)kp * 8);
-        if (!mr) be->lus_pending(Yloc, mloc, ld, row0, jb, j0, w, u12leaf.p);
+        be->lus_pending(Yloc, mloc, ld, row0, jb, j0, w, u12leaf.p);
       }
       if (mr) {
-        be->lus_leaf_mr(Yloc, mloc, ld, row0, m, l, jb, j0, w, u12leaf.p);       // pending update + the 8 pivot steps
+        // pending update (U12 solved by rank 0 inside its kernel and pushed to the others) + the 8 pivot steps
+        be->lus_leaf_mr(Yloc, mloc, ld, row0, m, l, jb, j0, w, nullptr);
         be->lus_swap_pack(Yloc, mloc, ld, row0, l, j0, w, swaps.p);               // rows the pivots exchange, other columns
         c.comm->allreduce_sum(swaps.p, (size_t)16 * l);
         be->lus_swap_apply(Yloc, mloc, ld, row0, l, j0, w, swaps.p);
