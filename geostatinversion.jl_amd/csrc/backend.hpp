@@ -100,6 +100,7 @@ class Backend {
   //      leaf's pivots exchange in the columns OUTSIDE the leaf (table: 16 x l doubles, all-reduced in between).
   virtual bool lus_mr_begin(class Comm* comm, int64_t m, int64_t l) { (void)comm; (void)m; (void)l; return false; }
   virtual void lus_leaf_mr(double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, const double*) {}
+  virtual bool lus_mr_swaps_done() { return false; }   // lus_leaf_mr also moved the rows in the other columns (peer pushes)
   virtual void lus_swap_pack(const double*, int64_t, int64_t, int64_t, int64_t, int64_t, int, double*) {}
   virtual void lus_swap_apply(double*, int64_t, int64_t, int64_t, int64_t, int64_t, int, const double*) {}
   // Y (m x l) <- thin Q; R (l x l, ld l) <- upper triangular factor if R != null.

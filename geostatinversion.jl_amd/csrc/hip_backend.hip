@@ -527,9 +527,14 @@ class HipBackend : public Backend {
     bind();
     mr_work_.ipiv = lus_ws(mloc, l).ipiv;
     hipk::lu2_leaf_mr(st_, mr_work_, Yloc, ld, mloc, row0, m, l, jb, j0, w, U12, mr_epoch_);
+    // the rows this leaf's pivots exchange, in the columns outside the leaf: peer pushes + polls, no collective
+    static const bool host_swaps = (getenv("GSI_LU_MR_HOST_SWAPS") != nullptr);      // A/B: pack + all-reduce + apply instead
+    mr_peer_swaps_ = !host_swaps;
+    if (mr_peer_swaps_) hipk::lus_swap_peer(st_, mr_work_, Yloc, ld, mloc, row0, m, l, j0, w, mr_epoch_);
     mr_epoch_ += (uint32_t)hipk::LU2_LEAF;
     check_launch("lu2_leaf_mr");
   }
+  bool lus_mr_swaps_done() override { return mr_peer_swaps_; }
   void lus_swap_pack(const double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l, int64_t j0, int w,
                      double* table) override {
     bind();
@@ -975,7 +980,7 @@ class HipBackend : public Backend {
   unsigned long long* mr_peer_[hipk::LU2_MAX_RANKS] = {nullptr};
   Comm* mr_comm_ = nullptr;
   uint32_t mr_epoch_ = 0;
-  bool mr_disabled_ = false;
+  bool mr_disabled_ = false, mr_peer_swaps_ = true;
   hipk::Lu2MrWork mr_work_{};
   int64_t lus_part_col_ = -1, lus_part_mloc_ = 0;     // sharded LU: column whose arg-max partials the last apply kernel left
   const double* lus_part_Y_ = nullptr;

@@ -103,6 +103,8 @@ int lu2_mr_resident_per_cu(int bs, int rpt);
 size_t lu2_mr_record_granules(int nranks, int grid);
 void lu2_leaf_mr(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l,
                  int64_t jb, int64_t j0, int wd, const double* us, uint32_t epoch_base);
+void lus_swap_peer(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l,
+                   int64_t j0, int wd, uint32_t epoch_base);
 void lus_swap_pack(hipStream_t st, const double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j0, int w,
                    const int32_t* ipiv, double* table);
 void lus_swap_apply(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j0, int w,

@@ -894,10 +894,10 @@ int lu2_mr_resident_per_cu(int bs, int rpt) {
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return nblk;
 }
-// a rank's exchange buffer: two parity sets of records, two U mailboxes (kp x 8 doubles as granule pairs), two row boxes
-// (one granule pair per panel column, l <= LU2_MR_MAXL) for the rows a pivot step exchanges between ranks
+// a rank's exchange buffer: two parity sets of records, two U mailboxes (kp x 8 doubles as granule pairs), two table boxes
+// (16 rows x l <= LU2_MR_MAXL columns as granule pairs) for the rows a leaf's pivots exchange between ranks
 size_t lu2_mr_record_granules(int nranks, int grid) {
-  return (size_t)2 * (size_t)nranks * (size_t)grid * REC + (size_t)2 * (2 * KPMAX * LW) + (size_t)2 * (2 * LU2_MR_MAXL);
+  return (size_t)2 * (size_t)nranks * (size_t)grid * REC + (size_t)2 * (2 * KPMAX * LW) + (size_t)2 * ((size_t)2 * LW * 2 * LU2_MR_MAXL);
 }
 
 // ---- the row interchanges of one leaf's pivots on the columns OUTSIDE the leaf, across ranks (LAPACK swaps whole rows; the
@@ -909,6 +909,13 @@ __device__ inline int lus_swap_slot(const int32_t* piv, int w, int32_t j0, int32
   if (row >= j0 && row < j0 + w) return row - j0;
   for (int s2 = 0; s2 < w; ++s2)
     if (piv[s2] == row) return w + s2;
+  return -1;
+}
+// slot of a row in the peer kernel's layout: t < LW: row j0 + t; LW + s: pivot r_s (first occurrence)
+__device__ inline int lus_swap_slot_lw(const int32_t* piv, int w, int32_t j0, int32_t row) {
+  if (row >= j0 && row < j0 + w) return row - j0;
+  for (int s2 = 0; s2 < w; ++s2)
+    if (piv[s2] == row) return LW + s2;
   return -1;
 }
 __global__ __launch_bounds__(256) void lus_swap_pack_kernel(const double* __restrict__ Y, int64_t ld, int64_t mloc, int64_t row0,
@@ -960,6 +967,105 @@ __global__ __launch_bounds__(256) void lus_swap_apply_kernel(double* __restrict_
     }
   }
 }
+// The same interchange WITHOUT a host-sequenced collective: every rank pushes the rows it owns into every other rank's table
+// box (granule pairs tagged with the leaf's first epoch, system-scope stores into peer-mapped memory), polls its own box for
+// the rows the others own, replays the swaps and writes back its rows.  One launch per leaf and rank, thread = one column.
+// A rank that owns none of the <= 16 rows has nothing to write and leaves at once.
+__global__ __launch_bounds__(256) void lus_swap_peer_kernel(double* __restrict__ Y, int64_t ld, int64_t mloc, int64_t row0,
+                                                            int64_t l, int32_t j0, int w, const int32_t* __restrict__ ipiv,
+                                                            LuMrArgs mr, unsigned long long* __restrict__ own, size_t box_off,
+                                                            uint32_t tag, int64_t pad, int poll_limit,
+                                                            int32_t* __restrict__ info) {
+  __shared__ int32_t piv[LW];
+  __shared__ int s_any;
+  if (threadIdx.x == 0) s_any = 0;
+  if (threadIdx.x < LW) piv[threadIdx.x] = (threadIdx.x < (unsigned)w) ? ipiv[j0 + threadIdx.x] : -1;
+  __syncthreads();
+  if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) return;   // a timed-out factorization drains
+  // canonical slots and their owners (the same on every rank)
+  int32_t srow[2 * LW];
+  bool scan[2 * LW], smine[2 * LW];
+  bool any_mine = false;
+#pragma unroll
+  for (int t = 0; t < 2 * LW; ++t) {
+    const int32_t row = (t < w) ? j0 + t : ((t >= LW && t - LW < w) ? piv[t - LW] : -1);
+    srow[t] = row;
+    bool canonical = row >= 0;
+    if (canonical && t >= LW) {
+      if (row >= j0 && row < j0 + w) canonical = false;
+      for (int s2 = 0; s2 < t - LW; ++s2) if (piv[s2] == row) canonical = false;
+    }
+    scan[t] = canonical;
+    smine[t] = canonical && row >= row0 && row < row0 + mloc;
+    any_mine = any_mine || smine[t];
+  }
+  if (!any_mine) return;
+  const size_t lq = (size_t)l;
+  bool timed_out = false;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < l; c += (int64_t)gridDim.x * 256) {
+    if (c >= j0 && c < j0 + w) continue;
+    double v[2 * LW];
+#pragma unroll
+    for (int t = 0; t < 2 * LW; ++t) {           // my rows: read, push to everyone else
+      v[t] = 0.0;
+      if (smine[t]) {
+        v[t] = Y[(srow[t] - row0) + c * ld];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v[t]);
+        const size_t off = box_off + ((size_t)t * lq + (size_t)c) * 2;
+        for (int q = 0; q < mr.nranks; ++q) {
+          if (q == mr.rank) continue;
+          __hip_atomic_store(mr.peer[q] + off, ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(mr.peer[q] + off + 1, ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * LW; ++t) {           // the others' rows: poll my own box
+      if (scan[t] && !smine[t]) {
+        const size_t off = box_off + ((size_t)t * lq + (size_t)c) * 2;
+        unsigned long long lo = 0, hi = 0;
+        int tries = timed_out ? poll_limit : 0;
+        for (;;) {
+          lo = poll_granule<true>(own + off);
+          hi = poll_granule<true>(own + off + 1);
+          if ((uint32_t)(lo >> 32) == tag && (uint32_t)(hi >> 32) == tag) break;
+          if (++tries > poll_limit) { timed_out = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        v[t] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+      }
+    }
+    for (int s2 = 0; s2 < w; ++s2) {             // LAPACK's order: swap rows j0 + s and r_s
+      const int b = lus_swap_slot_lw(piv, w, j0, piv[s2]);
+      if (b >= 0 && b != s2) {
+        double va = 0.0, vb = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2 * LW; ++t) { if (t == s2) va = v[t]; if (t == b) vb = v[t]; }
+#pragma unroll
+        for (int t = 0; t < 2 * LW; ++t) { if (t == s2) v[t] = vb; if (t == b) v[t] = va; }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * LW; ++t)
+      if (smine[t]) Y[(srow[t] - row0) + c * ld] = v[t];
+  }
+  if (timed_out) atomicExch(info, -1);
+}
+void lus_swap_peer(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l,
+                   int64_t j0, int wd, uint32_t epoch_base) {
+  LuMrArgs a{};
+  a.rank = w.rank; a.nranks = w.nranks; a.gbase = (int32_t)row0; a.mtot = (int32_t)m; a.us = nullptr;
+  for (int q = 0; q < w.nranks; ++q) a.peer[q] = w.peer[q];
+  const int64_t pad = (m + w.nranks - 1) / w.nranks;
+  const size_t G = (size_t)w.nranks * (size_t)w.grid;
+  const size_t box = (size_t)2 * G * REC + (size_t)2 * (2 * KPMAX * LW) + (size_t)((epoch_base >> 3) & 1u) * ((size_t)2 * LW * 2 * LU2_MR_MAXL);
+  const int poll_limit = w.poll_limit > 0 ? w.poll_limit : POLL_LIMIT;
+  const int g = (int)std::min<int64_t>((l + 255) / 256, 64);
+  hipLaunchKernelGGL(lus_swap_peer_kernel, dim3(g), dim3(256), 0, st, Y, ld, mloc, row0, l, (int32_t)j0, wd, w.ipiv, a, w.peer[w.rank], box,
+                     epoch_base + 1u, pad, poll_limit, w.info);
+}
+
 void lus_swap_pack(hipStream_t st, const double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j0, int w,
                    const int32_t* ipiv, double* table) {
   const int g = (int)std::min<int64_t>((2 * LW * l + 255) / 256, 256);

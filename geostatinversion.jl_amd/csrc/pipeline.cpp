@@ -410,9 +410,11 @@ void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t
       if (mr) {
         // pending update (U12 solved by rank 0 inside its kernel and pushed to the others) + the 8 pivot steps
         be->lus_leaf_mr(Yloc, mloc, ld, row0, m, l, jb, j0, w, nullptr);
-        be->lus_swap_pack(Yloc, mloc, ld, row0, l, j0, w, swaps.p);               // rows the pivots exchange, other columns
-        c.comm->allreduce_sum(swaps.p, (size_t)16 * l);
-        be->lus_swap_apply(Yloc, mloc, ld, row0, l, j0, w, swaps.p);
+        if (!be->lus_mr_swaps_done()) {                                             // rows the pivots exchange, other columns
+          be->lus_swap_pack(Yloc, mloc, ld, row0, l, j0, w, swaps.p);
+          c.comm->allreduce_sum(swaps.p, (size_t)16 * l);
+          be->lus_swap_apply(Yloc, mloc, ld, row0, l, j0, w, swaps.p);
+        }
         continue;
       }
       for (int s = 0; s < w; ++s) {
