@@ -1020,21 +1020,30 @@ __global__ __launch_bounds__(256) void lus_swap_peer_kernel(double* __restrict__
         }
       }
     }
+    {                                            // the others' rows: poll my own box, all slots of a round in flight together
+      unsigned long long lo[2 * LW], hi[2 * LW];
+      int tries = timed_out ? poll_limit : 0;
+      for (;;) {
+        bool ok = true;
 #pragma unroll
-    for (int t = 0; t < 2 * LW; ++t) {           // the others' rows: poll my own box
-      if (scan[t] && !smine[t]) {
-        const size_t off = box_off + ((size_t)t * lq + (size_t)c) * 2;
-        unsigned long long lo = 0, hi = 0;
-        int tries = timed_out ? poll_limit : 0;
-        for (;;) {
-          lo = poll_granule<true>(own + off);
-          hi = poll_granule<true>(own + off + 1);
-          if ((uint32_t)(lo >> 32) == tag && (uint32_t)(hi >> 32) == tag) break;
-          if (++tries > poll_limit) { timed_out = true; break; }
-          __builtin_amdgcn_s_sleep(1);
+        for (int t = 0; t < 2 * LW; ++t) {
+          if (scan[t] && !smine[t]) {
+            const size_t off = box_off + ((size_t)t * lq + (size_t)c) * 2;
+            lo[t] = poll_granule<true>(own + off);
+            hi[t] = poll_granule<true>(own + off + 1);
+          }
         }
-        v[t] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+#pragma unroll
+        for (int t = 0; t < 2 * LW; ++t)
+          if (scan[t] && !smine[t]) ok = ok && ((uint32_t)(lo[t] >> 32) == tag && (uint32_t)(hi[t] >> 32) == tag);
+        if (ok) break;
+        if (++tries > poll_limit) { timed_out = true; break; }
+        __builtin_amdgcn_s_sleep(1);
       }
+#pragma unroll
+      for (int t = 0; t < 2 * LW; ++t)
+        if (scan[t] && !smine[t])
+          v[t] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi[t] << 32) | (uint32_t)lo[t]));
     }
     for (int s2 = 0; s2 < w; ++s2) {             // LAPACK's order: swap rows j0 + s and r_s
       const int b = lus_swap_slot_lw(piv, w, j0, piv[s2]);
