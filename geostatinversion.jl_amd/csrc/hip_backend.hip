@@ -1083,7 +1083,9 @@ class RcclComm : public Comm {
     be_->bind();
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     hipIpcMemHandle_t h;
-    HIP_CHECK(hipIpcGetMemHandle(&h, mine));
+    std::memset(&h, 0, sizeof(h));
+    bool ok = (hipIpcGetMemHandle(&h, mine) == hipSuccess);     // a failure here must not skip the collective below
+    if (!ok) (void)hipGetLastError();
     double* send = be_->alloc(8);
     double* recv = be_->alloc((size_t)8 * nranks);
     HIP_CHECK(hipMemcpyAsync(send, &h, 64, hipMemcpyHostToDevice, be_->stream()));
@@ -1093,13 +1095,13 @@ class RcclComm : public Comm {
     HIP_CHECK(hipStreamSynchronize(be_->stream()));
     be_->release(send);
     be_->release(recv);
-    for (int g = 0; g < nranks; ++g) {
+    for (int g = 0; g < nranks && ok; ++g) {
       if (g == rank) { all[g] = mine; continue; }
       void* p = nullptr;
-      HIP_CHECK(hipIpcOpenMemHandle(&p, hs[(size_t)g], hipIpcMemLazyEnablePeerAccess));
+      if (hipIpcOpenMemHandle(&p, hs[(size_t)g], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; }
       all[g] = p;
     }
-    return true;
+    return ok;      // false on this rank alone is fine: the ranks all-reduce their answers before anyone relies on the buffers
   }
 
  private:
