@@ -485,7 +485,9 @@ int gemm_choose_split(int64_t nwg, int64_t K) {
   }
   if (K < 8 * BK || nwg >= 16 * CUS) return 1;
   int64_t maxs = K / (4 * BK);
-  if (maxs > 64) maxs = 64;
+  // up to 256 ways: a Gram matrix of a narrow, very tall panel (l = 48 at n = 1.3e8: ONE output tile) is an HBM stream that
+  // 64 workgroups cannot pull -- 23 ms per 6.4 GB at n = 1.7e7 where 256 workgroups take ~3 (the slabs stay tiny: s M L)
+  if (maxs > 256) maxs = 256;
   int best = 1;
   double best_cost = (double)((nwg + CUS - 1) / CUS);
   for (int64_t s = 2; s <= maxs; ++s) {
@@ -503,7 +505,7 @@ size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K) {
 }
 // the symmetric product C = A'A (l x l, K = m): fewer active tiles, so possibly more splits; bound by the chooser's cap
 size_t gemm_syrk_workspace_doubles(int64_t l, int64_t m) {
-  return (m >= 8 * BK) ? (size_t)64 * (size_t)l * (size_t)l : 0;
+  return (m >= 8 * BK) ? (size_t)256 * (size_t)l * (size_t)l : 0;
 }
 
 // number of 16-column tiles per workgroup pass.  (128-column chunks for the symmetric product, so that chunk and

@@ -34,6 +34,7 @@ namespace {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool pooled = false;      // a panel-sized workspace taken from (and returned to) the block cache instead of hipMalloc / hipFree
 };
 
 // roctx ranges around the phases of the hot path: bound lazily, so the library has no hard
@@ -77,7 +78,7 @@ class HipBackend : public Backend {
   ~HipBackend() override {
     hipSetDevice(device_);
     hipStreamSynchronize(st_);
-    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_, &ws_svdf_, &ws_qr_hh_}) if (b->p) hipFree(b->p);
+    for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_, &ws_svdf_, &ws_qr_hh_}) free_ws(*b);
     for (auto& b : pool_) hipFree(b.p);
     for (auto& ev : ev_pool_) hipEventDestroy(ev);
     for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -103,7 +104,11 @@ class HipBackend : public Backend {
   double* alloc(size_t count) override {
     bind();
     if (count == 0) count = 1;
-    const size_t bytes = count * sizeof(double);
+    size_t bytes = count * sizeof(double);
+    // Panel-sized requests are rounded up to 256 MiB: the n x l panel, the (n + 1) x l workspace of the out-of-place QR and the
+    // even-ld copy of the thin SVD then have the SAME size and hand one cached block to each other instead of going through
+    // hipFree / hipMalloc (at 512^3, l = 48 -- 51.5 GB blocks -- that was 4.9 s of an 11.4 s randsvd).
+    if (bytes > ((size_t)1 << 30)) bytes = (bytes + (((size_t)256 << 20) - 1)) & ~(((size_t)256 << 20) - 1);
     {
       std::lock_guard<std::mutex> g(mu_);
       for (size_t i = 0; i < pool_.size(); ++i)
@@ -147,7 +152,7 @@ class HipBackend : public Backend {
           sizes_.pop_back();
           break;
         }
-      if (bytes != 0 && bytes <= ((size_t)24 << 30)) {   // stored operators (tens of GB) are not worth caching
+      if (bytes != 0) {
         pool_.push_back({p, bytes});
         pooled_ += (int64_t)bytes;
         p = nullptr;
@@ -157,10 +162,10 @@ class HipBackend : public Backend {
       hipStreamSynchronize(st_);
       hipFree(p);
     }
-    // Panels of the tall problems are GBs each and come back every pass: keep up to 64 GB of them (of 288 GB; a
+    // Panels of the tall problems are GBs each and come back every pass: keep up to 160 GB of them (of 288 GB; a
     // failed hipMalloc empties the cache and retries, so nothing is ever refused because of it).  A tighter policy
-    // cost 0.7 s of hipFree/hipMalloc per randsvd at n = 1.7e7.
-    if (pooled_ > ((int64_t)64 << 30)) trim_pool((int64_t)32 << 30);
+    // cost 0.7 s of hipFree/hipMalloc per randsvd at n = 1.7e7 and 4.9 s at n = 1.3e8.
+    if (pooled_ > ((int64_t)160 << 30)) trim_pool((int64_t)104 << 30);
   }
   void trim_pool(int64_t keep_bytes) {
     hipStreamSynchronize(st_);
@@ -172,7 +177,10 @@ class HipBackend : public Backend {
     }
   }
   int64_t bytes_in_use() const override {
-    return in_use_ + pooled_ + (int64_t)(ws_gemm_.bytes + ws_lu_.bytes + ws_qr_.bytes + ws_svd_.bytes + ws_blas2_.bytes + ws_svdf_.bytes + ws_qr_hh_.bytes);
+    int64_t ws = 0;
+    for (const DevBuf* b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_svdf_, &ws_qr_hh_})
+      if (!b->pooled) ws += (int64_t)b->bytes;          // pooled workspaces are counted by alloc()
+    return in_use_ + pooled_ + ws;
   }
   void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) override {
     if (rows <= 0 || cols <= 0) return;
@@ -919,18 +927,27 @@ class HipBackend : public Backend {
   }
   // Cached workspaces make repeated factorizations allocation-free; one of panel size at 512^3 (tens of GB) would
   // instead starve the next phase, so anything above 8 GiB is given back when the call that grew it returns.
+  void free_ws(DevBuf& b) {
+    if (!b.p) return;
+    if (b.pooled) release((double*)b.p);       // back to the block cache (stream-ordered: no synchronisation)
+    else { (void)hipStreamSynchronize(st_); (void)hipFree(b.p); }
+    b.p = nullptr; b.bytes = 0; b.pooled = false;
+  }
   void trim(DevBuf& b) {
     if (b.bytes <= ((size_t)8 << 30) || !b.p) return;
-    (void)hipStreamSynchronize(st_);
-    (void)hipFree(b.p);
-    b.p = nullptr; b.bytes = 0;
+    free_ws(b);
   }
   struct TrimGuard { HipBackend* be; DevBuf* b; ~TrimGuard() { be->trim(*b); } };
   void grow(DevBuf& b, size_t bytes) {
     if (bytes <= b.bytes) return;
-    HIP_CHECK(hipStreamSynchronize(st_));
-    if (b.p) hipFree(b.p);
-    b.p = nullptr; b.bytes = 0;
+    if (bytes > ((size_t)1 << 30)) {             // panel-sized: from the block cache, where a just-released panel usually waits
+      free_ws(b);
+      b.p = alloc((bytes + 7) / 8);
+      b.bytes = bytes;
+      b.pooled = true;
+      return;
+    }
+    free_ws(b);
     bytes = (bytes + 4095) & ~(size_t)4095;
     hipError_t e = hipMalloc(&b.p, bytes);
     if (e != hipSuccess) {   // give the cache of released panels back and retry once (the other phases' workspaces may be
