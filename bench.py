@@ -235,6 +235,7 @@ def secondary_fft_512cube(gsi, ctx, barrier):
     spectrum + work array); rank 256 needs the panels spread over GPUs.  ONE step."""
     gc3, K5, p5, q5 = 512, 39, 9, 2
     n5, l5 = gc3 ** 3, K5 + p5
+    ctx.release_cache()      # 232 of 288 GB are about to be used: what the earlier workloads left cached goes back first (untimed)
     op5 = gsi.fft_powerlaw_operator(ctx, [gc3, gc3, gc3], -3.5, fftrf=True)
     e5, ph5, _ = run_steps(gsi, ctx, op5, n5, K5, p5, q5, 1, 0, barrier)
     peak_bytes5 = ctx.device_bytes()

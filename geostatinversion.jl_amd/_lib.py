@@ -87,6 +87,7 @@ SIGNATURES = {
     "gsi_ctx_phase_reset": (C.c_int, [c_vp]),
     "gsi_ctx_phase_times": (C.c_int, [c_vp, c_dp, C.POINTER(c_i64)]),
     "gsi_ctx_counters": (C.c_int, [c_vp, C.POINTER(c_i64)]),
+    "gsi_ctx_release_cache": (C.c_int, [c_vp]),
     "gsi_ctx_device_bytes": (C.c_int, [c_vp, C.POINTER(c_i64)]),
 }
 

@@ -74,6 +74,10 @@ class Context:
         L.check(self.lib.gsi_ctx_counters(self.h, out), self.lib)
         return {"cholqr2": out[0], "householder": out[1], "jacobi_sweeps": out[2], "scholqr3": out[3]}
 
+    def release_cache(self):
+        """Return cached device memory (released panels, idle workspaces) to the driver (`gsi_ctx_release_cache`)."""
+        L.check(self.lib.gsi_ctx_release_cache(self.h), self.lib)
+
     def device_bytes(self):
         b = C.c_int64()
         L.check(self.lib.gsi_ctx_device_bytes(self.h, C.byref(b)), self.lib)

@@ -953,6 +953,12 @@ int gsi_ctx_counters(gsi_ctx* ctx, int64_t* out4) {
     ctx->c.be->counters(out4);
   });
 }
+int gsi_ctx_release_cache(gsi_ctx* ctx) {
+  return guarded([&] {
+    REQUIRE(ctx, "ctx is NULL");
+    ctx->c.be->release_cache();
+  });
+}
 int gsi_ctx_device_bytes(gsi_ctx* ctx, int64_t* bytes) {
   return guarded([&] {
     REQUIRE(ctx && bytes, "NULL argument");

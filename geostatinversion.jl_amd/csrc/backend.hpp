@@ -33,6 +33,7 @@ class Backend {
   virtual double* alloc(size_t count) = 0;  // throws Error(GSI_ERR_OOM)
   virtual void release(double* p) = 0;
   virtual int64_t bytes_in_use() const = 0;
+  virtual void release_cache() {}            // return cached (released) blocks and idle workspaces to the driver
   virtual void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) = 0;
   virtual void download2d(double* host, int64_t ldh, const double* src, int64_t lds, int64_t rows, int64_t cols) = 0;
   virtual void copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) = 0;

@@ -176,6 +176,12 @@ class HipBackend : public Backend {
       pool_.pop_back();
     }
   }
+  void release_cache() override {
+    bind();
+    for (DevBuf* b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_, &ws_svdf_, &ws_qr_hh_})
+      if (b->bytes > ((size_t)64 << 20)) free_ws(*b);
+    trim_pool(0);
+  }
   int64_t bytes_in_use() const override {
     int64_t ws = 0;
     for (const DevBuf* b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_svdf_, &ws_qr_hh_})

@@ -54,6 +54,8 @@ mutable struct Context
 		return c
 	end
 end
+"Return the context's cached device memory (released panels, idle workspaces) to the driver."
+release_cache!(c::Context) = check(ccall((:gsi_ctx_release_cache, libgsi), Cint, (Ptr{Cvoid},), c.h))
 const default_ctx = Ref{Union{Nothing, Context}}(nothing)
 ctx() = something(default_ctx[], (default_ctx[] = Context(0)))
 
