@@ -562,7 +562,10 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
   // GSI_FFT_B0 KB of LDS so that several workgroups share a CU.  Strided lines want long segments: a power of two of
   // neighbouring lines, up to 16 (256 bytes) within GSI_FFT_B1 KB, but at least 4 (64 bytes) whatever that costs.
   static const int b0 = getenv("GSI_FFT_B0") ? atoi(getenv("GSI_FFT_B0")) : 64;
-  static const int b1 = getenv("GSI_FFT_B1") ? atoi(getenv("GSI_FFT_B1")) : 76;
+  // 140 KB (round 3; was 76): 1024-point lines (512^3 grids) get 8 lines per tile = 128-byte segments, one workgroup per CU,
+  // instead of 4 lines (64-byte segments) and two workgroups: 171.8 -> 144.1 ms per 16 columns at 512^3 (3.0 -> 3.6 TB/s),
+  // 256^3 +3 %, 2048-point lines unchanged (4 lines are all that fit the 8192-point tile)
+  static const int b1 = getenv("GSI_FFT_B1") ? atoi(getenv("GSI_FFT_B1")) : 140;
   const int64_t line_bytes = (int64_t)ps.Ma * (int64_t)sizeof(double2);
   const int tmax = FFT_MAX_TILE / ps.Ma;            // >= 1: Ma <= 8192
   int T;
