@@ -181,6 +181,7 @@ class Backend {
   // true (once) if the last error was a lost resource rather than a property of the input, and the backend has switched
   // to a path that does not need it: the caller may run the same entry point again on its intact inputs
   virtual bool retryable_failure() { return false; }
+  virtual void forgive_lost_coresidency() {}     // undo what a time-out inside a self-test switched off
 
   // ---- profiling ----
   virtual void profile(bool on) = 0;

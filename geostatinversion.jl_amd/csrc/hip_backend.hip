@@ -842,6 +842,12 @@ class HipBackend : public Backend {
     if (it == lu2_resident_.end()) it = lu2_resident_.emplace(key, hipk::lu2_resident_per_cu(bs, rpt)).first;
     return (int64_t)it->second * ncus_ >= grid;
   }
+  void forgive_lost_coresidency() override {
+    bind();
+    (void)hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), st_);
+    lu2_lost_ = false;
+    lu2_retry_ = false;          // (mr_disabled_ stays as the self-test left it)
+  }
   bool retryable_failure() override {
     const bool r = lu2_retry_;
     lu2_retry_ = false;
@@ -1097,11 +1103,12 @@ class RcclComm : public Comm {
     }
     RCCL_CHECK(r.GroupEnd());
   }
-  // one process per GPU: IPC handles travel through an all-gather, every rank maps its peers' buffers.  NOT exercised on
-  // the one-GPU build box (RCCL refuses two ranks on one device): opt-in, GSI_LU_PEER=1.
+  // one process per GPU: IPC handles travel through an all-gather, every rank maps its peers' buffers.  The mapping of
+  // OTHER processes' buffers cannot be exercised on the one-GPU build box (RCCL refuses two ranks on one device), which is
+  // why pipeline.cpp:lus_mr_selftest makes the path prove itself on the machine it runs on before it is used.
   bool share_pointers(void* mine, size_t bytes, void** all) override {
     (void)bytes;
-    static const bool on = (getenv("GSI_LU_PEER") != nullptr);
+    static const bool on = !(getenv("GSI_LU_PEER") != nullptr && getenv("GSI_LU_PEER")[0] == '0');   // GSI_LU_PEER=0: never
     if (!on) return false;
     be_->bind();
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");

@@ -367,32 +367,79 @@ static bool all_shards_tall(int64_t m, int G, int64_t l);
 // every rank then picks the same winner (largest value, lowest global row: LAPACK's idamax).  Left-looking leaves of 8
 // inside blocks of lus_block() columns, exactly like the single-rank kernels; the U12 rows (rank 0 holds the first l
 // rows) reach the other ranks by an all-reduce with zeros.
-void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l) {
+static void lu_panel_sharded_impl(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l, bool mr);
+
+// do ALL ranks answer yes?  (one all-reduced flag: a rank that cannot take a path would leave the others polling)
+static bool all_ranks_agree(Context& c, bool mine) {
+  Backend* be = c.be.get();
+  const double v = mine ? 1.0 : 0.0;
+  Buf flag(be, 1);
+  be->upload2d(flag.p, 1, &v, 1, 1, 1);
+  c.comm->allreduce_sum(flag.p, 1);
+  double all = 0.0;
+  be->download2d(&all, 1, flag.p, 1, 1, 1);
+  return all == (double)c.nranks();
+}
+
+// The in-kernel pivot exchange relies on things a build box with one GPU cannot prove about the machine it later runs on
+// (peer mappings, visibility of system-scope stores across the fabric).  So, once per communicator, it has to EARN its
+// place: a small panel (2048 rows per rank x 24 columns: three leaves of one block -- records, U mailbox, row boxes) is
+// factored by the per-step form and by the persistent leaves; the fast path is used only if every rank got bit-identical
+// factors and no kernel raised a flag.  Anything else -- a mapping that failed, a poll that timed out -- leaves the per-step
+// form in charge, silently and on all ranks.
+static bool lus_mr_selftest(Context& c) {
   Backend* be = c.be.get();
   const int G = c.nranks(), rank = c.rank();
+  const int64_t rows = 2048, lt = 24, mt = rows * G;
+  bool ok = all_ranks_agree(c, be->lus_mr_begin(c.comm.get(), mt, lt));
+  if (!ok) return false;
+  Buf A(be, (size_t)rows * lt), B(be, (size_t)rows * lt);
+  be->randn(A.p, (size_t)rows * lt, 0x5e1f7e57ull + (uint64_t)rank);
+  be->copy2d(B.p, rows, A.p, rows, rows, lt);
+  bool mine = true;
+  try {
+    lu_panel_sharded_impl(c, A.p, mt, rows * rank, rows, lt, false);
+    lu_panel_sharded_impl(c, B.p, mt, rows * rank, rows, lt, true);
+    be->axpy(rows * lt, -1.0, A.p, B.p);
+    mine = (be->nrm2(rows * lt, B.p) == 0.0);
+    std::string msg;
+    if (be->take_error(&msg) != 0) mine = false;
+  } catch (const Error&) {
+    mine = false;
+  }
+  be->forgive_lost_coresidency();          // a time-out in here must not cost the context its single-GPU fast path
+  return all_ranks_agree(c, mine);
+}
+
+void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l) {
+  Backend* be = c.be.get();
+  const int G = c.nranks();
   if (G > 1 && l > (m + G - 1) / G)
     throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: the first rank must hold the first l rows");
-  ScopedPhase ph(be, PH_LU);
-  const int64_t reclen = 4 + 2 * l, ld = std::max<int64_t>(mloc, 1);
-  const int nb = be->lus_block();
   // One persistent launch per leaf and rank, pivot exchange inside the kernels (peer-written records), when the backend
-  // and the communicator can do it -- decided by ALL ranks together (a rank that cannot would leave the others polling).
+  // and the communicator can do it -- decided by ALL ranks together, after the self-test above has passed on this
+  // communicator.
   bool mr = false;
   if (c.comm) {
-    auto it = c.lus_mr_ok.find(m);
-    if (it == c.lus_mr_ok.end()) {
-      const double mine = be->lus_mr_begin(c.comm.get(), m, l) ? 1.0 : 0.0;
-      Buf flag(be, 1);
-      be->upload2d(flag.p, 1, &mine, 1, 1, 1);
-      c.comm->allreduce_sum(flag.p, 1);
-      double all = 0.0;
-      be->download2d(&all, 1, flag.p, 1, 1, 1);
-      it = c.lus_mr_ok.emplace(m, all == (double)G).first;
+    if (c.lus_mr_selftest < 0) c.lus_mr_selftest = lus_mr_selftest(c) ? 1 : 0;
+    if (c.lus_mr_selftest == 1) {
+      auto it = c.lus_mr_ok.find(m);
+      if (it == c.lus_mr_ok.end()) it = c.lus_mr_ok.emplace(m, all_ranks_agree(c, be->lus_mr_begin(c.comm.get(), m, l))).first;
+      mr = it->second && be->lus_mr_begin(c.comm.get(), m, l);
     }
-    mr = it->second && be->lus_mr_begin(c.comm.get(), m, l);
     if (!mr && getenv("GSI_LU_MR_REQUIRE") != nullptr)      // tests: the in-kernel exchange must be what runs
       throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: the multi-rank persistent leaf path is not available (GSI_LU_MR_REQUIRE)");
   }
+  lu_panel_sharded_impl(c, Yloc, m, row0, mloc, l, mr);
+}
+
+static void lu_panel_sharded_impl(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l, bool mr) {
+  Backend* be = c.be.get();
+  const int G = c.nranks(), rank = c.rank();
+  ScopedPhase ph(be, PH_LU);
+  const int64_t reclen = 4 + 2 * l, ld = std::max<int64_t>(mloc, 1);
+  const int nb = be->lus_block();
+  if (mr && !be->lus_mr_begin(c.comm.get(), m, l)) throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: persistent leaves refused");
   Buf rec(be, (size_t)reclen), recs(be, (size_t)reclen * G), u12leaf(be, (size_t)nb * 8), u12blk(be, (size_t)nb * l);
   Buf swaps;
   if (mr) swaps = Buf(be, (size_t)16 * l);

@@ -32,6 +32,7 @@ struct Context {
   std::unique_ptr<Backend> be;
   std::unique_ptr<Comm> comm;  // null when single rank
   std::map<int64_t, bool> lus_mr_ok;   // panel height -> all ranks can run the sharded LU with in-kernel pivot exchange
+  int lus_mr_selftest = -1;            // -1 not run yet; 1 / 0: the in-kernel exchange reproduced the per-step factors on this communicator
   int rank() const { return comm ? comm->rank : 0; }
   int nranks() const { return comm ? comm->nranks : 1; }
 };
