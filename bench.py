@@ -229,6 +229,42 @@ def secondary_fft_1000sq(gsi, ctx, barrier):
         "phases_ms_per_step": {k: v[0] / 5 for k, v in ph4.items()}}
 
 
+def secondary_pointcov(gsi, ctx, barrier):
+    """The covariance of SCATTERED points as a row-streamed implicit operator (SURVEY.md 8b "coords + kernel id + params"):
+    one product A*X at n = 202500 points (the nodes of a 450 x 450 grid handed over as coordinates), l = 320, exponential
+    kernel -- against the table-based implicit grid operator on the same points (the same matrix: their difference is the
+    check)."""
+    import numpy as np
+    g, l = 450, 320
+    n = g * g
+    xs, ys = np.meshgrid(np.arange(g, dtype=np.float64), np.arange(g, dtype=np.float64), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel()])
+    lib = ctx.lib
+    X = gsi.DeviceMatrix(ctx, n, l).randn(1)
+    Y = gsi.DeviceMatrix(ctx, n, l)
+    out = {}
+    cols = {}
+    for tag, op in (("table", gsi.gridcov_implicit_operator(ctx, g, g, 45.0, kind=1)),
+                    ("points", gsi.pointcov_implicit_operator(ctx, P, "exponential", ell=45.0))):
+        gsi._lib.check(lib.gsi_op_mul_dev(ctx.h, op.h, 0, X.h, Y.h), lib)
+        barrier()
+        t0 = time.perf_counter()
+        gsi._lib.check(lib.gsi_op_mul_dev(ctx.h, op.h, 0, X.h, Y.h), lib)
+        barrier()
+        out[tag] = time.perf_counter() - t0
+        cols[tag] = Y.to_host()[:, :2]
+        op.close()
+    X.close()
+    Y.close()
+    return {
+        "workload": f"implicit covariance exp(-d/45) of n = {n} SCATTERED points (given as coordinates), l = {l}: one product; row "
+                    "panels of A generated on a second stream, consumed by the stored-operand contraction (DESIGN.md 4.9)",
+        "ms_per_product": 1e3 * out["points"], "contraction_TFLOP/s": 2.0 * n * n * l / out["points"] / 1e12,
+        "table_based_grid_operator_ms_per_product": 1e3 * out["table"],
+        "table_based_grid_operator_TFLOP/s": 2.0 * n * n * l / out["table"] / 1e12,
+        "max_rel_diff_vs_table_operator": float(np.abs(cols["points"] - cols["table"]).max() / np.abs(cols["table"]).max())}
+
+
 def secondary_fft_512cube(gsi, ctx, barrier):
     """BASELINE.json configs[2]'s own grid: 512^3 points (n = 1.34e8), FFTRF convention (512 is a power of two: exactly
     FFTRF.jl:83-90's 1024^3 embedding), at the sketch width one GPU's 288 GB hold (four n x l fp64 panels of 51 GB +
@@ -455,6 +491,7 @@ def main():
         guarded("c2_dense_65536", lambda: secondary_c2(gsi, ctx, barrier))
         guarded("implicit_dense_1e6", lambda: secondary_implicit(gsi, ctx, barrier))
         guarded("fft_powerlaw_1000sq", lambda: secondary_fft_1000sq(gsi, ctx, barrier))
+        guarded("pointcov_implicit_2e5", lambda: secondary_pointcov(gsi, ctx, barrier))
         if not args.no_fft_512cube:
             guarded("fft_powerlaw_512cube", lambda: secondary_fft_512cube(gsi, ctx, barrier))
         out["secondary"] = sec
