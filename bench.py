@@ -312,6 +312,42 @@ def full_size_parity(host, Ns, K, p, q, Sv):
             "inputs": "centred samples, Omega and the last timed step's Z/S downloaded from HBM: the timed operator itself"}
 
 
+def same_numbers_as_one_gpu(gsi, device, n, Ns, decay, K, p, q, world, seed, Sv, Z0_rows):
+    """Rank 0, after the timed region of an N > 1 run: the SAME randsvd on ONE GPU (a second context without a communicator:
+    whole operator, the global Omega = the ranks' row blocks stacked, gsi_randsvd's replicated code path) and the distance
+    of the N-rank result from it.  The one-GPU path is the one the oracle checks at this size in the N = 1 line."""
+    from oracle import oracle as orc
+    from helpers import rel_sv_err
+    import numpy as np
+    l = K + p
+    t0 = time.perf_counter()
+    ctx1 = gsi.Context(device)
+    pad = (n + world - 1) // world
+    Om = np.empty((n, l), order="F")
+    for r in range(world):                                   # the ranks' Omega blocks, regenerated from their seeds
+        r0 = min(r * pad, n)
+        nl = min(pad, n - r0)
+        if nl > 0:
+            blk = gsi.DeviceMatrix(ctx1, nl, l).randn(seed + 7919 * r)
+            Om[r0:r0 + nl] = blk.to_host()
+            blk.close()
+    op1 = gsi.lowrank_synthetic_operator(ctx1, n, Ns, seed=0, decay=decay)
+    Omega = gsi.DeviceMatrix.from_host(ctx1, Om)
+    del Om
+    Z = gsi.DeviceMatrix(ctx1, n, l)
+    S = gsi.DeviceMatrix(ctx1, l, 1)
+    gsi._lib.check(ctx1.lib.gsi_randsvd_dev(ctx1.h, op1.h, Omega.h, K, p, q, Z.h, S.h), ctx1.lib)
+    S1 = S.to_host()[:, 0].copy()
+    Z1 = Z.to_host()[:Z0_rows.shape[0]]
+    for m in (Omega, Z, S, op1):
+        m.close()
+    ctx1.close()
+    return {"n": int(n), "ranks": int(world), "sv_rel_err_vs_one_gpu": rel_sv_err(Sv, S1, K),
+            "xis_err_up_to_sign_vs_one_gpu_rank0_rows": orc.xis_error_up_to_sign(Z0_rows, Z1, K),
+            "seconds": time.perf_counter() - t0,
+            "what": "rank 0 re-runs the step on one GPU (no communicator) from the same samples and the stacked Omega blocks"}
+
+
 def main():
     # stdout carries exactly ONE line (the JSON result of rank 0): libraries that chat on fd 1 (gloo's
     # "[Gloo] Rank 0 is connected ...", RCCL's version banner) are sent to stderr for the whole run.
@@ -345,6 +381,13 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     import gsi_amd as gsi
 
+    # rehearsal of the N > 1 run on a ONE-GPU box: every rank a process on device 0, joined by the library's shared-memory
+    # communicator (RCCL refuses two ranks on one device).  The ranks share the GPU, so the figure is not a scaling number;
+    # the code path -- row shards, gsi_randsvd_rows, the cross-process pivot exchange of the sharded LU -- is the real one.
+    one_gpu = bool(os.environ.get("GSI_BENCH_ONE_GPU"))
+    if one_gpu:
+        local_rank = 0
+        os.environ["GSI_SHM_COMM"] = "1"
     dist = None
     use_dist = world > 1 or bool(os.environ.get("GSI_BENCH_FORCE_DIST"))   # the latter: rehearse the N > 1 code on one GPU
     if use_dist:
@@ -379,12 +422,20 @@ def main():
     l = K + p
     op = gsi.lowrank_synthetic_operator(ctx, n, Ns, seed=0, decay=args.decay)      # samples generated + centred in HBM
     full_parity = world == 1 and not args.no_cpu_baseline and not args.no_full_parity
-    keep = {} if full_parity else None
+    # N > 1 (same problem row-sharded): rank 0 afterwards re-runs the step on one GPU and reports how far the N-rank numbers
+    # are from it -- when the whole problem fits one GPU comfortably (n <= 2e6: 16 GB of samples, 5 GB panels)
+    vs_one_gpu = world > 1 and rank == 0 and n <= 2000000 and not args.no_full_parity
+    keep = {} if (full_parity or vs_one_gpu) else None
     elapsed, phases, Sv = run_steps(gsi, ctx, op, n, K, p, q, args.steps, args.warmup, barrier, keep=keep, rows=use_dist)
     elapsed = max_over_ranks(elapsed)
     counters = ctx.counters()
     dev_bytes = ctx.device_bytes()
     host = None
+    Z0_rows = None
+    if vs_one_gpu:
+        Z0_rows = keep["Z"].to_host()
+        keep["Omega"].close()
+        keep["Z"].close()
     if full_parity:                      # after the timed region: what the oracle needs, off the device
         try:
             host = {"samples": gsi.device_samples(op, Ns), "Omega": keep["Omega"].to_host(), "Z": keep["Z"].to_host()}
@@ -463,7 +514,8 @@ def main():
                                    f"(BASELINE.json metric config; SURVEY.md 8d C4-ii)"
                                    + ("" if world == 1 else (", same problem row-sharded" if args.scaling == "strong"
                                                               else ", 1e6 rows per GPU")),
-                       "n": n, "samples": Ns, "K": K, "p": p, "q": q, "parallelism": f"row-shard x{world}" + (" (Omega and Z as row shards: gsi_randsvd_rows)" if use_dist else ""),
+                       "n": n, "samples": Ns, "K": K, "p": p, "q": q, "parallelism": f"row-shard x{world}" + (" (Omega and Z as row shards: gsi_randsvd_rows)" if use_dist else "")
+                       + (" -- REHEARSAL: all ranks share GPU 0 (GSI_BENCH_ONE_GPU)" if one_gpu and world > 1 else ""),
                        "operator_bytes_per_gpu": 8.0 * nloc * Ns, "device_bytes_in_use": dev_bytes},
             "roofline": roofline,
             "phases_hbm": phases_hbm,
@@ -474,6 +526,12 @@ def main():
         }
         # size-independent property at the full size: the trailing p singular values exist, descending, positive
         out["sv_descending_positive"] = bool(all(Sv[i] >= Sv[i + 1] for i in range(l - 1)) and Sv[K - 1] > 0)
+        if vs_one_gpu:
+            try:
+                out["multi_rank_vs_one_gpu"] = same_numbers_as_one_gpu(gsi, local_rank, n, Ns, args.decay, K, p, q, world, 1234, Sv,
+                                                                       Z0_rows)
+            except Exception as exc:                        # noqa: BLE001 -- the check must not take the line down
+                out["multi_rank_vs_one_gpu"] = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---------------- secondary workloads (one GPU only) -------------------------------------------------------
     if world == 1 and not args.no_secondary:

@@ -4,6 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1061,6 +1066,19 @@ RcclApi& rccl() {
                                     (rccl().GetErrorString ? rccl().GetErrorString(_r) : "rccl error")); \
   } while (0)
 
+// all[g] = rank g's buffer as this process addresses it: its own pointer, an IPC mapping of everybody else's
+static bool ipc_open_all(int nranks, int rank, void* mine, const hipIpcMemHandle_t* hs, void** all, std::vector<void*>* opened) {
+  bool ok = true;
+  for (int g = 0; g < nranks && ok; ++g) {
+    if (g == rank) { all[g] = mine; continue; }
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, hs[g], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; p = nullptr; }
+    all[g] = p;
+    if (p && opened) opened->push_back(p);
+  }
+  return ok;
+}
+
 class RcclComm : public Comm {
  public:
   RcclComm(HipBackend* be, int n, int r, const void* id) : be_(be) {
@@ -1125,12 +1143,7 @@ class RcclComm : public Comm {
     HIP_CHECK(hipStreamSynchronize(be_->stream()));
     be_->release(send);
     be_->release(recv);
-    for (int g = 0; g < nranks && ok; ++g) {
-      if (g == rank) { all[g] = mine; continue; }
-      void* p = nullptr;
-      if (hipIpcOpenMemHandle(&p, hs[(size_t)g], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; }
-      all[g] = p;
-    }
+    if (ok) ok = ipc_open_all(nranks, rank, mine, hs.data(), all, nullptr);
     return ok;      // false on this rank alone is fine: the ranks all-reduce their answers before anyone relies on the buffers
   }
 
@@ -1230,11 +1243,202 @@ class LocalComm : public Comm {
 };
 static bool local_comm_requested() { return getenv("GSI_LOCAL_COMM") != nullptr; }
 
+// ---- ranks as PROCESSES of one node without RCCL (GSI_SHM_COMM=1): host barriers and IPC handles in a POSIX shared-memory
+//      block, payloads through one staging buffer per rank that every peer maps with hipIpcOpenMemHandle.  Two uses: the
+//      cross-PROCESS half of the multi-rank code (IPC mapping of the pivot-exchange buffer, persistent kernels of different
+//      processes polling each other's memory) runs on a one-GPU box, where RCCL refuses two ranks on one device; and a node
+//      without librccl still has a communicator.  Rank-ordered sums (deterministic, identical on every rank).  A collective
+//      is: copy into my staging buffer, synchronise, barrier, read the peers' staging buffers, synchronise, barrier -- not
+//      a performance path.
+struct ShmBlock {
+  std::atomic<uint32_t> arrived;
+  std::atomic<uint32_t> generation;
+  uint32_t ok[16];
+  hipIpcMemHandle_t stage[16];
+  hipIpcMemHandle_t shared[16];
+};
+static_assert(std::atomic<uint32_t>::is_always_lock_free, "process-shared atomics");
+
+class ShmComm : public Comm {
+ public:
+  ShmComm(HipBackend* be, int n, int r, const void* id) : be_(be) {
+    nranks = n;
+    rank = r;
+    if (n < 1 || n > 16) throw Error(GSI_ERR_ARG, "shared-memory communicator: 1..16 ranks");
+    char name[96];
+    std::memcpy(name, (const char*)id + 16, 95);
+    name[95] = 0;
+    if (std::memcmp(id, "gsi-shm-comm", 12) != 0 || name[0] != '/')
+      throw Error(GSI_ERR_ARG, "shared-memory communicator: the id does not come from gsi_comm_unique_id() under GSI_SHM_COMM");
+    if (const char* e = getenv("GSI_SHM_TIMEOUT_S")) timeout_s_ = std::max(1, atoi(e));
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);      // whoever comes first creates it: zero-filled = initial state
+    if (fd < 0) throw Error(GSI_ERR_RCCL, std::string("shm_open(") + name + ") failed");
+    if (ftruncate(fd, sizeof(ShmBlock)) != 0) { close(fd); throw Error(GSI_ERR_RCCL, "shared-memory communicator: ftruncate failed"); }
+    void* m = mmap(nullptr, sizeof(ShmBlock), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) throw Error(GSI_ERR_RCCL, "shared-memory communicator: mmap failed");
+    blk_ = (ShmBlock*)m;
+    be_->bind();
+    size_t mb = 64;
+    if (const char* e = getenv("GSI_SHM_STAGE_MB")) mb = (size_t)std::max(1, atoi(e));
+    cap_ = mb * 1024 * 1024 / sizeof(double);
+    bool ok = (hipMalloc((void**)&stage_, cap_ * sizeof(double)) == hipSuccess);
+    hipIpcMemHandle_t h;
+    std::memset(&h, 0, sizeof(h));
+    if (ok) ok = (hipIpcGetMemHandle(&h, stage_) == hipSuccess);
+    if (!ok) (void)hipGetLastError();
+    blk_->stage[rank] = h;
+    blk_->ok[rank] = ok ? 1u : 0u;
+    barrier();
+    if (rank == 0) shm_unlink(name);                            // every rank has it mapped: nothing is left behind in /dev/shm
+    for (int g = 0; g < nranks; ++g) ok = ok && blk_->ok[g] != 0;
+    std::vector<hipIpcMemHandle_t> hs(blk_->stage, blk_->stage + nranks);
+    void* all[16] = {nullptr};
+    if (ok) ok = ipc_open_all(nranks, rank, stage_, hs.data(), all, &opened_);
+    blk_->ok[rank] = ok ? 1u : 0u;
+    barrier();
+    for (int g = 0; g < nranks; ++g) ok = ok && blk_->ok[g] != 0;
+    barrier();                                                  // ok[] is reused by share_pointers
+    if (!ok) { cleanup(); throw Error(GSI_ERR_RCCL, "shared-memory communicator: the ranks' staging buffers could not be mapped (hipIpc)"); }
+    for (int g = 0; g < nranks; ++g) peer_[g] = (const double*)all[g];
+  }
+  ~ShmComm() override {
+    be_->bind();
+    (void)hipStreamSynchronize(be_->stream());
+    cleanup();
+  }
+  void allreduce_sum(double* buf, size_t count) override {
+    hipStream_t st = be_->stream();
+    for (size_t off = 0; off < count || off == 0; off += cap_) {
+      const size_t c = std::min(cap_, count - off);
+      stage_in(buf + off, c);
+      if (c) HIP_CHECK(hipMemcpyAsync(buf + off, peer_[0], c * sizeof(double), hipMemcpyDeviceToDevice, st));
+      for (int g = 1; g < nranks && c; ++g) hipk::axpy(st, (int64_t)c, 1.0, peer_[g], buf + off);
+      done_reading();
+      if (count == 0) break;
+    }
+  }
+  void allgather(const double* send, double* recv, size_t count) override {
+    for (size_t off = 0; off < count || off == 0; off += cap_) {
+      const size_t c = std::min(cap_, count - off);
+      stage_in(send + off, c);
+      for (int g = 0; g < nranks && c; ++g)
+        HIP_CHECK(hipMemcpyAsync(recv + (size_t)g * count + off, peer_[g], c * sizeof(double), hipMemcpyDeviceToDevice, be_->stream()));
+      done_reading();
+      if (count == 0) break;
+    }
+  }
+  // blocks of `count` doubles per destination: the staging buffer holds nranks segments of one chunk
+  void reduce_scatter_sum(const double* send, double* recv, size_t count) override {
+    hipStream_t st = be_->stream();
+    const size_t cc = std::max<size_t>(cap_ / (size_t)nranks, 1);
+    for (size_t off = 0; off < count || off == 0; off += cc) {
+      const size_t c = std::min(cc, count - off);
+      stage_blocks(send, count, off, c, cc);
+      if (c) HIP_CHECK(hipMemcpyAsync(recv + off, peer_[0] + (size_t)rank * cc, c * sizeof(double), hipMemcpyDeviceToDevice, st));
+      for (int g = 1; g < nranks && c; ++g) hipk::axpy(st, (int64_t)c, 1.0, peer_[g] + (size_t)rank * cc, recv + off);
+      done_reading();
+      if (count == 0) break;
+    }
+  }
+  void alltoall(const double* send, double* recv, size_t count) override {
+    const size_t cc = std::max<size_t>(cap_ / (size_t)nranks, 1);
+    for (size_t off = 0; off < count || off == 0; off += cc) {
+      const size_t c = std::min(cc, count - off);
+      stage_blocks(send, count, off, c, cc);
+      for (int g = 0; g < nranks && c; ++g)
+        HIP_CHECK(hipMemcpyAsync(recv + (size_t)g * count + off, peer_[g] + (size_t)rank * cc, c * sizeof(double), hipMemcpyDeviceToDevice,
+                                 be_->stream()));
+      done_reading();
+      if (count == 0) break;
+    }
+  }
+  // the buffers are mapped exactly as RcclComm maps them (the handles travel through the shared block instead of an all-gather)
+  bool share_pointers(void* mine, size_t, void** all) override {
+    static const bool on = !(getenv("GSI_LU_PEER") != nullptr && getenv("GSI_LU_PEER")[0] == '0');
+    if (!on) return false;
+    be_->bind();
+    hipIpcMemHandle_t h;
+    std::memset(&h, 0, sizeof(h));
+    bool ok = (hipIpcGetMemHandle(&h, mine) == hipSuccess);
+    if (!ok) (void)hipGetLastError();
+    blk_->shared[rank] = h;
+    blk_->ok[rank] = ok ? 1u : 0u;
+    barrier();
+    for (int g = 0; g < nranks; ++g) ok = ok && blk_->ok[g] != 0;
+    std::vector<hipIpcMemHandle_t> hs(blk_->shared, blk_->shared + nranks);
+    barrier();                                                  // everybody has read the slots
+    if (ok) ok = ipc_open_all(nranks, rank, mine, hs.data(), all, &opened_);
+    return ok;      // as with RCCL: the caller all-reduces the ranks' answers before anyone relies on the buffers
+  }
+
+ private:
+  void barrier() {
+    const uint32_t gen = blk_->generation.load(std::memory_order_acquire);
+    if (blk_->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)nranks) {
+      blk_->arrived.store(0, std::memory_order_relaxed);
+      blk_->generation.fetch_add(1, std::memory_order_release);
+      return;
+    }
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint64_t it = 0; blk_->generation.load(std::memory_order_acquire) == gen; ++it) {
+      if (it < 4096) continue;
+      sched_yield();
+      if ((it & 1023) == 0) {
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (t1.tv_sec - t0.tv_sec > timeout_s_)
+          throw Error(GSI_ERR_RCCL, "shared-memory communicator: a rank did not reach the barrier (GSI_SHM_TIMEOUT_S)");
+      }
+    }
+  }
+  void stage_in(const double* src, size_t c) {                 // my chunk -> my staging buffer, visible to every rank
+    be_->bind();
+    if (c) HIP_CHECK(hipMemcpyAsync(stage_, src, c * sizeof(double), hipMemcpyDeviceToDevice, be_->stream()));
+    HIP_CHECK(hipStreamSynchronize(be_->stream()));
+    barrier();
+  }
+  void stage_blocks(const double* send, size_t count, size_t off, size_t c, size_t cc) {
+    be_->bind();
+    for (int g = 0; g < nranks && c; ++g)
+      HIP_CHECK(hipMemcpyAsync(stage_ + (size_t)g * cc, send + (size_t)g * count + off, c * sizeof(double), hipMemcpyDeviceToDevice,
+                               be_->stream()));
+    HIP_CHECK(hipStreamSynchronize(be_->stream()));
+    barrier();
+  }
+  void done_reading() {                                        // nobody overwrites a staging buffer a peer still reads
+    HIP_CHECK(hipStreamSynchronize(be_->stream()));
+    barrier();
+  }
+  void cleanup() {
+    for (void* p : opened_) (void)hipIpcCloseMemHandle(p);
+    opened_.clear();
+    (void)hipGetLastError();
+    if (blk_) {
+      try { if (!std::uncaught_exceptions()) { const int t = timeout_s_; timeout_s_ = std::min(t, 10); barrier(); timeout_s_ = t; } } catch (...) {}
+      munmap(blk_, sizeof(ShmBlock));
+      blk_ = nullptr;
+    }
+    if (stage_) { (void)hipFree(stage_); stage_ = nullptr; }
+  }
+
+  HipBackend* be_;
+  ShmBlock* blk_ = nullptr;
+  double* stage_ = nullptr;
+  size_t cap_ = 0;
+  const double* peer_[16] = {nullptr};
+  std::vector<void*> opened_;
+  int timeout_s_ = 300;
+};
+static bool shm_comm_requested() { return getenv("GSI_SHM_COMM") != nullptr; }
+
 }  // namespace
 
 Backend* make_backend(int device_id) { return new HipBackend(device_id); }
 Comm* make_comm(Backend* be, int nranks, int rank, const void* unique_id) {
   if (local_comm_requested()) return new LocalComm(static_cast<HipBackend*>(be), nranks, rank, unique_id);
+  if (shm_comm_requested()) return new ShmComm(static_cast<HipBackend*>(be), nranks, rank, unique_id);
   return new RcclComm(static_cast<HipBackend*>(be), nranks, rank, unique_id);
 }
 void comm_unique_id(void* id_out) {
@@ -1244,6 +1448,15 @@ void comm_unique_id(void* id_out) {
     const uint64_t c = counter.fetch_add(1);
     std::memcpy(id_out, "gsi-local-comm", 14);
     std::memcpy((char*)id_out + 16, &c, sizeof(c));
+    return;
+  }
+  if (shm_comm_requested()) {           // ranks are processes of this node: the name of a shared-memory block nobody has used
+    static std::atomic<uint64_t> counter{1};
+    timespec t;
+    clock_gettime(CLOCK_REALTIME, &t);
+    std::memcpy(id_out, "gsi-shm-comm", 12);
+    snprintf((char*)id_out + 16, 96, "/gsi-shm-%ld-%llu-%lld%09ld", (long)getpid(), (unsigned long long)counter.fetch_add(1),
+             (long long)t.tv_sec, (long)t.tv_nsec);
     return;
   }
   ncclUniqueId uid;
