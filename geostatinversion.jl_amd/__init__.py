@@ -15,7 +15,7 @@ from .context import (Context, Operator, DeviceMatrix, dense_operator, gridcov_o
                       gridcov_implicit_operator, pointcov_implicit_operator, fft_powerlaw_operator, lowrank_synthetic_operator,
                       default_context)
 from . import randmatfact as RandMatFact
-from .randmatfact import rangefinder, randsvd, randsvd_rows, eig_nystrom, colnorms, lu_L, lu_L_sharded, lu_L_sharded_virtual, qr_thinQ, svd_tall, gemm
+from .randmatfact import rangefinder, randsvd, randsvd_rows, eig_nystrom, colnorms, lu_L, lu_L_dev, lu_L_sharded, lu_L_sharded_virtual, qr_thinQ, svd_tall, gemm
 from .lowrank import LowRankCovMatrix, PCGALowRankMatrix, device_samples
 from .getxis import getxis, getxis_iwantfields, getxis_device, randsvdwithseed
 from .pcga import pcgadirect, pcgalsqr, rga, pcga, DeviceBasis, ShardedDeviceBasis
@@ -23,7 +23,7 @@ from .pcga import pcgadirect, pcgalsqr, rga, pcga, DeviceBasis, ShardedDeviceBas
 __all__ = [
     "GsiError", "load", "LIB_PATH", "Context", "Operator", "DeviceMatrix", "dense_operator",
     "gridcov_operator", "gridcov_implicit_operator", "pointcov_implicit_operator", "fft_powerlaw_operator", "lowrank_synthetic_operator", "default_context", "RandMatFact", "rangefinder", "randsvd", "randsvd_rows", "eig_nystrom",
-    "colnorms", "lu_L", "lu_L_sharded", "lu_L_sharded_virtual", "qr_thinQ", "svd_tall", "gemm", "LowRankCovMatrix", "PCGALowRankMatrix", "device_samples",
+    "colnorms", "lu_L", "lu_L_dev", "lu_L_sharded", "lu_L_sharded_virtual", "qr_thinQ", "svd_tall", "gemm", "LowRankCovMatrix", "PCGALowRankMatrix", "device_samples",
     "getxis", "getxis_iwantfields", "getxis_device", "randsvdwithseed", "pcgadirect", "pcgalsqr", "rga", "pcga",
     "DeviceBasis", "ShardedDeviceBasis",
 ]

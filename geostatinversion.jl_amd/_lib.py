@@ -63,6 +63,7 @@ SIGNATURES = {
     "gsi_randsvd_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsi_randsvd_rows": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsi_lu_L": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_dp, C.POINTER(C.c_int32)]),
+    "gsi_lu_L_dev": (C.c_int, [c_vp, c_vp, C.POINTER(C.c_int32)]),
     "gsi_lu_L_sharded": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_dp, C.POINTER(C.c_int32)]),
     "gsi_lu_L_sharded_virtual": (C.c_int, [c_vp, c_dp, c_i64, c_i64, C.c_int, c_dp, C.POINTER(C.c_int32)]),
     "gsi_qr_thinQ": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_dp, c_dp]),

@@ -220,8 +220,9 @@ def fft_powerlaw_operator(ctx, Ns, beta, fftrf=False):
     `fftrf=False` (`gsi_op_fft_powerlaw`): embedding on the next power of two >= 2N, |k| in cycles per grid spacing --
     the covariance family FFTRF samples from, for any grid.  `fftrf=True` (`gsi_op_fft_powerlaw_fftrf`): FFTRF.jl's own
     convention (exactly 2N points per axis, integer wavenumbers, FFTRF.jl:83-90) = the covariance of
-    `powerlaw_structuredgrid(Ns, k0, dk, beta)` fields up to dk^2 and the per-sample normalisation; power-of-two grids
-    only."""
+    `powerlaw_structuredgrid(Ns, k0, dk, beta)` fields up to dk^2 and the per-sample normalisation; any grid (those that
+    are not powers of two through a re-embedded spectrum, same matrix).  With a communicator on `ctx` every rank creates it
+    and the products run on row shards."""
     Ns = [int(v) for v in Ns]
     arr = (C.c_int64 * len(Ns))(*Ns)
     h = C.c_void_p()

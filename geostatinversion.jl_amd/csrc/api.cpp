@@ -597,6 +597,20 @@ int gsi_lu_L(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double* L_out,
   });
 }
 
+int gsi_lu_L_dev(gsi_ctx* ctx, gsi_mat* Y, int32_t* ipiv_out) {
+  return guarded([&] {
+    REQUIRE(ctx && Y, "NULL argument");
+    REQUIRE(Y->ctx == ctx, "matrix belongs to another context");
+    REQUIRE(Y->rows >= 1 && Y->cols >= 1 && Y->cols <= Y->rows, "lu_L: need 1 <= l <= m (tall panel)");
+    Backend* be = ctx->c.be.get();
+    {
+      ScopedPhase ph(be, PH_LU);
+      be->lu_L(Y->buf.p, Y->rows, Y->cols, Y->rows, ipiv_out);     // in place: a lost co-residency leaves no input to re-run from
+    }
+    check_async_errors(ctx->c);
+  });
+}
+
 int gsi_lu_L_sharded(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double* L_out, int32_t* ipiv_out) {
   return guarded([&] {
     REQUIRE(ctx && Y && L_out, "NULL argument");

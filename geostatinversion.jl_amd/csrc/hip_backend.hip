@@ -388,10 +388,11 @@ class HipBackend : public Backend {
   void lu_L(double* Y, int64_t m, int64_t l, int64_t ld, int32_t* ipiv_host) override {
     bind();
     // Panels of up to 4096 rows per CU: leaves held in registers, left-looking blocks, streaming rank-64 updates
-    // (panel_lu_leaf.hip).  Taller panels (and GSI_LU_SWEEPS=1, the A/B knob) take the per-column sweeps below.
+    // (panel_lu_leaf.hip).  Everything else takes the streamed leaves below.
     static const bool force_sweeps = (getenv("GSI_LU_SWEEPS") != nullptr);
     hipk::Lu2Work w2;
-    if (!force_sweeps && !lu2_lost_ && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid) &&
+    static const bool tall_first = (getenv("GSI_LU_TALL") != nullptr && getenv("GSI_LU_TALL")[0] == '1');
+    if (!force_sweeps && !tall_first && !lu2_lost_ && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid) &&
         lu2_fits(w2.bs, w2.rpt, w2.grid)) {
       // test / A-B knobs, read per call: GSI_LU_POLL_LIMIT (polls before a workgroup gives up), GSI_LU_TEST_MUTE_EPOCH
       // (one workgroup stays silent at that pivot step: exercises the info = -1 path), GSI_LU_COOPERATIVE=1
@@ -412,6 +413,24 @@ class HipBackend : public Backend {
       check_launch("lu2_L");
       if (ipiv_host) {
         HIP_CHECK(hipMemcpyAsync(ipiv_host, w2.ipiv, sizeof(int32_t) * l, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+      }
+      return;
+    }
+    // Everything the resident kernel does not take -- panels the register file cannot hold (more than 4096 rows per CU), a
+    // context that lost co-residency once, a leaf grid that does not fit the chip: streamed leaves with lazily evaluated
+    // candidates (same blocks, pivots and arithmetic; no spin-waits between workgroups).  GSI_LU_TALL=1 forces it for any
+    // height (tests: bit-identical to the resident kernel), GSI_LU_TALL=0 / GSI_LU_SWEEPS=1 take the per-column sweeps of
+    // round 1 instead (A/B).
+    static const char* tall_env = getenv("GSI_LU_TALL");
+    const bool tall_off = tall_env != nullptr && tall_env[0] == '0';
+    if (!force_sweeps && !tall_off && m < ((int64_t)1 << 31)) {
+      grow(ws_lu_, hipk::lu3_work_bytes(l));
+      int32_t* ipiv_dev = nullptr;
+      hipk::lu3_L(st_, Y, m, l, ld, ws_lu_.p, flags_ + 0, &ipiv_dev);
+      check_launch("lu3_L");
+      if (ipiv_host) {
+        HIP_CHECK(hipMemcpyAsync(ipiv_host, ipiv_dev, sizeof(int32_t) * l, hipMemcpyDeviceToHost, st_));
         HIP_CHECK(hipStreamSynchronize(st_));
       }
       return;
@@ -840,7 +859,7 @@ class HipBackend : public Backend {
   }
 
   // The persistent leaf kernel spins on records of ALL its workgroups: the grid must fit the chip at this kernel's
-  // occupancy (registers, LDS, waves).  Queried once per instantiation; a panel that does not fit takes the sweeps.
+  // occupancy (registers, LDS, waves).  Queried once per instantiation; a panel that does not fit takes the streamed leaves.
   bool lu2_fits(int bs, int rpt, int grid) {
     const int key = bs * 16 + rpt;
     auto it = lu2_resident_.find(key);
@@ -869,13 +888,13 @@ class HipBackend : public Backend {
       HIP_CHECK(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), st_));
       if (h[0] < 0) {
         // co-residency of the persistent leaf kernel was lost (a workgroup never got a CU: the GPU is shared with
-        // another queue).  The panel of that factorization is destroyed; this context factors with the per-column
-        // sweeps (no spin-waits between workgroups) from now on, and the entry point may be re-run on its inputs.
+        // another queue).  The panel of that factorization is destroyed; this context factors with
+        // streamed leaves (no spin-waits between workgroups) from now on, and the entry point may be re-run on its inputs.
         lu2_lost_ = true;
         lu2_retry_ = true;
         mr_disabled_ = true;
         if (msg) *msg = "lu(): the pivot exchange between workgroups timed out (GPU shared with another job?); "
-                        "this context now uses the per-column sweeps";
+                        "this context now streams its leaves (no spin-waits)";
         return GSI_ERR_INTERNAL;
       }
       if (h[0] != 0) {

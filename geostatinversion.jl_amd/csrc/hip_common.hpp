@@ -113,6 +113,10 @@ void lus_swap_apply(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t
 bool lu2_config(int64_t m, int ncus, int* bs, int* rpt, int* grid);
 void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu2Work& w);
 
+// panels taller than the register file: streamed leaves, lazily evaluated (no spin-waits); `work` = lu3_work_bytes(l) bytes
+size_t lu3_work_bytes(int64_t l);
+void lu3_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, void* work, int32_t* info, int32_t** ipiv_out);
+
 // row-sharded form (the exchange between ranks is pipeline.cpp's): primitives on this rank's rows [row0, row0 + mloc)
 int lus_grid(int64_t mloc);
 void lus_candidate(hipStream_t st, const double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l, int64_t j, double* rec,

@@ -1138,6 +1138,417 @@ void lu2_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const Lu
 }
 
 // =====================================================================================================================
+// Panels TALLER than the register file (more than 4096 rows per CU: 1100^2 grids, the 256^3 / 512^3 grids of the FFT
+// operator): the same blocks, leaves, pivots and arithmetic -- operation for operation, so the factors are bit-identical
+// to the register-resident kernel's -- with the leaf's 8 columns STREAMED instead of resident, and evaluated lazily:
+//   open   (one pass):  a <- a - L[:, jb:j0] U12 for the leaf's columns, written back once (kp + 8 reads, 8 writes; a
+//                       block's first leaf has nothing pending: one read of column j0); arg-max of column j0;
+//   pivot s (1 workgroup): finishes the arg-max, interchanges rows j0+s and r in all l columns, eliminates the new pivot
+//                       row with the s pivot rows before it and keeps it (u_s) in a 8 x 8 state block in HBM;
+//   cand  s+1 (one pass over s+2 columns, READ ONLY): every row below the pivots re-derives its current value in column
+//                       s+1 from its 8 STORED values and u_0..u_s (s(s+1)/2 fmas in registers) -- the right-looking
+//                       sweeps of panel_lu.hip read AND write the live columns at every step instead;
+//   close  (one pass):  multipliers of all rows below the leaf's pivots (8 reads, 8 writes).
+// Column passes per 8-column leaf: (kp + 16) + 35 + 16 against 88 + in-block products for the sweeps; no spin-waits, no
+// co-residency assumption.  Blocks end with the register-resident path's own U12 + rank-64 kernels.
+// =====================================================================================================================
+namespace {
+constexpr int T_BS = 256;       // threads per workgroup
+constexpr int T_R = 4;          // rows per thread and pass iteration (T_R * (kp-chunk + 8) loads in flight)
+constexpr int T_MAXWG = 4096;   // workgroups per streaming launch (grid-stride over the rows) = partial arg-maxes per step
+struct Lu3State {               // the leaf's pivot rows so far: u[t] = pivot row t after its elimination (entries k > t are U), 1 / u[t][t]
+  double u[LW][LW];
+  double rp[LW];
+};
+
+// What ends every candidate pass: the workgroup's arg-max goes to pval / pidx [blockIdx.x].  A one-workgroup launch then
+// finishes pivot step s of the leaf at j0: reduces the partial arg-maxes to the pivot row r, interchanges rows j0 + s and r
+// in all l columns, eliminates the new pivot row with the s pivot rows before it and keeps it (u_s) in the state block.
+// (Letting the workgroup that arrives LAST at a ticket counter do that inside the candidate pass -- one launch per pivot step
+// instead of two -- measured 1.7 x SLOWER at 1.2e6 rows: thousands of device-scope atomics on one address per step.)
+struct Lu3Step {
+  double* Y;
+  int64_t ld, m;
+  int32_t l, j0;
+  int s, w;                    // pivot step 0 <= s < w of the w-column leaf
+  double* pval;
+  int64_t* pidx;
+  Lu3State* stt;
+  int32_t* ipiv;
+  int32_t* info;
+};
+__device__ inline void lu3_step_tail(double best, int32_t besti, const Lu3Step& p) {
+  __shared__ double s_v[T_BS / 64];
+  __shared__ int32_t s_i[T_BS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  wave_argmax(best, besti);
+  if (lane == 0) { s_v[wave] = best; s_i[wave] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    double bv = -1.0;
+    int32_t bi = -1;
+    for (int q = 0; q < T_BS / 64; ++q)
+      if (s_i[q] >= 0 && (s_v[q] > bv || (s_v[q] == bv && s_i[q] < bi))) { bv = s_v[q]; bi = s_i[q]; }
+    p.pval[blockIdx.x] = bv;
+    p.pidx[blockIdx.x] = bi;
+  }
+}
+__global__ __launch_bounds__(T_BS) void lu3_pivot_kernel(Lu3Step p, int nwg) {
+  __shared__ double s_v[T_BS / 64];
+  __shared__ int32_t s_i[T_BS / 64];
+  __shared__ double s_x[LW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double best = -1.0;
+  int32_t besti = -1;
+  for (int e = tid; e < nwg; e += T_BS) {
+    const double v = p.pval[e];
+    const int32_t i = (int32_t)p.pidx[e];
+    if (i >= 0 && (v > best || (v == best && i < besti))) { best = v; besti = i; }
+  }
+  wave_argmax(best, besti);
+  if (lane == 0) { s_v[wave] = best; s_i[wave] = besti; }
+  __syncthreads();
+  double bestv = -1.0;
+  int32_t r = -1;
+  for (int q = 0; q < T_BS / 64; ++q)
+    if (s_i[q] >= 0 && (s_v[q] > bestv || (s_v[q] == bestv && s_i[q] < r))) { bestv = s_v[q]; r = s_i[q]; }
+  double* const Y = p.Y;
+  const int64_t ld = p.ld;
+  const int32_t j0 = p.j0, j = p.j0 + p.s;
+  const int s = p.s, w = p.w;
+  const bool valid = (r >= j && (int64_t)r < p.m);
+  if (!valid) r = j;                              // all-NaN column: no interchange (as lu_leaf_kernel)
+  if (tid == 0) {
+    p.ipiv[j] = r;
+    if (!(bestv > 0.0)) atomicCAS(p.info, 0, j + 1);
+  }
+  if (r != j) {
+    for (int32_t c = tid; c < p.l; c += T_BS) {
+      if (c >= j0 && c < j0 + w) continue;
+      double* col = Y + (int64_t)c * ld;
+      const double vj = col[j], vr = col[r];
+      col[j] = vr;
+      col[r] = vj;
+    }
+  }
+  if (tid < LW) {                                 // the leaf's own columns: STORED values travel, row r's become the pivot row
+    const int k = tid;
+    double xr = 0.0;
+    if (k < w) {
+      double* col = Y + (int64_t)(j0 + k) * ld;
+      xr = col[r];
+      if (r != j) col[r] = col[j];
+    }
+    s_x[k] = xr;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    Lu3State* stt = p.stt;
+    double x[LW];
+#pragma unroll
+    for (int k = 0; k < LW; ++k) x[k] = s_x[k];
+    for (int t = 0; t < s; ++t) {
+      const double rp = stt->rp[t];
+      const double lt = (rp != 0.0) ? x[t] * rp : x[t];
+      x[t] = lt;
+      for (int k = t + 1; k < LW; ++k) x[k] -= lt * stt->u[t][k];
+    }
+    for (int k = 0; k < LW; ++k) stt->u[s][k] = x[k];
+    const double piv = x[s];
+    stt->rp[s] = (piv != 0.0) ? 1.0 / piv : 0.0;
+    for (int k = 0; k < w; ++k) Y[j + (int64_t)(j0 + k) * ld] = x[k];      // row j is final: multipliers, then U
+  }
+}
+
+// FUSED: the PREVIOUS leaf (columns j0 - 8 .. j0 - 1, pivot rows in `prev`) was not closed: its columns still hold stored
+// values below its pivots; this pass turns them into multipliers on the way (written back once) -- 8 column reads less per leaf
+template <bool PENDING, bool FUSED>
+__global__ __launch_bounds__(T_BS) void lu3_open_kernel(int32_t jb, Lu3Step p) {
+  static_assert(PENDING || !FUSED, "a block's first leaf has no predecessor to close");
+  double* const Y = p.Y;
+  const int64_t ld = p.ld, m = p.m;
+  const int32_t j0 = p.j0;
+  const int w = p.w;
+  const Lu3State* const prev = p.stt;
+  constexpr int NW = T_BS / 64;
+  __shared__ double Ls[PENDING ? KPMAX * LSP : 1];
+  __shared__ double Us[PENDING ? KPMAX * LW : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kp = j0 - jb;
+  if (PENDING) {     // U12 = L11^-1 A12 of the leaf's columns, by every workgroup for itself (as lu_leaf_kernel does)
+    for (int e = tid; e < kp * kp; e += T_BS) {
+      const int r = e % kp, c = e / kp;
+      Ls[r * LSP + c] = Y[(jb + r) + (int64_t)(jb + c) * ld];
+    }
+    __syncthreads();
+    for (int v = wave; v < LW; v += NW) {
+      double x = (lane < kp && v < w) ? Y[(jb + lane) + (int64_t)(j0 + v) * ld] : 0.0;
+      for (int cp = 0; cp < kp; ++cp) {
+        const double xc = readlane_d(x, __builtin_amdgcn_readfirstlane(cp));
+        if (lane > cp && lane < kp) x -= Ls[lane * LSP + cp] * xc;
+      }
+      if (lane < kp) Us[lane * LW + v] = x;
+    }
+    __syncthreads();
+  }
+  double best = -1.0;
+  int32_t besti = -1;
+  const int64_t stride = (int64_t)gridDim.x * (T_BS * T_R);
+  for (int64_t base = (int64_t)j0 + (int64_t)blockIdx.x * (T_BS * T_R) + tid; base < m; base += stride) {
+    if (!PENDING) {
+      double v[T_R];
+#pragma unroll
+      for (int rr = 0; rr < T_R; ++rr) {
+        const int64_t i = base + rr * T_BS;
+        v[rr] = (i < m) ? fabs(Y[i + (int64_t)j0 * ld]) : -1.0;
+      }
+#pragma unroll
+      for (int rr = 0; rr < T_R; ++rr)
+        if (v[rr] > best) { best = v[rr]; besti = (int32_t)(base + rr * T_BS); }
+    } else {
+      if (FUSED) {     // phase A: the previous leaf's columns become multipliers (the pending loop below re-reads them: L2 hits)
+        double x[T_R][LW];
+#pragma unroll
+        for (int t = 0; t < LW; ++t) {
+          const double* cb = Y + (int64_t)(j0 - LW + t) * ld;
+#pragma unroll
+          for (int rr = 0; rr < T_R; ++rr) {
+            const int64_t i = base + rr * T_BS;
+            x[rr][t] = (i < m) ? cb[i] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < T_R; ++rr) {
+#pragma unroll
+          for (int t = 0; t < LW; ++t) {
+            const double rp = prev->rp[t];
+            const double lt = (rp != 0.0) ? x[rr][t] * rp : x[rr][t];
+            x[rr][t] = lt;
+#pragma unroll
+            for (int k = t + 1; k < LW; ++k) x[rr][k] -= lt * prev->u[t][k];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < LW; ++t) {
+          double* cb = Y + (int64_t)(j0 - LW + t) * ld;
+#pragma unroll
+          for (int rr = 0; rr < T_R; ++rr) {
+            const int64_t i = base + rr * T_BS;
+            if (i < m) cb[i] = x[rr][t];
+          }
+        }
+      }
+      double a[T_R][LW];
+#pragma unroll
+      for (int k = 0; k < LW; ++k) {
+        const double* cb = Y + (int64_t)(j0 + (k < w ? k : 0)) * ld;
+#pragma unroll
+        for (int rr = 0; rr < T_R; ++rr) {
+          const int64_t i = base + rr * T_BS;
+          a[rr][k] = (i < m && k < w) ? cb[i] : 0.0;
+        }
+      }
+      for (int c = 0; c < kp; c += 4) {            // kp is a multiple of the leaf width
+        double lv[4][T_R];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const double* cb = Y + (int64_t)(jb + c + cc) * ld;
+#pragma unroll
+          for (int rr = 0; rr < T_R; ++rr) {
+            const int64_t i = base + rr * T_BS;
+            lv[cc][rr] = (i < m) ? cb[i] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          double u[LW];
+#pragma unroll
+          for (int k = 0; k < LW; ++k) u[k] = Us[(c + cc) * LW + k];
+#pragma unroll
+          for (int rr = 0; rr < T_R; ++rr)
+#pragma unroll
+            for (int k = 0; k < LW; ++k) a[rr][k] -= lv[cc][rr] * u[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < LW; ++k) {
+        if (k < w) {
+          double* cb = Y + (int64_t)(j0 + k) * ld;
+#pragma unroll
+          for (int rr = 0; rr < T_R; ++rr) {
+            const int64_t i = base + rr * T_BS;
+            if (i < m) cb[i] = a[rr][k];
+          }
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < T_R; ++rr) {
+        const int64_t i = base + rr * T_BS;
+        const double av = fabs(a[rr][0]);
+        if (i < m && av > best) { best = av; besti = (int32_t)i; }
+      }
+    }
+  }
+  lu3_step_tail(best, besti, p);                  // step 0 of the leaf
+}
+
+// candidates of column j0 + S1 among the rows below the S1 pivots found so far: read only
+template <int S1>
+__global__ __launch_bounds__(T_BS) void lu3_cand_kernel(Lu3Step p) {      // p.s == S1
+  const double* const Y = p.Y;
+  const int64_t ld = p.ld, m = p.m;
+  const int32_t j0 = p.j0;
+  const Lu3State* const stt = p.stt;
+  double u[S1][S1 + 1], rp[S1];
+#pragma unroll
+  for (int t = 0; t < S1; ++t) {
+    rp[t] = stt->rp[t];
+#pragma unroll
+    for (int k = t + 1; k <= S1; ++k) u[t][k] = stt->u[t][k];
+  }
+  double best = -1.0;
+  int32_t besti = -1;
+  const int64_t stride = (int64_t)gridDim.x * (T_BS * T_R);
+  for (int64_t base = (int64_t)j0 + S1 + (int64_t)blockIdx.x * (T_BS * T_R) + threadIdx.x; base < m; base += stride) {
+    double x[T_R][S1 + 1];
+#pragma unroll
+    for (int k = 0; k <= S1; ++k) {
+      const double* cb = Y + (int64_t)(j0 + k) * ld;
+#pragma unroll
+      for (int rr = 0; rr < T_R; ++rr) {
+        const int64_t i = base + rr * T_BS;
+        x[rr][k] = (i < m) ? cb[i] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < T_R; ++rr) {
+#pragma unroll
+      for (int t = 0; t < S1; ++t) {
+        const double lt = (rp[t] != 0.0) ? x[rr][t] * rp[t] : x[rr][t];
+#pragma unroll
+        for (int k = t + 1; k <= S1; ++k) x[rr][k] -= lt * u[t][k];
+      }
+      const int64_t i = base + rr * T_BS;
+      const double av = fabs(x[rr][S1]);
+      if (i < m && av > best) { best = av; besti = (int32_t)i; }
+    }
+  }
+  lu3_step_tail(best, besti, p);
+}
+
+// the leaf is done: multipliers of every row below its w pivots
+__global__ __launch_bounds__(T_BS) void lu3_close_kernel(double* __restrict__ Y, int64_t ld, int64_t m, int32_t j0, int w,
+                                                         const Lu3State* stt) {
+  double u[LW][LW], rp[LW];
+#pragma unroll
+  for (int t = 0; t < LW; ++t) {
+    rp[t] = stt->rp[t];
+#pragma unroll
+    for (int k = t + 1; k < LW; ++k) u[t][k] = stt->u[t][k];
+  }
+  const int64_t stride = (int64_t)gridDim.x * (T_BS * T_R);
+  for (int64_t base = (int64_t)j0 + w + (int64_t)blockIdx.x * (T_BS * T_R) + threadIdx.x; base < m; base += stride) {
+    double x[T_R][LW];
+#pragma unroll
+    for (int k = 0; k < LW; ++k) {
+      const double* cb = Y + (int64_t)(j0 + (k < w ? k : 0)) * ld;
+#pragma unroll
+      for (int rr = 0; rr < T_R; ++rr) {
+        const int64_t i = base + rr * T_BS;
+        x[rr][k] = (i < m && k < w) ? cb[i] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < T_R; ++rr) {
+#pragma unroll
+      for (int t = 0; t < LW; ++t) {
+        if (t < w) {
+          const double lt = (rp[t] != 0.0) ? x[rr][t] * rp[t] : x[rr][t];
+          x[rr][t] = lt;
+#pragma unroll
+          for (int k = t + 1; k < LW; ++k) x[rr][k] -= lt * u[t][k];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LW; ++k) {
+      if (k < w) {
+        double* cb = Y + (int64_t)(j0 + k) * ld;
+#pragma unroll
+        for (int rr = 0; rr < T_R; ++rr) {
+          const int64_t i = base + rr * T_BS;
+          if (i < m) cb[i] = x[rr][k];
+        }
+      }
+    }
+  }
+}
+
+static int lu3_grid(int64_t rows) {
+  const int64_t per = (int64_t)T_BS * T_R;
+  const int64_t g = (rows + per - 1) / per;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, T_MAXWG));
+}
+}  // namespace
+
+size_t lu3_work_bytes(int64_t l) {
+  return sizeof(double) * T_MAXWG + sizeof(int64_t) * T_MAXWG + sizeof(Lu3State) + sizeof(double) * (size_t)LU2_NB * (size_t)l +
+         sizeof(int32_t) * (size_t)(l + 4) + 512;
+}
+
+void lu3_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, void* work, int32_t* info, int32_t** ipiv_out) {
+  char* base = (char*)work;
+  double* pval = (double*)base; base += sizeof(double) * T_MAXWG;
+  int64_t* pidx = (int64_t*)base; base += sizeof(int64_t) * T_MAXWG;
+  Lu3State* stt = (Lu3State*)base; base += sizeof(Lu3State);
+  double* u12 = (double*)base; base += sizeof(double) * (size_t)LU2_NB * (size_t)l;
+  int32_t* ipiv = (int32_t*)base;
+  *ipiv_out = ipiv;
+  const int nb = LU2_NB;
+  static const bool fuse = !(getenv("GSI_LU_TALL_NOFUSE") != nullptr);     // A/B: every leaf closed by a pass of its own
+  for (int64_t jb = 0; jb < l; jb += nb) {
+    const int b = (int)((l - jb < nb) ? (l - jb) : nb);
+    for (int64_t j0 = jb; j0 < jb + b; j0 += LW) {
+      const int wd = (int)((jb + b - j0 < LW) ? (jb + b - j0) : LW);
+      Lu3Step p{Y, ld, m, (int32_t)l, (int32_t)j0, 0, wd, pval, pidx, stt, ipiv, info};
+      const int g = lu3_grid(m - j0);
+      if (j0 == jb) hipLaunchKernelGGL((lu3_open_kernel<false, false>), dim3(g), dim3(T_BS), 0, st, (int32_t)jb, p);
+      else if (fuse) hipLaunchKernelGGL((lu3_open_kernel<true, true>), dim3(g), dim3(T_BS), 0, st, (int32_t)jb, p);   // closes the leaf before
+      else hipLaunchKernelGGL((lu3_open_kernel<true, false>), dim3(g), dim3(T_BS), 0, st, (int32_t)jb, p);
+      hipLaunchKernelGGL(lu3_pivot_kernel, dim3(1), dim3(T_BS), 0, st, p, g);
+      for (int s1 = 1; s1 < wd; ++s1) {           // candidates of column s1, then its pivot
+        p.s = s1;
+        const int gc = lu3_grid(m - j0 - s1);
+        switch (s1) {
+          case 1: hipLaunchKernelGGL(lu3_cand_kernel<1>, dim3(gc), dim3(T_BS), 0, st, p); break;
+          case 2: hipLaunchKernelGGL(lu3_cand_kernel<2>, dim3(gc), dim3(T_BS), 0, st, p); break;
+          case 3: hipLaunchKernelGGL(lu3_cand_kernel<3>, dim3(gc), dim3(T_BS), 0, st, p); break;
+          case 4: hipLaunchKernelGGL(lu3_cand_kernel<4>, dim3(gc), dim3(T_BS), 0, st, p); break;
+          case 5: hipLaunchKernelGGL(lu3_cand_kernel<5>, dim3(gc), dim3(T_BS), 0, st, p); break;
+          case 6: hipLaunchKernelGGL(lu3_cand_kernel<6>, dim3(gc), dim3(T_BS), 0, st, p); break;
+          default: hipLaunchKernelGGL(lu3_cand_kernel<7>, dim3(gc), dim3(T_BS), 0, st, p); break;
+        }
+        hipLaunchKernelGGL(lu3_pivot_kernel, dim3(1), dim3(T_BS), 0, st, p, gc);
+      }
+      const bool next_opens = fuse && (j0 + wd < jb + b);        // the next leaf of this block closes this one on its way
+      if (m > j0 + wd && !next_opens)
+        hipLaunchKernelGGL(lu3_close_kernel, dim3(lu3_grid(m - j0 - wd)), dim3(T_BS), 0, st, Y, ld, m, (int32_t)j0, wd, stt);
+    }
+    const int64_t c0 = jb + b, t = l - c0;
+    if (t > 0) {                               // the register-resident path's own block update
+      const int64_t mr = m - c0;
+      const unsigned gu = (unsigned)((t + 63) / 64);
+      const unsigned gr = (unsigned)((mr + 127) / 128);
+      hipLaunchKernelGGL(lu_u12_kernel<64>, dim3(gu), dim3(256), 0, st, Y, ld, jb, jb, c0, l, u12);
+      if (mr > 0) launch_rankk<64>(st, gr, Y, ld, m, c0, jb, c0, t, u12);
+    }
+  }
+  int eb = (int)((l * l + 255) / 256);
+  if (eb > 1024) eb = 1024;
+  hipLaunchKernelGGL(lu2_extract_L_kernel, dim3(eb), dim3(256), 0, st, Y, ld, l);
+}
+
+// =====================================================================================================================
 // Row-sharded form of the same factorization ("sharded alternative"): every rank keeps only its rows
 // [row0, row0 + mloc) of the panel; per pivot step the ranks exchange one record each {local max |value|, its global
 // row, that row, row j} (pipeline.cpp:lu_panel_sharded runs the collectives), everything else is row-local.  The

@@ -162,6 +162,14 @@ def lu_L(Y, *, return_pivots=False, ctx=None):
     return (out, piv) if return_pivots else out
 
 
+def lu_L_dev(Y, *, return_pivots=False):
+    """`lu(Y).L` of a device-resident panel (`DeviceMatrix`), in place (`gsi_lu_L_dev`)."""
+    cx = Y.ctx
+    piv = np.empty(Y.shape[1], dtype=np.int32)
+    L.check(cx.lib.gsi_lu_L_dev(cx.h, Y.h, piv.ctypes.data_as(C.POINTER(C.c_int32))), cx.lib)
+    return (Y, piv) if return_pivots else Y
+
+
 def lu_L_sharded(Y, *, return_pivots=False, ctx=None):
     """`lu(Y).L` with the panel row-sharded over the ranks of `ctx`'s communicator (collective; every rank passes the
     whole panel and receives the whole L): bit-identical to `lu_L`."""

@@ -406,6 +406,12 @@ function lu_L(Y::Matrix{Float64}; c::Context=ctx())
 		c.h, Y, m, l, Lout, piv))
 	return Lout, piv .+ Int32(1)
 end
+"`lu(Y).L` of a device-resident panel, in place (`gsi_lu_L_dev`): returns the 1-based pivot rows."
+function lu_L!(Y::DeviceMatrix)
+	piv = Vector{Int32}(undef, Y.cols)
+	check(ccall((:gsi_lu_L_dev, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}), Y.c.h, Y.h, piv))
+	return piv .+ Int32(1)
+end
 "`Matrix(qr(Y, Val(true)).Q)` up to an orthogonal change of basis (`gsi_qr_thinQ`): returns (Q, R) with Y = Q R."
 function qr_thinQ(Y::Matrix{Float64}; c::Context=ctx())
 	m, l = size(Y)

@@ -1044,6 +1044,70 @@ def test_lu_headline_height_matches_lapack(gsi, ctx, m, l, ties):
     assert np.abs(L - Lref).max() < 1e-11 * max(1.0, np.abs(Lref).max())
 
 
+# ---- panels taller than the register-resident path holds (> 4096 rows per CU = 1 048 576 rows): streamed leaves with lazily
+#      evaluated candidates (panel_lu_leaf.hip: lu3_*).  (a) Forced onto panels the resident kernel also takes
+#      (GSI_LU_TALL=1): the factors must be BIT-identical to the resident kernel's and the pivots dgetrf's -- ties, several
+#      64-column blocks, a ragged last leaf, tiny panels; (b) a panel that only this path takes, against dgetrf. ------------
+@pytest.mark.gpu
+def test_lu_streamed_leaves_bit_identical_to_resident(gsi, tmp_path):
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import gsi_amd as gsi
+from oracle import oracle as orc
+out = sys.argv[1]
+ctx = gsi.Context(0)
+res = {}
+for idx, (m, l, ties) in enumerate([(100, 25, False), (9, 2, False), (64, 64, False), (5000, 160, True), (3000, 33, True),
+                                    (300000, 136, True), (70001, 72, False), (600001, 24, True)]):
+    rng = np.random.default_rng(m + l)
+    Y = rng.standard_normal((m, l))
+    if ties and m >= 3000:
+        Y[1500:1600] = Y[100:200]
+        for j in range(0, l, 5):
+            r = rng.choice(m, size=3, replace=False)
+            Y[r, j] = [9.5, -9.5, 9.5]
+    L, piv = gsi.lu_L(Y, return_pivots=True, ctx=ctx)
+    assert np.array_equal(piv, orc.lu_pivots(Y)), (m, l)
+    if m <= 70001:
+        Lref = orc.lu_L(Y)
+        assert np.abs(L - Lref).max() < 1e-10 * max(1.0, np.abs(Lref).max()), (m, l)
+    res["L%d" % idx] = L
+    res["p%d" % idx] = piv
+np.savez(out, **res)
+print("lu-ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (("resident", {}), ("streamed", {"GSI_LU_TALL": "1"})):
+        env = dict(os.environ)
+        env.update(extra)
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0 and "lu-ok" in r.stdout, tag + "\n" + r.stdout[-2000:] + r.stderr[-4000:]
+        outs.append(np.load(f))
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,l", [(1300000, 24), (1048577, 72)])
+def test_lu_taller_than_the_register_file_matches_lapack(gsi, ctx, m, l):
+    rng = np.random.default_rng(m + l)
+    Y = rng.standard_normal((m, l))
+    for j in range(0, l, 3):                       # equal-magnitude maxima far apart: the lowest row must win
+        r = rng.choice(m, size=3, replace=False)
+        Y[r, j] = [7.5, -7.5, 7.5]
+    L, piv = gsi.lu_L(Y, return_pivots=True, ctx=ctx)
+    assert np.array_equal(piv, orc.lu_pivots(Y))
+    Lref = orc.lu_L(Y)
+    assert np.abs(L - Lref).max() < 1e-11 * max(1.0, np.abs(Lref).max())
+    assert np.all(np.triu(L[:l], 1) == 0.0) and np.all(np.diag(L[:l]) == 1.0)
+
+
 # ---- the row-sharded LU with REAL row offsets on one GPU (ADVICE round 2): G virtual ranks, every lus_* kernel launched with
 #      its shard's row0 / mloc, the exchanges as device copies; bit-identical to the single-rank factorization.  Cases: a
 #      pivot search that crosses shards, ties across the shard boundary (the lowest global row must win), a ragged last
@@ -1068,7 +1132,7 @@ def test_lu_sharded_virtual_ranks_bit_identical(gsi, ctx, m, l, G):
 
 # ---- the persistent leaf kernel's time-out path (info = -1): one workgroup stays silent at a pivot step (test knob), every
 #      other workgroup runs out of polls, the launch drains, the call fails with GSI_ERR_INTERNAL (GSI_NO_RETRY) -- and
-#      without that switch the entry point re-runs on the per-column sweeps and returns LAPACK's factorization.  Then: two
+#      without that switch the entry point re-runs on the streamed leaves (no spin-waits) and returns LAPACK's factorization.  Then: two
 #      contexts on ONE GPU factoring concurrently (plain launches may interleave their workgroups; whatever happens both
 #      results must be dgetrf's). ---------------------------------------------------------------------------------------
 @pytest.mark.gpu
@@ -1093,7 +1157,7 @@ try:
     raise SystemExit("the muted exchange did not time out")
 except gsi.GsiError as e:
     assert e.code == 8 and "timed out" in str(e), str(e)
-L2, p2 = gsi.lu_L(Y, return_pivots=True, ctx=ctx)          # the context has switched to the sweeps
+L2, p2 = gsi.lu_L(Y, return_pivots=True, ctx=ctx)          # the context has switched to the streamed leaves
 assert np.array_equal(p2, pref) and np.abs(L2 - Lref).max() < 1e-11
 del os.environ["GSI_NO_RETRY"]
 ctx3 = gsi.Context(0)                                       # fresh context: time-out, then the automatic re-run
