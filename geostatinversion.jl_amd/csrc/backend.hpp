@@ -209,6 +209,10 @@ class Comm {
   // every rank hands in a device buffer; all[g] = rank g's buffer as THIS rank can address it (same process: the pointer
   // itself; other processes: an IPC mapping).  false: not supported by this communicator.  Collective.
   virtual bool share_pointers(void* mine, size_t bytes, void** all) { (void)mine; (void)bytes; (void)all; return false; }
+  // ranks of this communicator that run on the SAME device as this one (itself included).  1 with RCCL (it refuses two ranks
+  // on one device); the RCCL-free communicators allow any placement, and kernels that need all their workgroups resident
+  // at once (the persistent LU leaves) must share the chip between that many launches.
+  virtual int ranks_on_my_device() { return 1; }
 };
 
 // Provided by whichever backend is linked into the library.

@@ -532,7 +532,8 @@ class HipBackend : public Backend {
     const int G = comm->nranks;
     const int64_t pad = (m + G - 1) / G;
     hipk::Lu2MrWork w{};
-    if (!hipk::lu2_mr_config(pad, G, ncus_, &w.bs, &w.rpt, &w.grid)) return false;
+    const int sharing = std::max(comm->ranks_on_my_device(), 1);     // > 1 only with the RCCL-free communicators: the leaf grids of
+    if (!hipk::lu2_mr_config(pad, G, ncus_ / sharing, &w.bs, &w.rpt, &w.grid, &w.hier)) return false;   // all of them must fit the chip
     const int key = 1000000 + w.bs * 16 + w.rpt;
     auto it = lu2_resident_.find(key);
     if (it == lu2_resident_.end()) it = lu2_resident_.emplace(key, hipk::lu2_mr_resident_per_cu(w.bs, w.rpt)).first;
@@ -553,6 +554,7 @@ class HipBackend : public Backend {
       for (int g = 0; g < G; ++g) mr_peer_[g] = (unsigned long long*)all[g];
       mr_comm_ = comm;
     }
+    if ((int64_t)it->second * ncus_ < (int64_t)w.grid * sharing) return false;
     w.rank = comm->rank; w.nranks = G;
     for (int g = 0; g < G; ++g) w.peer[g] = mr_peer_[g];
     w.info = flags_ + 0;
@@ -1183,6 +1185,7 @@ struct LocalGroup {
   int arrived = 0;
   uint64_t generation = 0;
   std::vector<const double*> src;
+  std::vector<int> device;               // device of every rank's context
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const uint64_t gen = generation;
@@ -1199,11 +1202,14 @@ class LocalComm : public Comm {
     nranks = n;
     rank = r;
     const std::string key((const char*)id, 32);
-    std::lock_guard<std::mutex> g(g_local_mu);
+    std::unique_lock<std::mutex> lk(g_local_mu);
     auto& grp = g_local_groups[key];
-    if (!grp) { grp = std::make_shared<LocalGroup>(); grp->nranks = n; grp->src.assign((size_t)n, nullptr); }
+    if (!grp) { grp = std::make_shared<LocalGroup>(); grp->nranks = n; grp->src.assign((size_t)n, nullptr); grp->device.assign((size_t)n, -1); }
     if (grp->nranks != n) throw Error(GSI_ERR_ARG, "local communicator: ranks disagree on nranks");
+    grp->device[(size_t)r] = be_->device();
     grp_ = grp;
+    lk.unlock();
+    grp_->barrier();                      // like ncclCommInitRank: returns when every rank has joined (and registered its device)
     for (int d = 0, cnt = 0; hipGetDeviceCount(&cnt) == hipSuccess && d < cnt; ++d)      // best effort: peers on other GPUs
       if (d != be_->device()) { (void)hipDeviceEnablePeerAccess(d, 0); (void)hipGetLastError(); }
   }
@@ -1255,6 +1261,12 @@ class LocalComm : public Comm {
     finish();
     return true;
   }
+  int ranks_on_my_device() override {
+    std::lock_guard<std::mutex> g(grp_->mu);
+    int c = 0;
+    for (int q = 0; q < nranks; ++q) c += (grp_->device[(size_t)q] == be_->device()) ? 1 : 0;
+    return std::max(c, 1);
+  }
 
  private:
   HipBackend* be_;
@@ -1273,6 +1285,7 @@ struct ShmBlock {
   std::atomic<uint32_t> arrived;
   std::atomic<uint32_t> generation;
   uint32_t ok[16];
+  char busid[16][32];                    // PCI bus id of every rank's device
   hipIpcMemHandle_t stage[16];
   hipIpcMemHandle_t shared[16];
 };
@@ -1308,6 +1321,11 @@ class ShmComm : public Comm {
     if (!ok) (void)hipGetLastError();
     blk_->stage[rank] = h;
     blk_->ok[rank] = ok ? 1u : 0u;
+    std::memset(blk_->busid[rank], 0, sizeof(blk_->busid[rank]));
+    if (hipDeviceGetPCIBusId(blk_->busid[rank], (int)sizeof(blk_->busid[rank]) - 1, be_->device()) != hipSuccess) {
+      (void)hipGetLastError();
+      snprintf(blk_->busid[rank], sizeof(blk_->busid[rank]), "device-%d", be_->device());
+    }
     barrier();
     if (rank == 0) shm_unlink(name);                            // every rank has it mapped: nothing is left behind in /dev/shm
     for (int g = 0; g < nranks; ++g) ok = ok && blk_->ok[g] != 0;
@@ -1320,7 +1338,9 @@ class ShmComm : public Comm {
     barrier();                                                  // ok[] is reused by share_pointers
     if (!ok) { cleanup(); throw Error(GSI_ERR_RCCL, "shared-memory communicator: the ranks' staging buffers could not be mapped (hipIpc)"); }
     for (int g = 0; g < nranks; ++g) peer_[g] = (const double*)all[g];
+    for (int g = 0; g < nranks; ++g) same_device_ += (std::strncmp(blk_->busid[g], blk_->busid[rank], sizeof(blk_->busid[g])) == 0) ? 1 : 0;
   }
+  int ranks_on_my_device() override { return std::max(same_device_, 1); }
   ~ShmComm() override {
     be_->bind();
     (void)hipStreamSynchronize(be_->stream());
@@ -1448,6 +1468,7 @@ class ShmComm : public Comm {
   size_t cap_ = 0;
   const double* peer_[16] = {nullptr};
   std::vector<void*> opened_;
+  int same_device_ = 0;
   int timeout_s_ = 300;
 };
 static bool shm_comm_requested() { return getenv("GSI_SHM_COMM") != nullptr; }

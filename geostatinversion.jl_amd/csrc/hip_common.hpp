@@ -96,9 +96,10 @@ struct Lu2MrWork {
   int32_t* ipiv;                             // [l] this rank's copy of the pivot rows (identical on every rank)
   int32_t* info;
   int rank, nranks, bs, rpt, grid;
+  int hier = 0;                              // two-hop exchange (ranks reduce among their own workgroups first)
   int poll_limit = 0;
 };
-bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid);
+bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier);
 int lu2_mr_resident_per_cu(int bs, int rpt);
 size_t lu2_mr_record_granules(int nranks, int grid);
 void lu2_leaf_mr(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l,

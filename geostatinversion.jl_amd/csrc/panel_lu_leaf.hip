@@ -147,8 +147,15 @@ __device__ unsigned long long g_lu_trace[4 * 8 * 8];
 // into EVERY rank's record buffer (peer-mapped memory, system-scope stores; pollers read their own memory only).  Rank 0
 // owns the diagonal block.  U12 of the pending update comes ready-made (rank 0 solved it, the host sequenced an
 // all-reduce); the interchange of the columns outside the leaf is done after the launch (lus_swaps_*).
+// MR, hier (shards of more than 256 / nranks workgroups: weak scaling, 10^6 rows per rank): TWO hops.  A workgroup publishes
+// into its OWN rank's buffer only (slots 0 .. grid - 1) and every workgroup reduces its rank's records exactly as the
+// single-GPU kernel does; workgroup 0 of each rank then writes the rank's result {max, row, its 8 values, row j's 8 values}
+// into every rank's buffer (slots grid + rank), and every workgroup polls those nranks records: one more store latency
+// across the fabric per pivot step, and the number of records a workgroup polls stays <= 256.
 struct LuMrArgs {
   int rank, nranks;
+  int hier;                                  // two-hop exchange for shards too tall for nranks x grid <= 256 records (see below)
+  int slots;                                 // record slots of the exchange: nranks * grid, or (hier) grid + nranks
   int32_t gbase, mtot;
   const double* us;                          // kp x LW, [c * LW + k]
   unsigned long long* peer[LU2_MAX_RANKS];   // every rank's record buffer (peer[rank] == recs)
@@ -179,8 +186,10 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x;
   const int Gl = gridDim.x;                                 // this rank's workgroups
-  const int G = MR ? Gl * mr.nranks : Gl;                   // records in the exchange
-  const int gslot = MR ? mr.rank * Gl + g : g;              // this workgroup's record
+  const bool hier = MR && mr.hier != 0;
+  const int G = MR ? mr.slots : Gl;                         // record slots of the exchange (layout of the buffer)
+  const int GP = hier ? Gl : G;                             // records a workgroup polls in the (first) hop
+  const int gslot = MR ? (hier ? g : mr.rank * Gl + g) : g; // this workgroup's record
   const int32_t gbase = MR ? mr.gbase : 0;                  // global index of local row 0
   const int32_t mtot = MR ? mr.mtot : m;
   const int kp = j0 - jb;
@@ -381,9 +390,14 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
         else bits = (unsigned long long)__double_as_longlong(s_oldpub[unit - 2 - LW]);
         const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
         if constexpr (MR) {
-          for (int q = 0; q < mr.nranks; ++q)      // one copy into every rank's buffer: remote stores, local polls
-            __hip_atomic_store(mr.peer[q] + set_off + (size_t)gslot * REC + lane, ((unsigned long long)epoch << 32) | half,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (hier) {                              // first hop stays on this rank
+            __hip_atomic_store(rec_set + (size_t)gslot * REC + lane, ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+          } else {
+            for (int q = 0; q < mr.nranks; ++q)    // one copy into every rank's buffer: remote stores, local polls
+              __hip_atomic_store(mr.peer[q] + set_off + (size_t)gslot * REC + lane, ((unsigned long long)epoch << 32) | half,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
         } else {
           __hip_atomic_store(rec_set + (size_t)g * REC + lane, ((unsigned long long)epoch << 32) | half,
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -401,9 +415,9 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
     // (255 workgroups polling the same three lines serialise on one memory channel)
     unsigned long long* res = recs + (size_t)2 * (size_t)G * REC + (size_t)(epoch & 1u) * (size_t)LU2_RES_COPIES * REC;
     if (onehop) {
-      const int ncw1 = (G + 63) / 64;                                      // one lane per record
+      const int ncw1 = (GP + 63) / 64;                                     // one lane per record
       if (wave < ncw1) {
-        const bool mine = tid < G;
+        const bool mine = tid < GP;
         const unsigned long long* src = rec_set + (size_t)(mine ? tid : 0) * REC;
         const bool extra = tid < 2 * LW;                                    // workgroup 0's copy of row j
         const unsigned long long* xsrc = rec_set + 2 * (2 + LW) + (extra ? tid : 0);
@@ -466,6 +480,73 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
         if (lane == 0) { c_val[0] = fv; c_idx[0] = fi; }
       }
       __syncthreads();
+      if constexpr (MR) {
+        if (hier) {                               // second hop: the ranks' results (slots Gl .. Gl + nranks - 1 of every buffer)
+          if (wave == 0) {
+            if (g == 0) {                         // this rank's result, one granule per lane, into every rank's buffer
+              const int unit = lane >> 1;
+              if (unit < 2 + 2 * LW) {
+                unsigned long long bits;
+                if (unit == 0) bits = (unsigned long long)__double_as_longlong(c_val[0]);
+                else if (unit == 1) bits = (unsigned long long)(long long)c_idx[0];
+                else if (unit < 2 + LW) bits = reinterpret_cast<const unsigned long long*>(c_rowbits[0])[unit - 2];
+                else bits = reinterpret_cast<const unsigned long long*>(c_oldbits)[unit - 2 - LW];
+                const uint32_t half = (lane & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+                for (int q = 0; q < mr.nranks; ++q)
+                  __hip_atomic_store(mr.peer[q] + set_off + (size_t)(Gl + mr.rank) * REC + lane, ((unsigned long long)epoch << 32) | half,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              }
+            }
+            const bool rmine = lane < mr.nranks;
+            const unsigned long long* src = rec_set + (size_t)(Gl + (rmine ? lane : 0)) * REC;
+            unsigned long long g0 = 0, g1 = 0, g2 = 0;
+            int tries = s_abort ? poll_limit : 0;
+            bool ok;
+            for (;;) {
+              if (rmine) {
+                g0 = poll_granule<true>(src + 0);
+                g1 = poll_granule<true>(src + 1);
+                g2 = poll_granule<true>(src + 2);
+              }
+              ok = !rmine || ((uint32_t)(g0 >> 32) == epoch && (uint32_t)(g1 >> 32) == epoch && (uint32_t)(g2 >> 32) == epoch);
+              if (__all(ok)) break;
+              if (++tries > poll_limit) break;
+              __builtin_amdgcn_s_sleep(1);
+            }
+            if (!__all(ok)) s_abort = 1;
+            double cv = -1.0;
+            int32_t ci = -1;
+            if (rmine) {
+              cv = __longlong_as_double((long long)(((unsigned long long)(uint32_t)g1 << 32) | (uint32_t)g0));
+              ci = (int32_t)(uint32_t)g2;
+            }
+            double rv = cv;
+            int32_t ri = ci;
+            wave_argmax(rv, ri);
+            const unsigned long long own = __ballot(rmine && ri >= 0 && ci == ri);
+            const int qw = own ? (__ffsll((long long)own) - 1) : 0;
+            // the winner's 8 row values (its rank's record) and row j's (rank 0's record): 16 granules each, one per lane
+            const bool vmine = lane < 2 * LW, omine = lane >= 32 && lane < 32 + 2 * LW;
+            const unsigned long long* vsrc = rec_set + (size_t)(Gl + qw) * REC + 4 + (vmine ? lane : 0);
+            const unsigned long long* osrc = rec_set + (size_t)Gl * REC + 2 * (2 + LW) + (omine ? lane - 32 : 0);
+            unsigned long long gv = 0;
+            tries = s_abort ? poll_limit : 0;
+            for (;;) {
+              if (vmine) gv = poll_granule<true>(vsrc);
+              if (omine) gv = poll_granule<true>(osrc);
+              ok = !(vmine || omine) || ((uint32_t)(gv >> 32) == epoch);
+              if (__all(ok)) break;
+              if (++tries > poll_limit) break;
+              __builtin_amdgcn_s_sleep(1);
+            }
+            if (!__all(ok)) s_abort = 1;
+            if (vmine) c_rowbits[0][lane] = (uint32_t)gv;
+            if (omine) c_oldbits[lane - 32] = (uint32_t)gv;
+            if (lane == 0) { c_val[0] = rv; c_idx[0] = ri; }
+          }
+          __syncthreads();
+        }
+      }
     } else
     {
     const int ncw = leader ? (G * LPR + 63) / 64 : 1;                     // waves that hold entries of the reduction
@@ -856,14 +937,24 @@ int lu2_resident_per_cu(int bs, int rpt) {
 // ---- the leaf launch of the MULTI-RANK factorization: this rank's rows, G = w.grid workgroups per rank, records exchanged
 //      through every rank's peer-mapped buffer.  Launch geometry for shards of at most `pad` rows on `nranks` ranks:
 //      nranks * grid <= 256 records, every rank the same (bs, rpt, grid).
-bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid) {
+bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier) {
   if (nranks < 1 || nranks > LU2_MAX_RANKS) return false;
-  const int gmax = std::min(256 / nranks, ncus);
   static const int cfg[4][2] = {{256, 1}, {256, 4}, {512, 4}, {512, 8}};
-  for (int c = 0; c < 4; ++c) {
+  static const char* he = getenv("GSI_LU_MR_HIER");              // 1: always two hops (tests), 0: never
+  const bool force_hier = he != nullptr && he[0] == '1', no_hier = he != nullptr && he[0] == '0';
+  // one hop: every workgroup of every rank is a record of the exchange (nranks * grid <= 256)
+  const int gmax = std::min(256 / nranks, ncus);
+  for (int c = 0; c < 4 && !force_hier; ++c) {
     const int64_t per = (int64_t)cfg[c][0] * cfg[c][1];
     const int64_t g = (pad + per - 1) / per;
-    if (g <= gmax) { *bs = cfg[c][0]; *rpt = cfg[c][1]; *grid = (int)std::max<int64_t>(g, 1); return true; }
+    if (g <= gmax) { *bs = cfg[c][0]; *rpt = cfg[c][1]; *grid = (int)std::max<int64_t>(g, 1); *hier = 0; return true; }
+  }
+  // two hops: a rank's workgroups reduce among themselves first (grid + nranks <= 256 record slots)
+  const int gmax2 = std::min(256 - nranks, ncus);
+  for (int c = 0; c < 4 && !no_hier && nranks > 1; ++c) {
+    const int64_t per = (int64_t)cfg[c][0] * cfg[c][1];
+    const int64_t g = (pad + per - 1) / per;
+    if (g <= gmax2) { *bs = cfg[c][0]; *rpt = cfg[c][1]; *grid = (int)std::max<int64_t>(g, 1); *hier = 1; return true; }
   }
   return false;
 }
@@ -872,6 +963,7 @@ static void launch_leaf_mr_t(hipStream_t st, const Lu2MrWork& w, double* Y, int6
                              int64_t l, int64_t jb, int64_t j0, int wd, const double* us, uint32_t epoch_base) {
   LuMrArgs a{};
   a.rank = w.rank; a.nranks = w.nranks; a.gbase = (int32_t)row0; a.mtot = (int32_t)m; a.us = us;
+  a.hier = w.hier; a.slots = w.hier ? w.grid + w.nranks : w.nranks * w.grid;
   for (int q = 0; q < w.nranks; ++q) a.peer[q] = w.peer[q];
   const int poll_limit = w.poll_limit > 0 ? w.poll_limit : POLL_LIMIT;
   hipLaunchKernelGGL((lu_leaf_kernel<BS, R, true>), dim3(w.grid), dim3(BS), 0, st, Y, ld, (int32_t)mloc, (int32_t)l, (int32_t)jb,
@@ -1067,7 +1159,7 @@ void lus_swap_peer(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, in
   a.rank = w.rank; a.nranks = w.nranks; a.gbase = (int32_t)row0; a.mtot = (int32_t)m; a.us = nullptr;
   for (int q = 0; q < w.nranks; ++q) a.peer[q] = w.peer[q];
   const int64_t pad = (m + w.nranks - 1) / w.nranks;
-  const size_t G = (size_t)w.nranks * (size_t)w.grid;
+  const size_t G = w.hier ? (size_t)w.grid + (size_t)w.nranks : (size_t)w.nranks * (size_t)w.grid;
   const size_t box = (size_t)2 * G * REC + (size_t)2 * (2 * KPMAX * LW) + (size_t)((epoch_base >> 3) & 1u) * ((size_t)2 * LW * 2 * LU2_MR_MAXL);
   const int poll_limit = w.poll_limit > 0 ? w.poll_limit : POLL_LIMIT;
   const int g = (int)std::min<int64_t>((l + 255) / 256, 64);

@@ -1492,18 +1492,25 @@ def _join_multirank(procs, marker, timeout=900):
         assert pr.returncode == 0 and marker in so, "rank %d\n" % r + so[-3000:] + se[-4000:]
 
 
+# hier: the sharded LU's TWO-hop pivot exchange (ranks reduce among their own workgroups, then exchange one record per rank:
+# what shards of more than 256 / nranks workgroups take -- 10^6 rows per rank), forced onto these small shards
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_multirank_pipeline_on_one_gpu(gsi, world):
-    _join_multirank([_spawn_multirank(_MULTIRANK_THREADS, [world], {"GSI_LOCAL_COMM": "1"})], "multirank-one-gpu-ok")
+@pytest.mark.parametrize("world,hier", [(2, False), (3, False), (2, True)])
+def test_multirank_pipeline_on_one_gpu(gsi, world, hier):
+    env = {"GSI_LOCAL_COMM": "1"}
+    if hier:
+        env["GSI_LU_MR_HIER"] = "1"
+    _join_multirank([_spawn_multirank(_MULTIRANK_THREADS, [world], env)], "multirank-one-gpu-ok")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_multirank_processes_on_one_gpu(gsi, world, tmp_path):
+@pytest.mark.parametrize("world,hier", [(2, False), (3, False), (3, True)])
+def test_multirank_processes_on_one_gpu(gsi, world, hier, tmp_path):
     """One PROCESS per rank, all on GPU 0: what the rank threads cannot cover -- hipIpc mappings of another process's buffers,
     and persistent kernels of different processes exchanging pivots through them."""
     env = {"GSI_SHM_COMM": "1", "GSI_SHM_TIMEOUT_S": "120"}
+    if hier:
+        env["GSI_LU_MR_HIER"] = "1"
     _join_multirank([_spawn_multirank(_MULTIRANK_PROCESS, [world, r, str(tmp_path)], env) for r in range(world)],
                     "multirank-processes-ok")
 
