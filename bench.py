@@ -265,6 +265,62 @@ def secondary_pointcov(gsi, ctx, barrier):
         "max_rel_diff_vs_table_operator": float(np.abs(cols["points"] - cols["table"]).max() / np.abs(cols["table"]).max())}
 
 
+def secondary_pcgalsqr_c5(gsi, ctx, barrier):
+    """BASELINE.json configs[4] on one GPU: a 10^6-parameter synthetic inversion by pcgalsqr (lsqr.jl:20-63) with the xi-basis
+    resident in HBM -- K = 256 vectors from randsvd of a LowRankCovMatrix -- stored in fp64 and in fp32 ("fp32 mixed
+    precision, tolerance vs fp64 reference"): two PCGA iterations each, forward model h(s) = (s .* x)[observed points]
+    (test/testrpcga.jl:110-112) on the host, nobs = 4096.  The time is end-to-end, i.e. mostly the K + 3 = 259 forward runs
+    per iteration and the 2 GB of perturbed fields that travel to the host for them (user code in the reference too)."""
+    import numpy as np
+    import scipy.sparse as sp
+    n, Ns, K, p, q, nobs = 1000000, 256, 256, 64, 1, 4096
+    op = gsi.lowrank_synthetic_operator(ctx, n, Ns, seed=3, decay=0.75)
+    Om = gsi.DeviceMatrix(ctx, n, K + p).randn(9)
+    Z = gsi.DeviceMatrix(ctx, n, K + p)
+    barrier()
+    t0 = time.perf_counter()
+    gsi._lib.check(ctx.lib.gsi_randsvd_dev(ctx.h, op.h, Om.h, K, p, q, Z.h, None), ctx.lib)
+    barrier()
+    t_basis = time.perf_counter() - t0
+    Om.close()
+    op.close()
+    b64 = gsi.DeviceBasis(Z, K)
+    b32 = gsi.DeviceBasis(Z, K, precision=32)
+    rng = np.random.default_rng(8)
+    idx = np.arange(nobs) * (n // nobs) + 17
+    xw = 1.0 + 0.1 * rng.standard_normal(n)
+    forward = lambda sv: (sv * xw)[idx]
+    X = np.full(n, 2.0)
+    coef = rng.standard_normal(6) * 3.0
+    truth = X + sum(c * b64[i] for i, c in enumerate(coef))
+    noise = 1e-4
+    y = forward(truth) + noise * rng.standard_normal(nobs)
+    R = noise ** 2 * sp.identity(nobs, format="csc")
+    out = {}
+    sols = {}
+    for tag, basis in (("fp64", b64), ("fp32", b32)):
+        barrier()
+        t0 = time.perf_counter()
+        sols[tag] = gsi.pcgalsqr(forward, X.copy(), X, basis, R, y, maxiters=2)
+        barrier()
+        out[f"seconds_2_iterations_{tag}_basis"] = time.perf_counter() - t0
+    mis0 = float(np.linalg.norm(forward(X) - y))
+    res = {"workload": f"pcgalsqr, n = {n} parameters, K = {K} xi-vectors resident in HBM (randsvd of a LowRankCovMatrix over {Ns} samples, "
+                       f"p = {p}, q = {q}), nobs = {nobs}, 2 iterations, host forward model (BASELINE.json configs[4] on one GPU)",
+           "basis_randsvd_ms": 1e3 * t_basis,
+           "fp32_vs_fp64_rel_diff": float(np.linalg.norm(sols["fp32"] - sols["fp64"]) / np.linalg.norm(sols["fp64"])),
+           "fp32_vs_fp64_tolerance": 1e-5,
+           "misfit_reduction_fp64": float(np.linalg.norm(forward(sols["fp64"]) - y)) / mis0,
+           "misfit_reduction_fp32": float(np.linalg.norm(forward(sols["fp32"]) - y)) / mis0,
+           "rel_error_vs_truth_fp64": float(np.linalg.norm(sols["fp64"] - truth) / np.linalg.norm(truth - X)),
+           "basis_bytes_fp64": 8.0 * n * K, "basis_bytes_fp32": 4.0 * n * K}
+    res.update(out)
+    b32.close()
+    b64.close()
+    Z.close()
+    return res
+
+
 def secondary_fft_512cube(gsi, ctx, barrier):
     """BASELINE.json configs[2]'s own grid: 512^3 points (n = 1.34e8), FFTRF convention (512 is a power of two: exactly
     FFTRF.jl:83-90's 1024^3 embedding), at the sketch width one GPU's 288 GB hold (four n x l fp64 panels of 51 GB +
@@ -551,6 +607,7 @@ def main():
         guarded("implicit_dense_1e6", lambda: secondary_implicit(gsi, ctx, barrier))
         guarded("fft_powerlaw_1000sq", lambda: secondary_fft_1000sq(gsi, ctx, barrier))
         guarded("pointcov_implicit_2e5", lambda: secondary_pointcov(gsi, ctx, barrier))
+        guarded("pcgalsqr_c5_1e6", lambda: secondary_pcgalsqr_c5(gsi, ctx, barrier))
         if not args.no_fft_512cube:
             guarded("fft_powerlaw_512cube", lambda: secondary_fft_512cube(gsi, ctx, barrier))
         out["secondary"] = sec
