@@ -170,6 +170,45 @@ def cpu_baseline_and_parity(gsi, ctx, Ns, K, p, q, n_s, decay):
     }, err, xerr
 
 
+def secondary_c1(gsi, ctx, barrier):
+    """BASELINE.json configs[0] -- the reference's own CPU-runnable case: dense 2000 x 2000 Gaussian covariance (50 x 40 grid,
+    ell = 5), K = 32, p = 16, q = 1 (test/testrmf.jl path).  HIP (matrix and Omega resident in HBM, median of 50 steps)
+    beside the oracle on this box's host cores, and the distance between the two on the same Omega."""
+    import numpy as np
+    from oracle import oracle as orc
+    from helpers import gaussian_cov, rel_sv_err
+    nx, ny, K, p, q = 50, 40, 32, 16, 1
+    n, l = nx * ny, K + p
+    A = gaussian_cov(nx, ny, 5.0)
+    Om = np.asfortranarray(np.random.default_rng(1).standard_normal((n, l)))
+    op = gsi.dense_operator(ctx, A)
+    Omd = gsi.DeviceMatrix.from_host(ctx, Om)
+    Z = gsi.DeviceMatrix(ctx, n, l)
+    S = gsi.DeviceMatrix(ctx, l, 1)
+    step = lambda: gsi._lib.check(ctx.lib.gsi_randsvd_dev(ctx.h, op.h, Omd.h, K, p, q, Z.h, S.h), ctx.lib)
+    for _ in range(3):
+        step()
+    ts = []
+    for _ in range(50):
+        barrier()
+        t0 = time.perf_counter()
+        step()
+        barrier()
+        ts.append(time.perf_counter() - t0)
+    Zh, Sh = Z.to_host(), S.to_host()[:, 0].copy()
+    for m in (Omd, Z, S, op):
+        m.close()
+    tc = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        Zr, Sr, _ = orc.randsvd_full(A, K, p, q, Om)
+        tc.append(time.perf_counter() - t0)
+    return {"workload": f"dense fp64 {n}x{n} Gaussian covariance (50x40 grid, ell=5), K={K}, p={p}, q={q} (BASELINE.json configs[0])",
+            "ms_per_step": 1e3 * sorted(ts)[len(ts) // 2], "GB/s": dense_bytes(n, l, q) / sorted(ts)[len(ts) // 2] / 1e9,
+            "oracle_ms_per_step": 1e3 * sorted(tc)[len(tc) // 2], "oracle_threads": host_threads(),
+            "sv_rel_err": rel_sv_err(Sh, Sr, K), "xis_err_up_to_sign": orc.xis_error_up_to_sign(Zh, Zr, K)}
+
+
 def secondary_c2(gsi, ctx, barrier):
     """BASELINE.json configs[1]: dense fp64 65536^2 Gaussian covariance, K = 128, p = 32, q = 2."""
     g, K2, p2, q2 = 256, 128, 32, 2
@@ -603,6 +642,8 @@ def main():
                 for ch in list(ctx._children):             # whatever the failed workload left on the device
                     ch.close()
 
+        if not args.no_cpu_baseline:                        # (it times the oracle beside the GPU)
+            guarded("c1_dense_2000", lambda: secondary_c1(gsi, ctx, barrier))
         guarded("c2_dense_65536", lambda: secondary_c2(gsi, ctx, barrier))
         guarded("implicit_dense_1e6", lambda: secondary_implicit(gsi, ctx, barrier))
         guarded("fft_powerlaw_1000sq", lambda: secondary_fft_1000sq(gsi, ctx, barrier))
