@@ -537,6 +537,30 @@ def test_implicit_gridcov_products(gsi, ctx, nx, ny, l):
 
 
 @pytest.mark.gpu
+def test_implicit_gridcov_at_the_headline_size(gsi, ctx):
+    """The 10^6 x 10^6 implicit covariance of the bench (1000 x 1000 grid, exp(-d / 100)) cannot be compared with a stored
+    matrix; rows of it can: A*X and A'*X for 16 columns against exp(-d(i, .) / 100) . X computed on the host for rows at both
+    ends, around the 32-bit row * column boundaries and at random."""
+    g, ell, l = 1000, 100.0, 16
+    n = g * g
+    rng = np.random.default_rng(5)
+    X = np.asfortranarray(rng.standard_normal((n, l)))
+    op = gsi.gridcov_implicit_operator(ctx, g, g, ell, kind=1)
+    Y = op.matmul(X)
+    Yt = op.rmatmul_t(X)
+    op.close()
+    px, py = np.divmod(np.arange(n), g)                        # point = x * ny + y (tests/helpers.py:grid_points)
+    rows = np.concatenate([[0, 1, g - 1, g, n // 2, n - g, n - 1, 4295, 65535, 65536, 262143, 262144],
+                           rng.integers(0, n, size=40)])
+    scale = np.abs(Y).max()
+    for i in rows:
+        a = np.exp(-np.sqrt((px - px[i]) ** 2.0 + (py - py[i]) ** 2.0) / ell)
+        ref = a @ X
+        assert np.abs(Y[i] - ref).max() < 1e-12 * scale, i
+        assert np.abs(Yt[i] - ref).max() < 1e-12 * scale, i
+
+
+@pytest.mark.gpu
 def test_implicit_gridcov_randsvd(gsi, ctx):
     """randsvd through the implicit operator = randsvd of the stored matrix (same Omega), and = the oracle."""
     nx, ny, ell, K, p, q = 48, 40, 4.0, 20, 12, 2
