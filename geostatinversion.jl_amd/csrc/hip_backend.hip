@@ -731,9 +731,10 @@ class HipBackend : public Backend {
   void svd_small(double* G, int64_t l, double* U, double* S) override {
     bind();
     if (l > 5000) throw Error(GSI_ERR_ARG, "sketch width l = K+p > 5000 is not supported by the LDS-resident block Jacobi SVD");
-    grow(ws_svd_, sizeof(double) * (l + 8) + 64);
+    grow(ws_svd_, sizeof(double) * (l + 8) + 64 + sizeof(int32_t) * hipk::SVD_SCHED_INTS);
     hipk::SvdWork w;
     w.norms = (double*)ws_svd_.p;
+    w.pairs = (int32_t*)((char*)ws_svd_.p + sizeof(double) * (l + 8) + 64);
     w.rotcount = flags_ + 8;
     last_svd_sweeps_ = hipk::svd_small(st_, G, l, U, S, w);
     check_launch("svd_small");

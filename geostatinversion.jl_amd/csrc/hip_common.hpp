@@ -174,7 +174,9 @@ void scholqr3_apply(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld,
 struct SvdWork {
   int32_t* rotcount;  // [1]
   double* norms;      // [l]
+  int32_t* pairs;     // [SVD_SCHED_INTS] block-pair activity flags, then the sparse sweep's schedule (null: plain sweeps only)
 };
+constexpr int SVD_SCHED_INTS = 4096;
 // returns number of sweeps used
 int svd_small(hipStream_t st, double* G, int64_t l, double* U, double* S, const SvdWork& w);
 

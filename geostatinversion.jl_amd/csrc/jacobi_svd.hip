@@ -12,9 +12,14 @@
 // full inner round-robin sweep over them out of LDS -- one wave per column pair, the three
 // inner products by wavefront shuffles -- then writes the block back.  l <= 2*SVD_W needs
 // a single workgroup and no inter-workgroup traffic at all.
+#include "../../include/gsi_hip.h"
 #include "hip_common.hpp"
+#include "backend.hpp"
+#include <array>
+#include <atomic>
 #include <cstdlib>
 #include <cfloat>
+#include <vector>
 
 namespace gsi { namespace hipk {
 
@@ -157,11 +162,13 @@ __device__ __forceinline__ int jacobi_cross_rounds(double* __restrict__ cols, in
 }
 
 // grid.x = number of block pairs in this round; SVD_W = columns per block (16, or 8 for l > 600)
+// sched != null (sparse sweeps): workgroup b handles the block pair sched[3 b], sched[3 b + 1] with cross_only = sched[3 b + 2]
 template <int SVD_W>
 __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __restrict__ G, int l, int lp,
                                                                    int nblk, int round, double tol2,
                                                                    int32_t* __restrict__ rotcount,
-                                                                   int inner_sweeps, int cross_only) {
+                                                                   int inner_sweeps, int cross_only,
+                                                                   const int32_t* __restrict__ sched) {
   constexpr int SVD_C = 2 * SVD_W;   // columns resident per workgroup
   extern __shared__ double cols[];  // [SVD_C][lp] followed by one int slot (single LDS object)
   int& s_rot = *reinterpret_cast<int*>(cols + SVD_C * lp);
@@ -170,7 +177,8 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   const int wave = tid >> 6;
   const int quarter = lane >> 4, l16 = lane & 15;
   int ba, bb;
-  if (nblk <= 2) { ba = 0; bb = 1; }
+  if (sched != nullptr) { ba = sched[3 * blockIdx.x]; bb = sched[3 * blockIdx.x + 1]; cross_only = sched[3 * blockIdx.x + 2]; }
+  else if (nblk <= 2) { ba = 0; bb = 1; }
   else rr_pair(nblk, round, blockIdx.x, &ba, &bb);
   if (tid == 0) s_rot = 0;
   // load: local column c <- global column (c < W ? ba*W + c : bb*W + c - W), zero beyond l
@@ -244,6 +252,38 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   if (tid == 0 && s_rot) atomicAdd(rotcount, s_rot);
 }
 
+// Which block pairs still hold a column pair that would be rotated (the rotation test itself: c^2 > tol^2 a b)?  One workgroup
+// per pair ba <= bb of SVD_W-column blocks, one thread per column pair; flags[pair] = 1 / 0.  What it buys: the sweep that
+// only FINDS that nothing is left to rotate (one in ten at l = 320) becomes one small launch, and the late sweeps -- a few
+// percent of the pairs still active -- run on a schedule of the active block pairs only.
+template <int SVD_W>
+__global__ __launch_bounds__(SVD_W * SVD_W) void jacobi_activity_kernel(const double* __restrict__ G, int l, int lp, int nblk, double tol2,
+                                                                        int32_t* __restrict__ flags) {
+  extern __shared__ double cols[];            // [2 SVD_W][lp]
+  __shared__ int s_any;
+  // pair index -> (ba <= bb), row-major over the upper triangle
+  int ba = 0, rem = (int)blockIdx.x;
+  while (rem >= nblk - ba) { rem -= nblk - ba; ++ba; }
+  const int bb = ba + rem;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_any = 0;
+  for (int e = tid; e < 2 * SVD_W * lp; e += SVD_W * SVD_W) {
+    const int c = e / lp, r = e % lp;
+    const int gc = (c < SVD_W) ? ba * SVD_W + c : bb * SVD_W + (c - SVD_W);
+    cols[e] = (gc < l && r < l) ? G[r + (int64_t)gc * l] : 0.0;
+  }
+  __syncthreads();
+  const int i = tid / SVD_W, j = tid % SVD_W;
+  const double* x = cols + i * lp;
+  const double* y = cols + (SVD_W + j) * lp;
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int r = 0; r < l; ++r) { const double xv = x[r], yv = y[r]; a += xv * xv; b += yv * yv; c += xv * yv; }
+  const bool pairok = (ba != bb) || (i < j);
+  if (pairok && a > 0.0 && b > 0.0 && c * c > tol2 * (a * b)) s_any = 1;
+  __syncthreads();
+  if (tid == 0) flags[blockIdx.x] = s_any;
+}
+
 __global__ void jacobi_norms_kernel(const double* __restrict__ G, int l, double* __restrict__ norms) {
   // one wave per column
   const int col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -287,15 +327,99 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
   const double tol2 = tol * tol;
   const int max_sweeps = 40;
   int sweeps = 0;
+  // Activity-driven sweeps (16-column blocks, i.e. l <= 600; GSI_SVD_PLAIN=1: the plain loop below, A/B): after every sweep
+  // one small launch flags the block pairs that still hold a rotatable column pair.  None: converged (no sweep is spent on
+  // finding that out).  Few: the next sweep visits only those, packed greedily into rounds of disjoint block pairs.
+  const int npairs = nblk * (nblk + 1) / 2;
+  static const bool plain = (getenv("GSI_SVD_PLAIN") != nullptr);
+  if constexpr (SVD_W == 16) {
+    if (!plain && nblk > 2 && w.pairs != nullptr && npairs + 3 * npairs <= SVD_SCHED_INTS) {
+      static std::atomic<uint64_t> attr_mask2{0};
+      if (first_use_on_this_device(attr_mask2))
+        (void)hipFuncSetAttribute((const void*)jacobi_activity_kernel<SVD_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      std::vector<int32_t> flags((size_t)npairs, 1), sched;
+      int32_t* d_flags = w.pairs;
+      int32_t* d_sched = w.pairs + npairs;
+      bool sparse = false;
+      for (; sweeps < max_sweeps;) {
+        if (!sparse) {
+          for (int r = 0; r < nblk - 1; ++r)
+            hipLaunchKernelGGL(jacobi_block_kernel<SVD_W>, dim3(nblk / 2), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk,
+                               r, tol2, w.rotcount, 1, r == 0 ? 0 : 1, (const int32_t*)nullptr);
+        } else {
+          // active cross pairs -> rounds of disjoint block pairs (greedy); a block whose own (diagonal) pair is active gets
+          // its intra-block sweep with the first entry it appears in (cross_only = 0 sweeps both blocks and the cross pairs)
+          std::vector<char> diag((size_t)nblk, 0);
+          std::vector<std::array<int32_t, 3>> edges;
+          for (int ba = 0, pi = 0; ba < nblk; ++ba)
+            for (int bb = ba; bb < nblk; ++bb, ++pi) {
+              if (!flags[(size_t)pi]) continue;
+              if (ba == bb) diag[(size_t)ba] = 1;
+              else edges.push_back({ba, bb, 1});
+            }
+          std::vector<char> touched((size_t)nblk, 0);
+          for (auto& e : edges) { touched[(size_t)e[0]] = 1; touched[(size_t)e[1]] = 1; }
+          for (int b = 0; b < nblk; ++b)
+            if (diag[(size_t)b] && !touched[(size_t)b]) {        // a block that is only active within itself: any partner
+              int partner = -1;
+              for (int c = 0; c < nblk && partner < 0; ++c)
+                if (c != b && diag[(size_t)c] && !touched[(size_t)c]) partner = c;
+              if (partner < 0) partner = (b + 1) % nblk;
+              edges.push_back({std::min(b, partner), std::max(b, partner), 1});
+              touched[(size_t)b] = 1; touched[(size_t)partner] = 1;
+            }
+          std::vector<std::vector<std::array<int32_t, 3>>> rounds;
+          std::vector<std::vector<char>> used;
+          for (auto& e : edges) {
+            size_t r = 0;
+            for (; r < rounds.size(); ++r)
+              if (!used[r][(size_t)e[0]] && !used[r][(size_t)e[1]]) break;
+            if (r == rounds.size()) { rounds.emplace_back(); used.emplace_back((size_t)nblk, 0); }
+            if (diag[(size_t)e[0]] || diag[(size_t)e[1]]) { e[2] = 0; diag[(size_t)e[0]] = 0; diag[(size_t)e[1]] = 0; }
+            rounds[r].push_back(e);
+            used[r][(size_t)e[0]] = 1; used[r][(size_t)e[1]] = 1;
+          }
+          sched.clear();
+          for (auto& rd : rounds) for (auto& e : rd) { sched.push_back(e[0]); sched.push_back(e[1]); sched.push_back(e[2]); }
+          if ((int)sched.size() > 3 * npairs) throw Error(GSI_ERR_INTERNAL, "svd_small: schedule overflow");
+          hipMemcpyAsync(d_sched, sched.data(), sizeof(int32_t) * sched.size(), hipMemcpyHostToDevice, st);
+          hipStreamSynchronize(st);          // (pageable source: the copy must be over before `sched` is rebuilt)
+          size_t off = 0;
+          for (auto& rd : rounds) {
+            hipLaunchKernelGGL(jacobi_block_kernel<SVD_W>, dim3((unsigned)rd.size()), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk,
+                               0, tol2, w.rotcount, 1, 1, (const int32_t*)(d_sched + off));
+            off += 3 * rd.size();
+          }
+        }
+        ++sweeps;
+        // The flag threshold is 4 tol, the rotation threshold tol: tol = sqrt(l) eps is the rounding level of the inner
+        // products themselves, so which of the pairs near tol "still need a rotation" depends on the order of summation
+        // (this kernel's differs from the quarter waves' of the sweep; with the same threshold a converged matrix kept a
+        // handful of flagged pairs for ever).  A pair above 4 tol here is above tol there and gets rotated: progress; what
+        // may be left unrotated is coupled below 4 sqrt(l) eps -- second order in the singular values.
+        hipLaunchKernelGGL(jacobi_activity_kernel<SVD_W>, dim3((unsigned)npairs), dim3(SVD_W * SVD_W),
+                           (size_t)2 * SVD_W * lp * sizeof(double), st, G, l, lp, nblk, 16.0 * tol2, d_flags);
+        hipMemcpyAsync(flags.data(), d_flags, sizeof(int32_t) * (size_t)npairs, hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+        int active = 0;
+        for (int32_t f : flags) active += f ? 1 : 0;
+        if (active == 0) break;
+        sparse = (2 * active <= npairs);     // at least half of the pairs clean: a schedule beats the full tournament
+      }
+      hipLaunchKernelGGL(jacobi_norms_kernel, dim3((l + 3) / 4), dim3(256), 0, st, G, l, w.norms);
+      hipLaunchKernelGGL(jacobi_finish_kernel, dim3(l), dim3(64), 0, st, G, l, w.norms, U, S);
+      return sweeps;
+    }
+  }
   for (; sweeps < max_sweeps; ++sweeps) {
     hipMemsetAsync(w.rotcount, 0, sizeof(int32_t), st);
     if (nblk == 2) {
       hipLaunchKernelGGL(jacobi_block_kernel<SVD_W>, dim3(1), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk, 0, tol2,
-                         w.rotcount, 2, 0);
+                         w.rotcount, 2, 0, (const int32_t*)nullptr);
     } else {
       for (int r = 0; r < nblk - 1; ++r)
         hipLaunchKernelGGL(jacobi_block_kernel<SVD_W>, dim3(nblk / 2), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk,
-                           r, tol2, w.rotcount, 1, r == 0 ? 0 : 1);
+                           r, tol2, w.rotcount, 1, r == 0 ? 0 : 1, (const int32_t*)nullptr);
     }
     int32_t rot = 0;
     hipMemcpyAsync(&rot, w.rotcount, sizeof(int32_t), hipMemcpyDeviceToHost, st);
