@@ -1539,6 +1539,45 @@ def test_multirank_processes_on_one_gpu(gsi, world, hier, tmp_path):
                     "multirank-processes-ok")
 
 
+@pytest.mark.gpu
+def test_shared_memory_communicator_single_rank_and_foreign_id(gsi):
+    """GSI_SHM_COMM=1 with ONE rank (every collective degenerates to a copy through the staging buffer) and an id that
+    did not come from gsi_comm_unique_id under that switch (must be refused, not dereferenced as a name)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import gsi_amd as gsi
+from oracle import oracle as orc
+from helpers import gaussian_cov, rel_sv_err
+ctx = gsi.Context(0)
+try:
+    ctx.comm_init(1, 0, bytes(128))
+    raise SystemExit("a foreign id was accepted")
+except gsi.GsiError as e:
+    assert "gsi_comm_unique_id" in str(e), str(e)
+ctx.comm_init(1, 0, ctx.unique_id())
+assert ctx.rank() == (0, 1)
+A = gaussian_cov(20, 15, 3.0)
+Om = np.random.default_rng(0).standard_normal((300, 24))
+Z, S = gsi.randsvd(A, 16, 8, 2, Omega=Om, return_S=True, ctx=ctx)
+Zr, Sr, _ = orc.randsvd_full(A, 16, 8, 2, Om)
+assert rel_sv_err(S, Sr, 16) < 1e-9
+Y = np.random.default_rng(1).standard_normal((4000, 40))
+L, p = gsi.lu_L_sharded(Y, return_pivots=True, ctx=ctx)
+assert np.array_equal(p, orc.lu_pivots(Y))
+print("shm-single-ok")
+"""
+    env = dict(os.environ)
+    env["GSI_SHM_COMM"] = "1"
+    env["GSI_FORCE_COMM"] = "1"          # a 1-rank job gets no communicator otherwise
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "shm-single-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 # ---- BASELINE configs[1] as configured: dense fp64 65536 x 65536 Gaussian covariance (256 x 256 grid, ell = 16), K = 128,
 #      p = 32, q = 2 -- HIP vs the oracle (dgemm / dgetrf / dgeqp3 / dgesdd) on the same host matrix and Omega: a 34 GB host
 #      matrix, its upload and ~20 s of host LAPACK (32 s in all on the GPU box; GSI_SKIP_C2_PARITY=1 skips it) -------------
