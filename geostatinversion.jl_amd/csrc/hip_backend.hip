@@ -84,6 +84,7 @@ class HipBackend : public Backend {
     hipSetDevice(device_);
     hipStreamSynchronize(st_);
     for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_, &ws_svdf_, &ws_qr_hh_}) free_ws(*b);
+    collect_garbage();
     for (auto& b : pool_) hipFree(b.p);
     for (auto& ev : ev_pool_) hipEventDestroy(ev);
     for (auto& r : records_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -185,13 +186,15 @@ class HipBackend : public Backend {
     bind();
     for (DevBuf* b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_, &ws_svdf_, &ws_qr_hh_})
       if (b->bytes > ((size_t)64 << 20)) free_ws(*b);
+    (void)hipStreamSynchronize(st_);
+    collect_garbage();
     trim_pool(0);
   }
   int64_t bytes_in_use() const override {
     int64_t ws = 0;
     for (const DevBuf* b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_svdf_, &ws_qr_hh_})
       if (!b->pooled) ws += (int64_t)b->bytes;          // pooled workspaces are counted by alloc()
-    return in_use_ + pooled_ + ws;
+    return in_use_ + pooled_ + ws + (int64_t)garbage_bytes_;
   }
   void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) override {
     if (rows <= 0 || cols <= 0) return;
@@ -887,6 +890,7 @@ class HipBackend : public Backend {
     HIP_CHECK(hipMemcpyAsync(h, flags_, sizeof(h), hipMemcpyDeviceToHost, st_));
     HIP_CHECK(hipStreamSynchronize(st_));
     HIP_CHECK(hipGetLastError());
+    if (!garbage_.empty()) collect_garbage();
     if (h[0] != 0 || h[1] != 0) {
       HIP_CHECK(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), st_));
       if (h[0] < 0) {
@@ -966,11 +970,22 @@ class HipBackend : public Backend {
   }
   // Cached workspaces make repeated factorizations allocation-free; one of panel size at 512^3 (tens of GB) would
   // instead starve the next phase, so anything above 8 GiB is given back when the call that grew it returns.
+  // A workspace that is outgrown is not freed on the spot: hipFree waits for the whole DEVICE, and with the ranks of a
+  // communicator as threads of one process (GSI_LOCAL_COMM) another rank's persistent LU kernel may at that moment be
+  // spinning for a record of the very kernel this thread is about to launch -- a dead-lock that ends in the kernel's poll
+  // time-out (seen once in five runs of test_multirank_pipeline_on_one_gpu[3]: rank B grew ws_lu_ inside the sharded LU
+  // while rank A's first leaf was already waiting for it).  The block waits in garbage_ until this context's call has
+  // finished its own device work (take_error: whatever still spins for us has all it needs by then).
   void free_ws(DevBuf& b) {
     if (!b.p) return;
     if (b.pooled) release((double*)b.p);       // back to the block cache (stream-ordered: no synchronisation)
-    else { (void)hipStreamSynchronize(st_); (void)hipFree(b.p); }
+    else { std::lock_guard<std::mutex> g(mu_); garbage_.push_back(b.p); garbage_bytes_ += b.bytes; }
     b.p = nullptr; b.bytes = 0; b.pooled = false;
+  }
+  void collect_garbage() {                     // caller: this context's stream is idle
+    std::vector<void*> g;
+    { std::lock_guard<std::mutex> lk(mu_); g.swap(garbage_); garbage_bytes_ = 0; }
+    for (void* p : g) (void)hipFree(p);
   }
   void trim(DevBuf& b) {
     if (b.bytes <= ((size_t)8 << 30) || !b.p) return;
@@ -991,6 +1006,8 @@ class HipBackend : public Backend {
     hipError_t e = hipMalloc(&b.p, bytes);
     if (e != hipSuccess) {   // give the cache of released panels back and retry once (the other phases' workspaces may be
       (void)hipGetLastError();   // in use by the caller: they stay)
+      (void)hipStreamSynchronize(st_);
+      collect_garbage();
       trim_pool(0);
       e = hipMalloc(&b.p, bytes);
     }
@@ -1019,6 +1036,8 @@ class HipBackend : public Backend {
   std::mutex mu_;
   std::vector<DevBuf> sizes_;
   std::vector<DevBuf> pool_;
+  std::vector<void*> garbage_;                 // outgrown workspaces, freed when this context's call has finished (free_ws)
+  size_t garbage_bytes_ = 0;
   int64_t in_use_ = 0, pooled_ = 0;
   bool prof_ = false;
   Rec cur_{};

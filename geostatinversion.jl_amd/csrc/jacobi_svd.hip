@@ -392,13 +392,17 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
           }
         }
         ++sweeps;
+        if (sweeps < 4 && l >= 128) continue;      // nobody converges in three sweeps at these widths: no look, no host round trip
         // The flag threshold is 4 tol, the rotation threshold tol: tol = sqrt(l) eps is the rounding level of the inner
         // products themselves, so which of the pairs near tol "still need a rotation" depends on the order of summation
         // (this kernel's differs from the quarter waves' of the sweep; with the same threshold a converged matrix kept a
         // handful of flagged pairs for ever).  A pair above 4 tol here is above tol there and gets rotated: progress; what
         // may be left unrotated is coupled below 4 sqrt(l) eps -- second order in the singular values.
+        // (its own LDS stride: odd, so that the 16 columns a wave's lanes walk sit in 16 different banks -- with the sweep
+        // kernel's stride, lp % 32 == 16, they collide eight ways: 53 us per launch)
+        const int lpa = l | 1;
         hipLaunchKernelGGL(jacobi_activity_kernel<SVD_W>, dim3((unsigned)npairs), dim3(SVD_W * SVD_W),
-                           (size_t)2 * SVD_W * lp * sizeof(double), st, G, l, lp, nblk, 16.0 * tol2, d_flags);
+                           (size_t)2 * SVD_W * lpa * sizeof(double), st, G, l, lpa, nblk, 16.0 * tol2, d_flags);
         hipMemcpyAsync(flags.data(), d_flags, sizeof(int32_t) * (size_t)npairs, hipMemcpyDeviceToHost, st);
         hipStreamSynchronize(st);
         int active = 0;
