@@ -209,6 +209,17 @@ def secondary_c1(gsi, ctx, barrier):
             "sv_rel_err": rel_sv_err(Sh, Sr, K), "xis_err_up_to_sign": orc.xis_error_up_to_sign(Zh, Zr, K)}
 
 
+def secondary_headline_p0(gsi, ctx, barrier, n, Ns, K, q, decay):
+    """The headline operator with NO oversampling (p = 0, l = K = 256: "rank=256" read literally; SURVEY.md 8 pins p = 64 for
+    the headline and asks for this one beside it)."""
+    op = gsi.lowrank_synthetic_operator(ctx, n, Ns, seed=0, decay=decay)
+    e, ph, _ = run_steps(gsi, ctx, op, n, K, 0, q, 5, 1, barrier)
+    op.close()
+    return {"workload": f"the headline LowRankCovMatrix (n={n}, N_s={Ns}), K={K}, p=0 (l={K}), q={q}", "steps": 5,
+            "ms_per_step": 1e3 * e / 5, "GB/s": lrcm_bytes(n, Ns, K, q) * 5 / e / 1e9,
+            "phases_ms_per_step": {k: v[0] / 5 for k, v in ph.items()}}
+
+
 def secondary_c2(gsi, ctx, barrier):
     """BASELINE.json configs[1]: dense fp64 65536^2 Gaussian covariance, K = 128, p = 32, q = 2."""
     g, K2, p2, q2 = 256, 128, 32, 2
@@ -642,6 +653,7 @@ def main():
                 for ch in list(ctx._children):             # whatever the failed workload left on the device
                     ch.close()
 
+        guarded("headline_p0", lambda: secondary_headline_p0(gsi, ctx, barrier, n, Ns, K, q, args.decay))
         if not args.no_cpu_baseline:                        # (it times the oracle beside the GPU)
             guarded("c1_dense_2000", lambda: secondary_c1(gsi, ctx, barrier))
         guarded("c2_dense_65536", lambda: secondary_c2(gsi, ctx, barrier))
