@@ -395,8 +395,21 @@ class HipBackend : public Backend {
     static const bool force_sweeps = (getenv("GSI_LU_SWEEPS") != nullptr);
     hipk::Lu2Work w2;
     static const bool tall_first = (getenv("GSI_LU_TALL") != nullptr && getenv("GSI_LU_TALL")[0] == '1');
-    if (!force_sweeps && !tall_first && !lu2_lost_ && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid) &&
-        lu2_fits(w2.bs, w2.rpt, w2.grid)) {
+    // Panels taller than the register file holds (up to GSI_LU_OV_MAX rows, default 5 x 2^20): the resident kernel on all
+    // CUs with the rows beyond its window evaluated lazily out of L2 / Infinity Cache / HBM; beyond that the streamed leaves
+    // win (measured cross-over: 6e6 rows at l = 320).  GSI_LU_OV=0 switches it off (A/B).
+    static const int64_t ov_max = getenv("GSI_LU_OV_MAX") ? atoll(getenv("GSI_LU_OV_MAX")) : ((int64_t)5 << 20);
+    static const bool ov_off = (getenv("GSI_LU_OV") != nullptr && getenv("GSI_LU_OV")[0] == '0');
+    bool fits = !force_sweeps && !tall_first && !lu2_lost_ && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid) &&
+                lu2_fits(w2.bs, w2.rpt, w2.grid);
+    if (!fits && !force_sweeps && !tall_first && !lu2_lost_ && !ov_off && m <= ov_max && ncus_ >= 1) {
+      const int g = std::min(ncus_, 256);
+      if (m > (int64_t)g * 4096) {
+        if (lu2_ov_resident_ < 0) lu2_ov_resident_ = hipk::lu2_resident_per_cu_ov();
+        if ((int64_t)lu2_ov_resident_ * ncus_ >= g) { w2.bs = 512; w2.rpt = 8; w2.grid = g; w2.ov = true; fits = true; }
+      }
+    }
+    if (fits) {
       // test / A-B knobs, read per call: GSI_LU_POLL_LIMIT (polls before a workgroup gives up), GSI_LU_TEST_MUTE_EPOCH
       // (one workgroup stays silent at that pivot step: exercises the info = -1 path), GSI_LU_COOPERATIVE=1
       if (const char* e = getenv("GSI_LU_POLL_LIMIT")) w2.poll_limit = atoi(e);
@@ -1050,6 +1063,7 @@ class HipBackend : public Backend {
   std::map<std::pair<int64_t, bool>, int> skip_tier1_by_height_;
   std::map<int, int> lu2_resident_;   // (bs, rpt) -> resident workgroups per CU of that leaf instantiation
   bool lu2_lost_ = false, lu2_retry_ = false;
+  int lu2_ov_resident_ = -1;
   // multi-rank persistent leaves: this rank's record buffer, the peers' (as this rank addresses them), the running epoch
   unsigned long long* mr_recs_ = nullptr;
   unsigned long long* mr_peer_[hipk::LU2_MAX_RANKS] = {nullptr};

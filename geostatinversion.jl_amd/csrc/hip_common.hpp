@@ -85,7 +85,9 @@ struct Lu2Work {
   int poll_limit = 0;          // polls before a workgroup gives up on a record (0: the default, ~ seconds)
   uint32_t mute_epoch = 0;     // tests only: the last workgroup publishes nothing at this pivot step (1-based)
   bool cooperative = false;    // launch the leaves with hipLaunchCooperativeKernel (co-residency guaranteed by the runtime)
+  bool ov = false;             // the panel is taller than grid x 4096 rows: <512, 8> leaves with lazily evaluated overflow rows
 };
+int lu2_resident_per_cu_ov();
 // workgroups of the (bs, rpt) leaf kernel that fit one CU (occupancy query); 0 if the query fails
 int lu2_resident_per_cu(int bs, int rpt);
 // the same leaf kernel across RANKS (one launch per rank, records written into every rank's peer-mapped buffer)

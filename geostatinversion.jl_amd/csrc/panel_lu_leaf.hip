@@ -160,7 +160,16 @@ struct LuMrArgs {
   const double* us;                          // kp x LW, [c * LW + k]
   unsigned long long* peer[LU2_MAX_RANKS];   // every rank's record buffer (peer[rank] == recs)
 };
-template <int BS, int R, bool MR>
+// OV (single rank only): the panel is TALLER than the grid's registers hold.  Rows beyond the resident window -- [ovb, m),
+// ovb = j0 + 8 + grid * R * BS -- stay in HBM with their STORED leaf values and are evaluated lazily, as the streamed
+// leaves (lu3_*) do it: the pending update is applied to them once on the way in (written back), every pivot step
+// re-derives their candidates from the stored values and the pivot rows so far (s_u), the leaf's last act turns them into
+// multipliers.  An overflow row that wins a pivot step hands its values over through the record like any other row and
+// receives the old row j's CURRENT values in exchange -- those are already eliminated through the steps before, which a
+// small list (s_lr, s_ll: row, first step still to apply) remembers.  Same operations on the same values in the same
+// order as the resident rows see: bit-identical factors.  What it is for: the panels just above 4096 rows per CU, whose
+// few overflow rows sit in L2 / Infinity Cache between the steps (1.2e6 rows: 9 instead of 14.7 ms).
+template <int BS, int R, bool MR, bool OV = false>
 __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int64_t ld, int32_t m, int32_t l,
                                                      int32_t jb, int32_t j0, int w, unsigned long long* __restrict__ recs,
                                                      uint32_t epoch_base, int32_t* __restrict__ ipiv,
@@ -183,6 +192,12 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
   __shared__ uint32_t c_oldbits[2 * LW];
   __shared__ int32_t c_slot[NW];
   __shared__ int s_abort;
+  __shared__ double s_u[OV ? LW * LW : 1];      // OV: the leaf's pivot rows so far (u_t) and 1 / u_tt
+  __shared__ double s_rp[OV ? LW : 1];
+  __shared__ int32_t s_lr[OV ? LW : 1];         // OV: overflow rows that hold values eliminated through step s_ll - 1
+  __shared__ int32_t s_ll[OV ? LW : 1];
+  __shared__ int32_t s_nl;
+  static_assert(!(OV && MR), "overflow rows: single-rank kernel only");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x;
   const int Gl = gridDim.x;                                 // this rank's workgroups
@@ -318,6 +333,40 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
     }
   }
 
+  // ---- OV: the rows beyond the resident window ---------------------------------------------------------------
+  const int32_t ovb = j0 + LW + Gl * (R * BS);              // first overflow row
+  const int32_t ovstride = Gl * BS;
+  const int32_t ov0 = ovb + g * BS + tid;                   // this thread's overflow rows: ov0 + k ovstride < m
+  // first step still to apply to overflow row i (0 unless it received an old row j during this leaf)
+  auto ov_level = [&](int32_t i) -> int {
+    int lev = 0;
+    const int nl = s_nl;
+    for (int q = 0; q < nl; ++q) if (s_lr[q] == i) lev = s_ll[q];
+    return lev;
+  };
+  if constexpr (OV) {
+    if (tid == 0) s_nl = 0;
+    if (kp > 0) {                                           // pending update, written back (as lu3_open_kernel)
+      for (int32_t i = ov0; i < m; i += ovstride) {
+        double x[LW];
+#pragma unroll
+        for (int k = 0; k < LW; ++k) x[k] = (k < w) ? *elem(colbase(j0 + k), i) : 0.0;
+        for (int c = 0; c < kp; c += 4) {
+          double lv4[4];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) lv4[cc] = *elem(colbase(jb + c + cc), i);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int k = 0; k < LW; ++k) x[k] -= lv4[cc] * Us[(c + cc) * LW + k];
+        }
+#pragma unroll
+        for (int k = 0; k < LW; ++k) if (k < w) *elem(colbase(j0 + k), i) = x[k];
+      }
+    }
+    __syncthreads();                                        // s_nl
+  }
+
   // Row interchanges of the columns OUTSIDE the leaf (LAPACK swaps whole rows): column c belongs to workgroup
   // c % G, thread c / G.  Pipelined one step behind: the two loads of step s are issued when its pivot is known and
   // stored swapped at step s + 1, so their latency hides behind the next exchange (same thread, program order:
@@ -347,6 +396,27 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
       const double av = fabs(a[rr][s]);
       if (av > best && (!MR || row0 + rr * BS < m)) { best = av; besti = grow0 + rr * BS; }   // MR: rows beyond the shard are no candidates
     }
+    if constexpr (OV) {                         // overflow rows: current value in column s from the stored values, lazily
+      if (live) {
+        for (int32_t i = ov0; i < m; i += ovstride) {
+          const int lev = ov_level(i);
+          double x[s + 1];
+#pragma unroll
+          for (int k = 0; k <= s; ++k) x[k] = *elem(colbase(j0 + k), i);
+#pragma unroll
+          for (int t = 0; t < s; ++t) {
+            if (t >= lev) {
+              const double rp = s_rp[t];
+              const double lt = (rp != 0.0) ? x[t] * rp : x[t];
+#pragma unroll
+              for (int k = t + 1; k <= s; ++k) x[k] -= lt * s_u[t * LW + k];
+            }
+          }
+          const double av = fabs(x[s]);
+          if (av > best) { best = av; besti = i; }
+        }
+      }
+    }
     double wv = best;
     int32_t wi = besti;
     wave_argmax(wv, wi);
@@ -355,6 +425,26 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
       if (isdiag && besti == drow) {            // wave (~40 instructions) is cheaper than two more barriers
 #pragma unroll
         for (int k = 0; k < LW; ++k) s_cand[wave][k] = d[k];
+      }
+      if constexpr (OV) {
+        if (besti >= ovb) {                     // an overflow row: all 8 of its current values
+          const int lev = ov_level(besti);
+          double x[LW];
+#pragma unroll
+          for (int k = 0; k < LW; ++k) x[k] = (k < w) ? *elem(colbase(j0 + k), besti) : 0.0;
+#pragma unroll
+          for (int t = 0; t < s; ++t) {
+            if (t >= lev) {
+              const double rp = s_rp[t];
+              const double lt = (rp != 0.0) ? x[t] * rp : x[t];
+              x[t] = lt;
+#pragma unroll
+              for (int k = t + 1; k < LW; ++k) x[k] -= lt * s_u[t * LW + k];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < LW; ++k) s_cand[wave][k] = x[k];
+        }
       }
 #pragma unroll
       for (int rr = 0; rr < R; ++rr)
@@ -662,6 +752,20 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
     for (int k = 0; k < LW; ++k) u[k] = valid ? c_row[k] : c_old[k];
     const double piv = u[s];
     const double rpiv = (piv != 0.0) ? 1.0 / piv : 0.0;
+    if constexpr (OV) {
+      if (live) {
+        if (tid < LW) s_u[s * LW + tid] = u[tid];
+        if (tid == LW) s_rp[s] = rpiv;
+        if (r >= ovb && r != j) {               // the pivot row was an overflow row: the old row j moves there, already
+          if (tid == 2 * LW) { const int q = s_nl; s_lr[q] = r; s_ll[q] = s; s_nl = q + 1; }     // eliminated through step s - 1
+          if ((r - ovb) % ovstride == g * BS + tid) {
+#pragma unroll
+            for (int k = 0; k < LW; ++k) if (k < w) *elem(colbase(j0 + k), r) = c_old[k];
+          }
+        }
+      }
+      __syncthreads();                          // s_u / the list before the next step's lazy evaluations
+    }
     // (e) bookkeeping by workgroup 0; pipelined interchange of this thread's column outside the leaf
     if (g == 0 && tid == 0 && live) {
       ipiv[j] = r;
@@ -722,6 +826,26 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
     step(integral_constant<int, 5>{});
     step(integral_constant<int, 6>{});
     step(integral_constant<int, 7>{});
+  }
+  if constexpr (OV) {                           // the overflow rows' multipliers
+    for (int32_t i = ov0; i < m; i += ovstride) {
+      const int lev = ov_level(i);
+      double x[LW];
+#pragma unroll
+      for (int k = 0; k < LW; ++k) x[k] = (k < w) ? *elem(colbase(j0 + k), i) : 0.0;
+#pragma unroll
+      for (int t = 0; t < LW; ++t) {
+        if (t >= lev && t < w) {
+          const double rp = s_rp[t];
+          const double lt = (rp != 0.0) ? x[t] * rp : x[t];
+          x[t] = lt;
+#pragma unroll
+          for (int k = t + 1; k < LW; ++k) x[k] -= lt * s_u[t * LW + k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < LW; ++k) if (k < w) *elem(colbase(j0 + k), i) = x[k];
+    }
   }
   if (s_abort && tid == 0) atomicExch(info, -1);
   if (has_col && pend) { swcol[pj] = pa1; swcol[pr] = pa0; }
@@ -899,6 +1023,13 @@ static void launch_leaf(hipStream_t st, int grid, double* Y, int64_t ld, int64_t
   static const int onehop = getenv("GSI_LU_ONEHOP") ? atoi(getenv("GSI_LU_ONEHOP")) : 1;   // A/B knob; 0 = two hops via a leader
   const int poll_limit = wk.poll_limit > 0 ? wk.poll_limit : POLL_LIMIT;
   LuMrArgs none{};
+  if constexpr (BS == 512 && R == 8) {
+    if (wk.ov) {                          // taller than the grid's registers: overflow rows evaluated lazily
+      hipLaunchKernelGGL((lu_leaf_kernel<512, 8, false, true>), dim3(grid), dim3(512), 0, st, Y, ld, (int32_t)m, (int32_t)l,
+                         (int32_t)jb, (int32_t)j0, w, wk.recs, epoch_base, wk.ipiv, wk.info, 1, poll_limit, wk.mute_epoch, none);
+      return;
+    }
+  }
   if (!wk.cooperative) {
     hipLaunchKernelGGL((lu_leaf_kernel<BS, R, false>), dim3(grid), dim3(BS), 0, st, Y, ld, (int32_t)m, (int32_t)l, (int32_t)jb,
                        (int32_t)j0, w, wk.recs, epoch_base, wk.ipiv, wk.info, onehop, poll_limit, wk.mute_epoch, none);
@@ -927,6 +1058,14 @@ static int leaf_resident_per_cu() {
 }
 // How many workgroups of the (bs, rpt) leaf kernel one CU holds (registers, LDS, waves): the persistent launch needs
 // grid <= that x CUs, or its spin-waits would wait for workgroups that cannot start.
+int lu2_resident_per_cu_ov() {
+  int nblk = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)lu_leaf_kernel<512, 8, false, true>, 512, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return nblk;
+}
 int lu2_resident_per_cu(int bs, int rpt) {
   if (bs == 256 && rpt == 1) return leaf_resident_per_cu<256, 1>();
   if (bs == 256) return leaf_resident_per_cu<256, 4>();

@@ -1086,7 +1086,10 @@ out = sys.argv[1]
 ctx = gsi.Context(0)
 res = {}
 for idx, (m, l, ties) in enumerate([(100, 25, False), (9, 2, False), (64, 64, False), (5000, 160, True), (3000, 33, True),
-                                    (300000, 136, True), (70001, 72, False), (600001, 24, True)]):
+                                    (300000, 136, True), (70001, 72, False), (600001, 24, True),
+                                    # above 4096 rows per CU the default path is the resident kernel with lazily evaluated
+                                    # OVERFLOW rows (panel_lu_leaf.hip, OV): also bit-identical to the streamed leaves
+                                    (1100000, 72, True), (1048585, 16, True)]):
     rng = np.random.default_rng(m + l)
     Y = rng.standard_normal((m, l))
     if ties and m >= 3000:

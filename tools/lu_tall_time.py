@@ -9,7 +9,7 @@ sys.path.insert(0, sys.argv[1])
 import gsi_amd as gsi
 ctx = gsi.Context(0); lib = ctx.lib
 out = {}
-for m, l in [(1210000, 320), (2000000, 320), (4000000, 320), (16777216, 64), (134217728, 48)]:
+for m, l in [(1100000, 320), (1210000, 320), (1500000, 320), (2000000, 320), (3000000, 320), (4000000, 320), (16777216, 64), (134217728, 48)]:
     Y = gsi.DeviceMatrix(ctx, m, l)
     ts = []
     for rep in range(3):
@@ -22,7 +22,8 @@ for m, l in [(1210000, 320), (2000000, 320), (4000000, 320), (16777216, 64), (13
     Y.close(); ctx.release_cache()
 print(json.dumps(out))
 '''
-for tag, extra in (("streamed", {}), ("streamed, every leaf closed by its own pass", {"GSI_LU_TALL_NOFUSE": "1"}), ("sweeps", {"GSI_LU_TALL": "0"})):
+for tag, extra in (("default (resident + overflow rows up to 5 x 2^20 rows, streamed beyond)", {}), ("streamed", {"GSI_LU_OV": "0"}),
+                   ("sweeps", {"GSI_LU_OV": "0", "GSI_LU_TALL": "0"})):
     env = dict(os.environ); env.update(extra)
     r = subprocess.run([sys.executable, "-c", CODE, ROOT], capture_output=True, text=True, env=env)
     print(tag, r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else r.stderr[-2000:], flush=True)
