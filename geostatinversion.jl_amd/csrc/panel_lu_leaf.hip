@@ -754,8 +754,11 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
     const double rpiv = (piv != 0.0) ? 1.0 / piv : 0.0;
     if constexpr (OV) {
       if (live) {
-        if (tid < LW) s_u[s * LW + tid] = u[tid];
-        if (tid == LW) s_rp[s] = rpiv;
+        if (tid == 0) {                         // (unrolled: u[] indexed by the thread id would live in scratch)
+#pragma unroll
+          for (int k = 0; k < LW; ++k) s_u[s * LW + k] = u[k];
+          s_rp[s] = rpiv;
+        }
         if (r >= ovb && r != j) {               // the pivot row was an overflow row: the old row j moves there, already
           if (tid == 2 * LW) { const int q = s_nl; s_lr[q] = r; s_ll[q] = s; s_nl = q + 1; }     // eliminated through step s - 1
           if ((r - ovb) % ovstride == g * BS + tid) {
