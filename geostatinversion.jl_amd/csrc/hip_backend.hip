@@ -548,8 +548,13 @@ class HipBackend : public Backend {
     const int G = comm->nranks;
     const int64_t pad = (m + G - 1) / G;
     hipk::Lu2MrWork w{};
-    const int sharing = std::max(comm->ranks_on_my_device(), 1);     // > 1 only with the RCCL-free communicators: the leaf grids of
-    if (!hipk::lu2_mr_config(pad, G, ncus_ / sharing, &w.bs, &w.rpt, &w.grid, &w.hier)) return false;   // all of them must fit the chip
+    // Ranks that share this device (possible only with the RCCL-free communicators): ALL their leaf grids must be resident
+    // together, and residency is decided per XCD -- the workgroups of a launch are dealt round-robin over the 8 XCDs, so a
+    // grid of g workgroups puts ceil(g / 8) on the first XCDs, and three grids of 82 want 33 CUs of an XCD that has 32 (seen:
+    // three rank processes at n = 1e6 timed out, two and four fit by arithmetic luck).
+    const int sharing = std::max(comm->ranks_on_my_device(), 1);
+    const int xcd_cus = std::max(ncus_ / 8, 1);
+    if (!hipk::lu2_mr_config(pad, G, sharing > 1 ? (xcd_cus / sharing) * 8 : ncus_, &w.bs, &w.rpt, &w.grid, &w.hier)) return false;
     const int key = 1000000 + w.bs * 16 + w.rpt;
     auto it = lu2_resident_.find(key);
     if (it == lu2_resident_.end()) it = lu2_resident_.emplace(key, hipk::lu2_mr_resident_per_cu(w.bs, w.rpt)).first;
@@ -570,7 +575,9 @@ class HipBackend : public Backend {
       for (int g = 0; g < G; ++g) mr_peer_[g] = (unsigned long long*)all[g];
       mr_comm_ = comm;
     }
-    if ((int64_t)it->second * ncus_ < (int64_t)w.grid * sharing) return false;
+    if (sharing > 1 ? (int64_t)sharing * ((w.grid + 7) / 8) > (int64_t)xcd_cus * it->second
+                    : (int64_t)it->second * ncus_ < (int64_t)w.grid)
+      return false;
     w.rank = comm->rank; w.nranks = G;
     for (int g = 0; g < G; ++g) w.peer[g] = mr_peer_[g];
     w.info = flags_ + 0;
