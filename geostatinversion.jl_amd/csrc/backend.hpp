@@ -213,6 +213,10 @@ class Comm {
   // on one device); the RCCL-free communicators allow any placement, and kernels that need all their workgroups resident
   // at once (the persistent LU leaves) must share the chip between that many launches.
   virtual int ranks_on_my_device() { return 1; }
+  // Ranks that are THREADS of one process share one HIP runtime: a call that waits for the device (hipFree does, and a
+  // hipMalloc that has to map new memory was seen to) waits for the other ranks' kernels too.  Before a rank launches a
+  // kernel that spins for its peers, all ranks meet here with their allocations done.  No-op for ranks in processes.
+  virtual void host_barrier() {}
 };
 
 // Provided by whichever backend is linked into the library.

@@ -921,7 +921,9 @@ class HipBackend : public Backend {
         lu2_retry_ = true;
         mr_disabled_ = true;
         if (msg) *msg = "lu(): the pivot exchange between workgroups timed out (GPU shared with another job?); "
-                        "this context now streams its leaves (no spin-waits)";
+                        "this context now streams its leaves (no spin-waits) [waited for: phase " + std::to_string(h[2]) +
+                        ", slot " + std::to_string(h[3]) + ", epoch " + std::to_string(h[4]) + ", by rank*1024+workgroup " +
+                        std::to_string(h[5]) + "]";
         return GSI_ERR_INTERNAL;
       }
       if (h[0] != 0) {
@@ -1302,6 +1304,7 @@ class LocalComm : public Comm {
     finish();
     return true;
   }
+  void host_barrier() override { grp_->barrier(); }
   int ranks_on_my_device() override {
     std::lock_guard<std::mutex> g(grp_->mu);
     int c = 0;

@@ -105,6 +105,14 @@ __device__ inline unsigned long long poll_granule(const unsigned long long* p) {
   else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// What a poll that ran out was waiting for: written once per factorization into info[2 .. 5] = {phase, slot, epoch, who}
+// (phase 1: U mailbox of rank 0, 2: record heads, 3: the winner's row values, 4: the ranks' result heads (two-hop exchange),
+// 5: their row values, 6: row boxes of the interchange kernel; who = rank * 1024 + workgroup).  take_error puts it into
+// the message: "never launched" (epoch of a leaf's first step) and "stopped mid-leaf" are different bugs.
+__device__ inline void lu_timeout_note(int32_t* info, int phase, int slot, uint32_t epoch, int who) {
+  if (atomicCAS(info + 2, 0, phase) == 0) { info[3] = slot; info[4] = (int32_t)epoch; info[5] = who; }
+}
+
 #ifdef GSI_LU_TRACE
 // debug build only (hipcc -DGSI_LU_TRACE): 100 MHz wall-clock stamps of the phases of every pivot step of the kp = 0
 // leaves, for 4 workgroups; dumped by lu2_L to $GSI_LU_TRACE
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
             lo = poll_granule<true>(recs + ubox + 2 * e);
             hi = poll_granule<true>(recs + ubox + 2 * e + 1);
             if ((uint32_t)(lo >> 32) == utag && (uint32_t)(hi >> 32) == utag) break;
-            if (++tries > poll_limit) { s_abort = 1; break; }
+            if (++tries > poll_limit) { s_abort = 1; lu_timeout_note(info, 1, e, utag, mr.rank * 1024 + g); break; }
             __builtin_amdgcn_s_sleep(1);
           }
           Us[e] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
           if (++tries > poll_limit) break;
           __builtin_amdgcn_s_sleep(1);
         }
-        if (!__all(ok)) s_abort = 1;
+        if (!__all(ok)) { s_abort = 1; if (!ok) lu_timeout_note(info, 2, tid, epoch, (MR ? mr.rank : 0) * 1024 + g); }
         LU_STAMP(2);
         if (extra) c_oldbits[tid] = (uint32_t)gx;
         double cv = -1.0;
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
           if (++tries > poll_limit) break;
           __builtin_amdgcn_s_sleep(1);
         }
-        if (!__all(ok)) s_abort = 1;
+        if (!__all(ok)) { s_abort = 1; if (!ok) lu_timeout_note(info, 3, gw, epoch, (MR ? mr.rank : 0) * 1024 + g); }
         LU_STAMP(3);
         if (mine) c_rowbits[0][lane] = (uint32_t)gv;
         if (lane == 0) { c_val[0] = fv; c_idx[0] = fi; }
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
               if (++tries > poll_limit) break;
               __builtin_amdgcn_s_sleep(1);
             }
-            if (!__all(ok)) s_abort = 1;
+            if (!__all(ok)) { s_abort = 1; if (!ok) lu_timeout_note(info, 4, lane, epoch, mr.rank * 1024 + g); }
             double cv = -1.0;
             int32_t ci = -1;
             if (rmine) {
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
               if (++tries > poll_limit) break;
               __builtin_amdgcn_s_sleep(1);
             }
-            if (!__all(ok)) s_abort = 1;
+            if (!__all(ok)) { s_abort = 1; if (!ok) lu_timeout_note(info, 5, qw, epoch, mr.rank * 1024 + g); }
             if (vmine) c_rowbits[0][lane] = (uint32_t)gv;
             if (omine) c_oldbits[lane - 32] = (uint32_t)gv;
             if (lane == 0) { c_val[0] = rv; c_idx[0] = ri; }
@@ -1271,7 +1279,7 @@ __global__ __launch_bounds__(256) void lus_swap_peer_kernel(double* __restrict__
         for (int t = 0; t < 2 * LW; ++t)
           if (scan[t] && !smine[t]) ok = ok && ((uint32_t)(lo[t] >> 32) == tag && (uint32_t)(hi[t] >> 32) == tag);
         if (ok) break;
-        if (++tries > poll_limit) { timed_out = true; break; }
+        if (++tries > poll_limit) { timed_out = true; lu_timeout_note(info, 6, (int)c, tag, mr.rank * 1024 + (int)blockIdx.x); break; }
         __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll

@@ -442,7 +442,12 @@ static void lu_panel_sharded_impl(Context& c, double* Yloc, int64_t m, int64_t r
   if (mr && !be->lus_mr_begin(c.comm.get(), m, l)) throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: persistent leaves refused");
   Buf rec(be, (size_t)reclen), recs(be, (size_t)reclen * G), u12leaf(be, (size_t)nb * 8), u12blk(be, (size_t)nb * l);
   Buf swaps;
-  if (mr) swaps = Buf(be, (size_t)16 * l);
+  if (mr) {
+    swaps = Buf(be, (size_t)16 * l);
+    // everything this factorization allocates exists now (lus_mr_begin sized the backend's own workspaces): from here on
+    // kernels spin for their peers, and with ranks as threads of one process no rank may still be inside an allocation
+    c.comm->host_barrier();
+  }
   for (int64_t jb = 0; jb < l; jb += nb) {
     const int b = (int)std::min<int64_t>(nb, l - jb);
     for (int64_t j0 = jb; j0 < jb + b; j0 += 8) {

@@ -10,7 +10,7 @@ import os, sys, time, numpy as np
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gsi_amd as gsi
 from oracle import oracle as orc
-shapes = [(30000, 72), (5000, 24), (120000, 136), (3001, 40), (64000, 64)]
+shapes = [(30000, 72), (5000, 24), (399, 24), (120000, 136), (3001, 40), (64000, 64), (100, 25), (640, 72)]   # incl. one-workgroup shards
 panels = []
 for k, (m, l) in enumerate(shapes):
     rng = np.random.default_rng(100 + k)
