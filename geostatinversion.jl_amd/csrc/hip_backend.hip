@@ -549,15 +549,19 @@ class HipBackend : public Backend {
     const int64_t pad = (m + G - 1) / G;
     hipk::Lu2MrWork w{};
     // Ranks that share this device (possible only with the RCCL-free communicators): ALL their leaf grids must be resident
-    // together, and residency is decided per XCD -- the workgroups of a launch are dealt round-robin over the 8 XCDs, so a
-    // grid of g workgroups puts ceil(g / 8) on the first XCDs, and three grids of 82 want 33 CUs of an XCD that has 32 (seen:
-    // three rank processes at n = 1e6 timed out, two and four fit by arithmetic luck).
+    // together, and residency is decided per SHADER ENGINE (8 CUs; 4 per XCD) -- the workgroups of a launch are dealt
+    // round-robin over the 8 XCDs and, inside an XCD, over its 4 engines, so a grid of g one-per-CU workgroups puts
+    // ceil(ceil(g / 8) / 4) on the first engines.  Measured with rank processes on one GPU: 2 x 123, 4 x 62, 3 x 40, 2 x 100
+    // workgroups run; 3 x 74, 3 x 80 and 3 x 82 time out (3 x 3 = 9 workgroups on engines of 8 CUs) although 222-246 <= 256.
     const int sharing = std::max(comm->ranks_on_my_device(), 1);
-    const int xcd_cus = std::max(ncus_ / 8, 1);
-    if (!hipk::lu2_mr_config(pad, G, sharing > 1 ? (xcd_cus / sharing) * 8 : ncus_, &w.bs, &w.rpt, &w.grid, &w.hier)) return false;
-    const int key = 1000000 + w.bs * 16 + w.rpt;
+    const int se_cus = std::max(ncus_ / 32, 1);                        // CUs per shader engine (8)
+    const int per_se = sharing > 1 ? std::max(se_cus / sharing, 0) : se_cus;
+    if (per_se < 1) return false;
+    if (!hipk::lu2_mr_config(pad, G, sharing > 1 ? per_se * 32 : ncus_, &w.bs, &w.rpt, &w.grid, &w.hier, &w.ov)) return false;
+    const int key = 1000000 + w.bs * 16 + w.rpt + (w.ov ? 100000 : 0);
     auto it = lu2_resident_.find(key);
-    if (it == lu2_resident_.end()) it = lu2_resident_.emplace(key, hipk::lu2_mr_resident_per_cu(w.bs, w.rpt)).first;
+    if (it == lu2_resident_.end())
+      it = lu2_resident_.emplace(key, w.ov ? hipk::lu2_mr_resident_per_cu_ov() : hipk::lu2_mr_resident_per_cu(w.bs, w.rpt)).first;
     if ((int64_t)it->second * ncus_ < w.grid) return false;
     if (mr_comm_ != comm) {                                 // first use over this communicator: record buffer, exchanged once
       if (mr_recs_ == nullptr) {
@@ -575,7 +579,7 @@ class HipBackend : public Backend {
       for (int g = 0; g < G; ++g) mr_peer_[g] = (unsigned long long*)all[g];
       mr_comm_ = comm;
     }
-    if (sharing > 1 ? (int64_t)sharing * ((w.grid + 7) / 8) > (int64_t)xcd_cus * it->second
+    if (sharing > 1 ? (int64_t)sharing * ((((w.grid + 7) / 8) + 3) / 4) > (int64_t)se_cus * it->second
                     : (int64_t)it->second * ncus_ < (int64_t)w.grid)
       return false;
     w.rank = comm->rank; w.nranks = G;

@@ -99,10 +99,12 @@ struct Lu2MrWork {
   int32_t* info;
   int rank, nranks, bs, rpt, grid;
   int hier = 0;                              // two-hop exchange (ranks reduce among their own workgroups first)
+  int ov = 0;                                // the shard is taller than grid x 4096 rows: overflow rows evaluated lazily
   int poll_limit = 0;
 };
-bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier);
+bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier, int* ov);
 int lu2_mr_resident_per_cu(int bs, int rpt);
+int lu2_mr_resident_per_cu_ov();
 size_t lu2_mr_record_granules(int nranks, int grid);
 void lu2_leaf_mr(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t m, int64_t l,
                  int64_t jb, int64_t j0, int wd, const double* us, uint32_t epoch_base);

@@ -168,7 +168,7 @@ struct LuMrArgs {
   const double* us;                          // kp x LW, [c * LW + k]
   unsigned long long* peer[LU2_MAX_RANKS];   // every rank's record buffer (peer[rank] == recs)
 };
-// OV (single rank only): the panel is TALLER than the grid's registers hold.  Rows beyond the resident window -- [ovb, m),
+// OV: the panel (or, with MR, this rank's shard) is TALLER than the grid's registers hold.  Rows beyond the resident window -- [ovb, m),
 // ovb = j0 + 8 + grid * R * BS -- stay in HBM with their STORED leaf values and are evaluated lazily, as the streamed
 // leaves (lu3_*) do it: the pending update is applied to them once on the way in (written back), every pivot step
 // re-derives their candidates from the stored values and the pivot rows so far (s_u), the leaf's last act turns them into
@@ -205,7 +205,6 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
   __shared__ int32_t s_lr[OV ? LW : 1];         // OV: overflow rows that hold values eliminated through step s_ll - 1
   __shared__ int32_t s_ll[OV ? LW : 1];
   __shared__ int32_t s_nl;
-  static_assert(!(OV && MR), "overflow rows: single-rank kernel only");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x;
   const int Gl = gridDim.x;                                 // this rank's workgroups
@@ -342,7 +341,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
   }
 
   // ---- OV: the rows beyond the resident window ---------------------------------------------------------------
-  const int32_t ovb = j0 + LW + Gl * (R * BS);              // first overflow row
+  const int32_t ovb = ((gbase == 0) ? j0 + LW : 0) + Gl * (R * BS);   // first overflow row (LOCAL index, as every i below)
   const int32_t ovstride = Gl * BS;
   const int32_t ov0 = ovb + g * BS + tid;                   // this thread's overflow rows: ov0 + k ovstride < m
   // first step still to apply to overflow row i (0 unless it received an old row j during this leaf)
@@ -421,7 +420,7 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
             }
           }
           const double av = fabs(x[s]);
-          if (av > best) { best = av; besti = i; }
+          if (av > best) { best = av; besti = gbase + i; }
         }
       }
     }
@@ -435,11 +434,12 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
         for (int k = 0; k < LW; ++k) s_cand[wave][k] = d[k];
       }
       if constexpr (OV) {
-        if (besti >= ovb) {                     // an overflow row: all 8 of its current values
-          const int lev = ov_level(besti);
+        if (besti - gbase >= ovb) {             // an overflow row: all 8 of its current values
+          const int32_t bl = besti - gbase;
+          const int lev = ov_level(bl);
           double x[LW];
 #pragma unroll
-          for (int k = 0; k < LW; ++k) x[k] = (k < w) ? *elem(colbase(j0 + k), besti) : 0.0;
+          for (int k = 0; k < LW; ++k) x[k] = (k < w) ? *elem(colbase(j0 + k), bl) : 0.0;
 #pragma unroll
           for (int t = 0; t < s; ++t) {
             if (t >= lev) {
@@ -767,11 +767,12 @@ __global__ __launch_bounds__(BS) void lu_leaf_kernel(double* __restrict__ Y, int
           for (int k = 0; k < LW; ++k) s_u[s * LW + k] = u[k];
           s_rp[s] = rpiv;
         }
-        if (r >= ovb && r != j) {               // the pivot row was an overflow row: the old row j moves there, already
-          if (tid == 2 * LW) { const int q = s_nl; s_lr[q] = r; s_ll[q] = s; s_nl = q + 1; }     // eliminated through step s - 1
-          if ((r - ovb) % ovstride == g * BS + tid) {
+        const int32_t rl = r - gbase;           // (local index; on another rank's rows this is out of [ovb, m))
+        if (rl >= ovb && rl < m && r != j) {    // the pivot row was one of MY overflow rows: the old row j moves there, already
+          if (tid == 2 * LW) { const int q = s_nl; s_lr[q] = rl; s_ll[q] = s; s_nl = q + 1; }    // eliminated through step s - 1
+          if ((rl - ovb) % ovstride == g * BS + tid) {
 #pragma unroll
-            for (int k = 0; k < LW; ++k) if (k < w) *elem(colbase(j0 + k), r) = c_old[k];
+            for (int k = 0; k < LW; ++k) if (k < w) *elem(colbase(j0 + k), rl) = c_old[k];
           }
         }
       }
@@ -1087,8 +1088,16 @@ int lu2_resident_per_cu(int bs, int rpt) {
 // ---- the leaf launch of the MULTI-RANK factorization: this rank's rows, G = w.grid workgroups per rank, records exchanged
 //      through every rank's peer-mapped buffer.  Launch geometry for shards of at most `pad` rows on `nranks` ranks:
 //      nranks * grid <= 256 records, every rank the same (bs, rpt, grid).
-bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier) {
+bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier, int* ov) {
+  *ov = 0;
   if (nranks < 1 || nranks > LU2_MAX_RANKS) return false;
+  // GSI_LU_MR_OV_GRID=k (tests): at most k workgroups per rank, the rest of the shard as overflow rows
+  static const int ov_cap = getenv("GSI_LU_MR_OV_GRID") ? atoi(getenv("GSI_LU_MR_OV_GRID")) : 0;
+  static const int64_t ov_max = getenv("GSI_LU_OV_MAX") ? atoll(getenv("GSI_LU_OV_MAX")) : ((int64_t)5 << 20);
+  if (ov_cap > 0 && nranks > 1 && pad > (int64_t)ov_cap * 4096 && ov_cap <= std::min(256 - nranks, ncus)) {
+    *bs = 512; *rpt = 8; *grid = ov_cap; *hier = 1; *ov = 1;
+    return true;
+  }
   static const int cfg[4][2] = {{256, 1}, {256, 4}, {512, 4}, {512, 8}};
   static const char* he = getenv("GSI_LU_MR_HIER");              // 1: always two hops (tests), 0: never
   const bool force_hier = he != nullptr && he[0] == '1', no_hier = he != nullptr && he[0] == '0';
@@ -1106,6 +1115,12 @@ bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* gr
     const int64_t g = (pad + per - 1) / per;
     if (g <= gmax2) { *bs = cfg[c][0]; *rpt = cfg[c][1]; *grid = (int)std::max<int64_t>(g, 1); *hier = 1; return true; }
   }
+  // taller still (up to GSI_LU_OV_MAX rows per rank): every CU a <512, 8> workgroup, two hops, the rows beyond the resident
+  // window evaluated lazily (OV)
+  if (!no_hier && nranks > 1 && gmax2 >= 1 && pad <= ov_max && !(getenv("GSI_LU_OV") != nullptr && getenv("GSI_LU_OV")[0] == '0')) {
+    *bs = 512; *rpt = 8; *grid = gmax2; *hier = 1; *ov = 1;
+    return true;
+  }
   return false;
 }
 template <int BS, int R>
@@ -1116,6 +1131,13 @@ static void launch_leaf_mr_t(hipStream_t st, const Lu2MrWork& w, double* Y, int6
   a.hier = w.hier; a.slots = w.hier ? w.grid + w.nranks : w.nranks * w.grid;
   for (int q = 0; q < w.nranks; ++q) a.peer[q] = w.peer[q];
   const int poll_limit = w.poll_limit > 0 ? w.poll_limit : POLL_LIMIT;
+  if constexpr (BS == 512 && R == 8) {
+    if (w.ov) {                           // shards taller than the grid's registers: overflow rows evaluated lazily
+      hipLaunchKernelGGL((lu_leaf_kernel<512, 8, true, true>), dim3(w.grid), dim3(512), 0, st, Y, ld, (int32_t)mloc, (int32_t)l,
+                         (int32_t)jb, (int32_t)j0, wd, w.peer[w.rank], epoch_base, w.ipiv, w.info, 1, poll_limit, 0u, a);
+      return;
+    }
+  }
   hipLaunchKernelGGL((lu_leaf_kernel<BS, R, true>), dim3(w.grid), dim3(BS), 0, st, Y, ld, (int32_t)mloc, (int32_t)l, (int32_t)jb,
                      (int32_t)j0, wd, w.peer[w.rank], epoch_base, w.ipiv, w.info, 1, poll_limit, 0u, a);
 }
@@ -1125,6 +1147,14 @@ void lu2_leaf_mr(hipStream_t st, const Lu2MrWork& w, double* Y, int64_t ld, int6
   else if (w.bs == 256) launch_leaf_mr_t<256, 4>(st, w, Y, ld, mloc, row0, m, l, jb, j0, wd, us, epoch_base);
   else if (w.rpt == 4) launch_leaf_mr_t<512, 4>(st, w, Y, ld, mloc, row0, m, l, jb, j0, wd, us, epoch_base);
   else launch_leaf_mr_t<512, 8>(st, w, Y, ld, mloc, row0, m, l, jb, j0, wd, us, epoch_base);
+}
+int lu2_mr_resident_per_cu_ov() {
+  int nblk = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)lu_leaf_kernel<512, 8, true, true>, 512, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return nblk;
 }
 int lu2_mr_resident_per_cu(int bs, int rpt) {
   int nblk = 0;

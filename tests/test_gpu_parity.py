@@ -1521,22 +1521,28 @@ def _join_multirank(procs, marker, timeout=900):
 
 # hier: the sharded LU's TWO-hop pivot exchange (ranks reduce among their own workgroups, then exchange one record per rank:
 # what shards of more than 256 / nranks workgroups take -- 10^6 rows per rank), forced onto these small shards
+# "ov": at most 8 workgroups per rank, so that the 300 000 x 136 panel's shards are TALLER than the resident window and the
+# persistent leaves evaluate their overflow rows lazily (what shards of more than ~10^6 rows per rank take)
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,hier", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("world,hier", [(2, False), (3, False), (2, True), (2, "ov")])
 def test_multirank_pipeline_on_one_gpu(gsi, world, hier):
     env = {"GSI_LOCAL_COMM": "1"}
-    if hier:
+    if hier == "ov":
+        env["GSI_LU_MR_OV_GRID"] = "8"
+    elif hier:
         env["GSI_LU_MR_HIER"] = "1"
     _join_multirank([_spawn_multirank(_MULTIRANK_THREADS, [world], env)], "multirank-one-gpu-ok")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,hier", [(2, False), (3, False), (3, True)])
+@pytest.mark.parametrize("world,hier", [(2, False), (3, False), (3, True), (3, "ov")])
 def test_multirank_processes_on_one_gpu(gsi, world, hier, tmp_path):
     """One PROCESS per rank, all on GPU 0: what the rank threads cannot cover -- hipIpc mappings of another process's buffers,
     and persistent kernels of different processes exchanging pivots through them."""
     env = {"GSI_SHM_COMM": "1", "GSI_SHM_TIMEOUT_S": "120"}
-    if hier:
+    if hier == "ov":
+        env["GSI_LU_MR_OV_GRID"] = "8"
+    elif hier:
         env["GSI_LU_MR_HIER"] = "1"
     _join_multirank([_spawn_multirank(_MULTIRANK_PROCESS, [world, r, str(tmp_path)], env) for r in range(world)],
                     "multirank-processes-ok")

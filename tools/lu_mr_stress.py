@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gsi_amd as gsi
 from oracle import oracle as orc
 shapes = [(30000, 72), (5000, 24), (399, 24), (120000, 136), (3001, 40), (64000, 64), (100, 25), (640, 72)]   # incl. one-workgroup shards
+if os.environ.get("GSI_STRESS_SHAPES"):
+    shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["GSI_STRESS_SHAPES"].split(",")]
 panels = []
 for k, (m, l) in enumerate(shapes):
     rng = np.random.default_rng(100 + k)
@@ -68,7 +70,15 @@ def go(tag, env_extra, world, procs):
     print(f"{tag}: world {world}, {ITER} LUs per rank:", "OK" if ok else "FAILED", [o for _, o, _ in outs], flush=True)
     if not ok:
         print(outs); sys.exit(1)
+if os.environ.get("GSI_STRESS_ONLY"):          # e.g. GSI_STRESS_ONLY=procs:3:GSI_LU_MR_OV_GRID=40
+    kind, world, *kv = os.environ["GSI_STRESS_ONLY"].split(":")
+    extra = dict(t.split("=") for t in kv)
+    extra.update({"GSI_SHM_COMM": "1", "GSI_SHM_TIMEOUT_S": "120"} if kind == "procs" else {"GSI_LOCAL_COMM": "1"})
+    go(os.environ["GSI_STRESS_ONLY"], extra, int(world), kind == "procs")
+    sys.exit(0)
 go("threads, one hop", {"GSI_LOCAL_COMM": "1"}, 3, False)
 go("threads, two hops", {"GSI_LOCAL_COMM": "1", "GSI_LU_MR_HIER": "1"}, 2, False)
 go("processes, one hop", {"GSI_SHM_COMM": "1", "GSI_SHM_TIMEOUT_S": "120"}, 3, True)
 go("processes, two hops", {"GSI_SHM_COMM": "1", "GSI_SHM_TIMEOUT_S": "120", "GSI_LU_MR_HIER": "1"}, 4, True)
+go("threads, overflow rows (2 workgroups per rank)", {"GSI_LOCAL_COMM": "1", "GSI_LU_MR_OV_GRID": "2"}, 2, False)
+go("processes, overflow rows (2 workgroups per rank)", {"GSI_SHM_COMM": "1", "GSI_SHM_TIMEOUT_S": "120", "GSI_LU_MR_OV_GRID": "2"}, 3, True)
