@@ -100,6 +100,11 @@ class Backend {
   //      leaf's pending update comes from lus_u12_leaf + all-reduce as before; lus_swap_pack / _apply move the rows the
   //      leaf's pivots exchange in the columns OUTSIDE the leaf (table: 16 x l doubles, all-reduced in between).
   virtual bool lus_mr_begin(class Comm* comm, int64_t m, int64_t l) { (void)comm; (void)m; (void)l; return false; }
+  // The exchange has three forms -- 0: one hop, 1: two hops, 2: two hops with lazily evaluated overflow rows -- chosen by the
+  // shard height.  lus_mr_mode: the form the last successful lus_mr_begin chose; lus_mr_force (self-test): the form the next
+  // ones must take (1, 2) or the natural choice again (0).
+  virtual int lus_mr_mode() { return 0; }
+  virtual void lus_mr_force(int mode) { (void)mode; }
   virtual void lus_leaf_mr(double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, const double*) {}
   virtual bool lus_mr_swaps_done() { return false; }   // lus_leaf_mr also moved the rows in the other columns (peer pushes)
   virtual void lus_swap_pack(const double*, int64_t, int64_t, int64_t, int64_t, int64_t, int, double*) {}

@@ -557,7 +557,7 @@ class HipBackend : public Backend {
     const int se_cus = std::max(ncus_ / 32, 1);                        // CUs per shader engine (8)
     const int per_se = sharing > 1 ? std::max(se_cus / sharing, 0) : se_cus;
     if (per_se < 1) return false;
-    if (!hipk::lu2_mr_config(pad, G, sharing > 1 ? per_se * 32 : ncus_, &w.bs, &w.rpt, &w.grid, &w.hier, &w.ov)) return false;
+    if (!hipk::lu2_mr_config(pad, G, sharing > 1 ? per_se * 32 : ncus_, &w.bs, &w.rpt, &w.grid, &w.hier, &w.ov, mr_force_)) return false;
     const int key = 1000000 + w.bs * 16 + w.rpt + (w.ov ? 100000 : 0);
     auto it = lu2_resident_.find(key);
     if (it == lu2_resident_.end())
@@ -602,6 +602,8 @@ class HipBackend : public Backend {
     check_launch("lu2_leaf_mr");
   }
   bool lus_mr_swaps_done() override { return mr_peer_swaps_; }
+  int lus_mr_mode() override { return mr_work_.ov ? 2 : (mr_work_.hier ? 1 : 0); }
+  void lus_mr_force(int mode) override { mr_force_ = mode; }
   void lus_swap_pack(const double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t l, int64_t j0, int w,
                      double* table) override {
     bind();
@@ -1077,6 +1079,7 @@ class HipBackend : public Backend {
   std::map<int, int> lu2_resident_;   // (bs, rpt) -> resident workgroups per CU of that leaf instantiation
   bool lu2_lost_ = false, lu2_retry_ = false;
   int lu2_ov_resident_ = -1;
+  int mr_force_ = 0;
   // multi-rank persistent leaves: this rank's record buffer, the peers' (as this rank addresses them), the running epoch
   unsigned long long* mr_recs_ = nullptr;
   unsigned long long* mr_peer_[hipk::LU2_MAX_RANKS] = {nullptr};

@@ -102,7 +102,7 @@ struct Lu2MrWork {
   int ov = 0;                                // the shard is taller than grid x 4096 rows: overflow rows evaluated lazily
   int poll_limit = 0;
 };
-bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier, int* ov);
+bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier, int* ov, int force = 0);
 int lu2_mr_resident_per_cu(int bs, int rpt);
 int lu2_mr_resident_per_cu_ov();
 size_t lu2_mr_record_granules(int nranks, int grid);

@@ -1088,9 +1088,14 @@ int lu2_resident_per_cu(int bs, int rpt) {
 // ---- the leaf launch of the MULTI-RANK factorization: this rank's rows, G = w.grid workgroups per rank, records exchanged
 //      through every rank's peer-mapped buffer.  Launch geometry for shards of at most `pad` rows on `nranks` ranks:
 //      nranks * grid <= 256 records, every rank the same (bs, rpt, grid).
-bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier, int* ov) {
+bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* grid, int* hier, int* ov, int force) {
   *ov = 0;
   if (nranks < 1 || nranks > LU2_MAX_RANKS) return false;
+  if (force == 2) {                        // (self-test) two workgroups per rank, the rest of the shard as overflow rows
+    if (nranks < 2 || pad <= 2 * 4096 || ncus < 2) return false;
+    *bs = 512; *rpt = 8; *grid = 2; *hier = 1; *ov = 1;
+    return true;
+  }
   // GSI_LU_MR_OV_GRID=k (tests): at most k workgroups per rank, the rest of the shard as overflow rows
   static const int ov_cap = getenv("GSI_LU_MR_OV_GRID") ? atoi(getenv("GSI_LU_MR_OV_GRID")) : 0;
   static const int64_t ov_max = getenv("GSI_LU_OV_MAX") ? atoll(getenv("GSI_LU_OV_MAX")) : ((int64_t)5 << 20);
@@ -1100,7 +1105,7 @@ bool lu2_mr_config(int64_t pad, int nranks, int ncus, int* bs, int* rpt, int* gr
   }
   static const int cfg[4][2] = {{256, 1}, {256, 4}, {512, 4}, {512, 8}};
   static const char* he = getenv("GSI_LU_MR_HIER");              // 1: always two hops (tests), 0: never
-  const bool force_hier = he != nullptr && he[0] == '1', no_hier = he != nullptr && he[0] == '0';
+  const bool force_hier = (he != nullptr && he[0] == '1') || force == 1, no_hier = he != nullptr && he[0] == '0' && force != 1;
   // one hop: every workgroup of every rank is a record of the exchange (nranks * grid <= 256)
   const int gmax = std::min(256 / nranks, ncus);
   for (int c = 0; c < 4 && !force_hier; ++c) {

@@ -387,28 +387,36 @@ static bool all_ranks_agree(Context& c, bool mine) {
 // factored by the per-step form and by the persistent leaves; the fast path is used only if every rank got bit-identical
 // factors and no kernel raised a flag.  Anything else -- a mapping that failed, a poll that timed out -- leaves the per-step
 // form in charge, silently and on all ranks.
-static bool lus_mr_selftest(Context& c) {
+static int lus_mr_selftest(Context& c) {
   Backend* be = c.be.get();
   const int G = c.nranks(), rank = c.rank();
-  const int64_t rows = 2048, lt = 24, mt = rows * G;
-  bool ok = all_ranks_agree(c, be->lus_mr_begin(c.comm.get(), mt, lt));
-  if (!ok) return false;
-  Buf A(be, (size_t)rows * lt), B(be, (size_t)rows * lt);
-  be->randn(A.p, (size_t)rows * lt, 0x5e1f7e57ull + (uint64_t)rank);
-  be->copy2d(B.p, rows, A.p, rows, rows, lt);
-  bool mine = true;
-  try {
-    lu_panel_sharded_impl(c, A.p, mt, rows * rank, rows, lt, false);
-    lu_panel_sharded_impl(c, B.p, mt, rows * rank, rows, lt, true);
-    be->axpy(rows * lt, -1.0, A.p, B.p);
-    mine = (be->nrm2(rows * lt, B.p) == 0.0);
-    std::string msg;
-    if (be->take_error(&msg) != 0) mine = false;
-  } catch (const Error&) {
-    mine = false;
+  int forms = 0;
+  for (int form = 0; form < 3; ++form) {          // every form the exchange can take has to prove itself (see Backend::lus_mr_mode)
+    const int64_t rows = (form == 2) ? 12288 : 2048, lt = 24, mt = rows * G;
+    be->lus_mr_force(form);
+    bool mine = false;
+    if (all_ranks_agree(c, be->lus_mr_begin(c.comm.get(), mt, lt) && be->lus_mr_mode() == form)) {
+      Buf A(be, (size_t)rows * lt), B(be, (size_t)rows * lt);
+      be->randn(A.p, (size_t)rows * lt, 0x5e1f7e57ull + (uint64_t)rank + 131ull * (uint64_t)form);
+      be->copy2d(B.p, rows, A.p, rows, rows, lt);
+      mine = true;
+      try {
+        lu_panel_sharded_impl(c, A.p, mt, rows * rank, rows, lt, false);
+        lu_panel_sharded_impl(c, B.p, mt, rows * rank, rows, lt, true);
+        be->axpy(rows * lt, -1.0, A.p, B.p);
+        mine = (be->nrm2(rows * lt, B.p) == 0.0);
+        std::string msg;
+        if (be->take_error(&msg) != 0) mine = false;
+      } catch (const Error&) {
+        mine = false;
+      }
+      be->forgive_lost_coresidency();        // a time-out in here must not cost the context its single-GPU fast path
+      if (all_ranks_agree(c, mine)) forms |= 1 << form;
+      else if (form == 0) break;             // the plain form failed: nothing to build the others on
+    }
   }
-  be->forgive_lost_coresidency();          // a time-out in here must not cost the context its single-GPU fast path
-  return all_ranks_agree(c, mine);
+  be->lus_mr_force(0);
+  return forms;
 }
 
 void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l) {
@@ -421,10 +429,12 @@ void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t
   // communicator.
   bool mr = false;
   if (c.comm) {
-    if (c.lus_mr_selftest < 0) c.lus_mr_selftest = lus_mr_selftest(c) ? 1 : 0;
-    if (c.lus_mr_selftest == 1) {
+    if (c.lus_mr_selftest < 0) c.lus_mr_selftest = lus_mr_selftest(c);
+    if (c.lus_mr_selftest != 0) {
       auto it = c.lus_mr_ok.find(m);
-      if (it == c.lus_mr_ok.end()) it = c.lus_mr_ok.emplace(m, all_ranks_agree(c, be->lus_mr_begin(c.comm.get(), m, l))).first;
+      if (it == c.lus_mr_ok.end())
+        it = c.lus_mr_ok.emplace(m, all_ranks_agree(c, be->lus_mr_begin(c.comm.get(), m, l) &&
+                                                         ((c.lus_mr_selftest >> be->lus_mr_mode()) & 1) != 0)).first;
       mr = it->second && be->lus_mr_begin(c.comm.get(), m, l);
     }
     if (!mr && getenv("GSI_LU_MR_REQUIRE") != nullptr)      // tests: the in-kernel exchange must be what runs

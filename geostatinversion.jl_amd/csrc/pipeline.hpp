@@ -32,7 +32,8 @@ struct Context {
   std::unique_ptr<Backend> be;
   std::unique_ptr<Comm> comm;  // null when single rank
   std::map<int64_t, bool> lus_mr_ok;   // panel height -> all ranks can run the sharded LU with in-kernel pivot exchange
-  int lus_mr_selftest = -1;            // -1 not run yet; 1 / 0: the in-kernel exchange reproduced the per-step factors on this communicator
+  int lus_mr_selftest = -1;            // -1 not run yet; else bit f set: form f of the in-kernel exchange (0 one hop, 1 two hops,
+                                       // 2 two hops + overflow rows) reproduced the per-step factors on this communicator
   int rank() const { return comm ? comm->rank : 0; }
   int nranks() const { return comm ? comm->nranks : 1; }
 };
