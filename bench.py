@@ -9,6 +9,13 @@ A = LowRankCovMatrix over N_s = 1024 synthetic sample fields (8.2 GB of mean-rem
 the device), K = 256, p = 64 (l = 320), q = 2.  Every product A*X is two MFMA contractions S (S'X)/(N_s-1).
 For --gpus N > 1 the SAME problem is row-sharded over the ranks (`--scaling strong`, the default: north_star's
 ">= 6x at 8 GPUs" is a strong-scaling statement); `--scaling weak` gives every rank 10^6 rows instead.
+`python3 bench.py --gpus N` starts its own N rank processes (fresh children, spawned before this process touches the
+GPU; one per device) and relays rank 0's line; under torch.distributed.run (RANK / WORLD_SIZE in the environment) it
+is one of the ranks.  Either way the ranks find each other through a directory (the communicator id as a file) and
+every barrier / reduction of the harness goes through the library's own communicator (gsi_ctx_host_allgather):
+no torch, no second communication layer.  The N > 1 line also carries which LU form ran (path_counters.lu_form, the
+self-test mask of the in-kernel pivot exchange, collectives per step, ranks seen) and ONE row-sharded step of the
+n = 10^6 implicit dense covariance -- the operator north_star's ">= 6x at 8 GPUs" is about.
 
 metric value = algorithmic GB/s of the whole job: [(2q+2) products x (16 n N_s + 16 n l) + (2q + 2) panel
                factorizations x 16 n l] bytes / step time        
@@ -16,8 +23,8 @@ roofline     = the dominant kernel, the fp64 MFMA contraction gemm_f64_kernel: 2
                average launch duration (HIP events on the library's stream around every operator contraction inside
                the timed region), against the 78.6 TFLOP/s dense fp64 MFMA peak; the same launches against the HBM
                peak ("hbm"); `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of this very command
-               (tools/profile_bench.sh -> profiles/r02_bench_traffic.json; null when that file was collected on a
-               different build of the kernel)
+               (tools/pmc_bench_traffic.sh -> profiles/r04_bench_traffic.json, older rounds' files behind it; keyed on a
+               hash over all of csrc/ + the public header: null when collected on a different build)
 phases_hbm   = the HBM-bound panel phases (LU, QR, Z = Q_W U): one read + one write of the n x l panel per
                factorization over the measured time per factorization, against 8 TB/s
 secondary    = BASELINE.json configs[1] (dense fp64 65536^2, K = 128, q = 2: the MFMA-bound stored operator), the
@@ -31,7 +38,10 @@ import argparse
 import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,7 +50,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILES = ["r03_bench_traffic.json", "r02_bench_traffic.json"]   # newest first; replayed only on a hash match
+TRAFFIC_FILES = ["r04_bench_traffic.json", "r03_bench_traffic.json", "r02_bench_traffic.json"]   # newest first; replayed only on a hash match
 
 
 def kernel_source_hash():
@@ -124,6 +134,7 @@ def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234, keep=
     barrier()
     elapsed = time.perf_counter() - t0
     phases = ctx.phase_times()
+    run_steps.last_path_info = ctx.path_info()      # LU forms / collectives of exactly the timed steps (reset by phase_reset)
     ctx.profile(False)
     Sh = S.to_host()[:, 0].copy()
     if keep is not None:                 # the caller compares this very step with the oracle (full-size parity leg)
@@ -133,6 +144,9 @@ def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234, keep=
     for m in (Omega, Z, S):
         m.close()
     return elapsed, phases, Sh
+
+
+run_steps.last_path_info = None
 
 
 def host_threads():
@@ -239,23 +253,68 @@ def secondary_c2(gsi, ctx, barrier):
         "phases_ms_per_step": {k: v[0] / 5 for k, v in ph2.items()}}
 
 
-def secondary_implicit(gsi, ctx, barrier):
-    """n = 1e6 dense covariance, never stored (north_star "10^6 x 10^6-implicit"): ONE step, no warm-up."""
+def one_gpu_implicit_reference():
+    """The 1-GPU time of the implicit 10^6 step as the driver last recorded it (BENCH_rNN.json of an earlier round, or the
+    builder's committed line): carried beside the N-rank step, never re-measured inside an N > 1 run (61 s of one GPU)."""
+    cands = sorted([f for f in os.listdir(ROOT) if f.startswith("BENCH_r") and f.endswith(".json")], reverse=True)
+    cands = [os.path.join(ROOT, f) for f in cands] + [os.path.join(ROOT, "profiles", f) for f in ("r04_bench_line.json", "r03_bench_line.json")]
+    for path in cands:
+        try:
+            d = json.load(open(path))
+            d = d.get("parsed", d)
+            if d.get("n_gpus", 1) != 1:
+                continue
+            ms = d["secondary"]["implicit_dense_1e6"]["ms_per_step"]
+            return {"ms_per_step": float(ms), "source": os.path.relpath(path, ROOT) + " (recorded 1-GPU line, not re-measured in this run)"}
+        except Exception:                                   # noqa: BLE001
+            continue
+    return None
+
+
+def secondary_implicit(gsi, ctx, barrier, rows=False, max_over_ranks=None):
+    """n = 1e6 dense covariance, never stored (north_star "10^6 x 10^6-implicit"): ONE step, no warm-up.  rows=True (N > 1):
+    the operator row-sharded over the ranks, gsi_randsvd_rows (Omega gathered for the products, panel LUs replicated on the
+    gathered panels, TSQR, Z as row shards) -- the step north_star's ">= 6x at 8 GPUs" is about."""
+    import numpy as np
     gi, K3, p3, q3 = 1000, 256, 64, 2
     n3, l3 = gi * gi, K3 + p3
     op3 = gsi.gridcov_implicit_operator(ctx, gi, gi, 100.0, kind=1)      # exponential kernel, ell = 100 (SURVEY 8d C4-i)
-    e3, ph3, _ = run_steps(gsi, ctx, op3, n3, K3, p3, q3, 1, 0, barrier)
+    keep = {} if rows else None
+    e3, ph3, S3 = run_steps(gsi, ctx, op3, n3, K3, p3, q3, 1, 0, barrier, keep=keep, rows=rows)
+    pinfo = run_steps.last_path_info
     op3.close()
+    extra = {}
+    if rows:
+        e3 = max_over_ranks(e3)
+        # size-independent check of the sharded result: Z = V sqrt(S) has |Z[:, i]|^2 = S_i, columns beyond K zero -- the column
+        # norms summed over the ranks' row blocks against the replicated singular values
+        Zl = keep["Z"].to_host()
+        keep["Omega"].close()
+        keep["Z"].close()
+        part = np.concatenate([(Zl[:, :K3] ** 2).sum(axis=0), [float(np.abs(Zl[:, K3:]).max()) if Zl.shape[0] else 0.0]])
+        tot = ctx.host_allgather(part)
+        col2 = tot[:, :K3].sum(axis=0)
+        world = ctx.rank()[1]
+        extra = {"n_gpus": world, "parallelism": f"row-shard x{world} (gsi_randsvd_rows)",
+                 "ZtZ_diag_vs_S_max_rel": float(np.max(np.abs(col2 - S3[:K3]) / S3[:K3])),
+                 "trailing_p_columns_max_abs": float(tot[:, K3].max()),
+                 "sv_descending_positive": bool(all(S3[i] >= S3[i + 1] for i in range(l3 - 1)) and S3[K3 - 1] > 0),
+                 "lu_form": pinfo["lu_form"], "collectives_per_step": pinfo["collectives"],
+                 "one_gpu_reference": one_gpu_implicit_reference()}
+        ref = extra["one_gpu_reference"]
+        if ref:
+            extra["speedup_vs_recorded_one_gpu"] = ref["ms_per_step"] / (1e3 * e3)
     gm = ph3["gemm_n"][0] + ph3["gemm_t"][0]
     gc = ph3["gemm_n"][1] + ph3["gemm_t"][1]
-    tf = 2.0 * n3 * n3 * l3 / (gm / gc * 1e-3) / 1e12
+    nloc3 = ctx.shard(n3)[1]
+    tf = 2.0 * nloc3 * n3 * l3 / (gm / gc * 1e-3) / 1e12              # this rank's contraction launches (its rows of A)
     return {
         "workload": f"implicit dense fp64 {n3}x{n3} exponential grid covariance exp(-d/100) (1000x1000 grid; 8 TB if "
                     f"stored), K={K3}, p={p3}, q={q3}: entries generated inside the contraction kernel from an 8 MB "
                     "table of the kernel over grid offsets",
         "steps": 1, "ms_per_step": 1e3 * e3, "equivalent_stored_GB/s": dense_bytes(n3, l3, q3) / e3 / 1e9,
         "gemm_TFLOP/s": tf, "gemm_frac_of_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
-        "phases_ms_per_step": {k: v[0] for k, v in ph3.items()}}
+        "phases_ms_per_step": {k: v[0] for k, v in ph3.items()}, **extra}
 
 
 def secondary_fft_1000sq(gsi, ctx, barrier):
@@ -455,12 +514,93 @@ def same_numbers_as_one_gpu(gsi, device, n, Ns, decay, K, p, q, world, seed, Sv,
             "what": "rank 0 re-runs the step on one GPU (no communicator) from the same samples and the stacked Omega blocks"}
 
 
+def spawn_ranks(n):
+    """`python3 bench.py --gpus N` without a launcher: THIS process becomes the launcher.  It never touches the GPU (no HIP
+    call, the product library is not even loaded here) -- N fresh children are started with RANK / LOCAL_RANK / WORLD_SIZE
+    and a rendezvous directory in their environment, rank 0's stdout (the one JSON line) is relayed, and the exit status is
+    non-zero if any child's is."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    rdv = tempfile.mkdtemp(prefix="gsi-bench-", dir=base)
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "GSI_BENCH_RDV": rdv})
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr))
+        import threading
+        got = []
+        reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+        reader.start()                           # rank 0's one line arrives at the very end; never block the watch loop on it
+        failed = None
+        deadline = None
+        while any([pr.poll() is None for pr in procs]):      # (a list: every child is polled on every round)
+            for r, pr in enumerate(procs):
+                if pr.returncode not in (None, 0) and failed is None:
+                    failed = r
+                    open(os.path.join(rdv, "failed"), "w").write("rank %d exited with %d\n" % (r, pr.returncode))
+                    # the others see the marker at their next rendezvous wait, or are ended after a grace period
+                    deadline = time.time() + float(os.environ.get("GSI_BENCH_FAIL_GRACE_S", "60"))
+            if deadline is not None and time.time() > deadline:
+                for pr in procs:
+                    if pr.poll() is None:
+                        pr.kill()                    # exactly the children started above
+            time.sleep(0.05)
+        rcs = [pr.returncode for pr in procs]
+        if any(rc != 0 for rc in rcs):
+            sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+            rc = rcs[failed] if failed is not None else next(rc for rc in rcs if rc != 0)
+            return rc if 0 < rc < 256 else 1          # the rank that failed first, not the ones ended because of it
+        reader.join(timeout=30)
+        sys.stdout.buffer.write(got[0] if got else b"")
+        sys.stdout.flush()
+        return 0
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        shutil.rmtree(rdv, ignore_errors=True)
+
+
+class Rendezvous:
+    """How the rank processes find each other before the communicator exists: files in a directory all of them can see
+    (spawn_ranks creates it; under torch.distributed.run it is derived from the launcher's pid and port)."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.dir = os.environ.get("GSI_BENCH_RDV")
+        self.own = False
+        if not self.dir:
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            self.dir = os.path.join(base, "gsi-bench-%s-%s-%d" % (os.environ.get("MASTER_PORT", "0"),
+                                                                  os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
+            os.makedirs(self.dir, exist_ok=True)
+            self.own = True
+
+    def broadcast(self, name, data=None, timeout=900):
+        path = os.path.join(self.dir, name)
+        if self.rank == 0:
+            with open(path + ".tmp", "wb") as f:
+                f.write(data)
+            os.rename(path + ".tmp", path)
+            return data
+        t0 = time.time()
+        while not os.path.exists(path):
+            if os.path.exists(os.path.join(self.dir, "failed")):
+                raise SystemExit("bench.py: another rank failed: " + open(os.path.join(self.dir, "failed")).read().strip())
+            if time.time() - t0 > timeout:
+                raise SystemExit("bench.py: timed out waiting for rank 0's " + name)
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            return f.read()
+
+    def close(self):
+        if self.own and self.rank == 0:
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
 def main():
-    # stdout carries exactly ONE line (the JSON result of rank 0): libraries that chat on fd 1 (gloo's
-    # "[Gloo] Rank 0 is connected ...", RCCL's version banner) are sent to stderr for the whole run.
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -478,14 +618,34 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=16384)
     ap.add_argument("--no-full-parity", action="store_true",
                     help="skip the oracle run at the headline size (about 1-2 min of host LAPACK, ~40 GB of host memory)")
+    ap.add_argument("--no-implicit", action="store_true",
+                    help="N > 1: skip the one row-sharded step of the implicit 10^6 x 10^6 covariance")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))            # the launcher: no GPU call before or after this line
+    # stdout carries exactly ONE line (the JSON result of rank 0): libraries that chat on fd 1 (RCCL's version banner)
+    # are sent to stderr for the whole run.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("GSI_BENCH_LAUNCH_TEST"):          # tests/test_bench_launcher.py: the launcher alone, on a box without a GPU
+        rv = Rendezvous(rank, world)
+        token = rv.broadcast("uid", b"launch-test" if rank == 0 else None)
+        if os.environ["GSI_BENCH_LAUNCH_TEST"] == "fail" and rank == 1:
+            raise SystemExit(3)
+        if os.environ["GSI_BENCH_LAUNCH_TEST"] == "fail" and rank == 0:
+            rv.broadcast("never-written-by-anyone" if False else "uid2", b"x")
+            time.sleep(600)                              # a rank stuck in a collective its failed peer never enters
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"launch_test": world, "token": token.decode(), "gpu_modules_loaded":
+                                             any("gsi_amd" in m or m == "torch" for m in sys.modules)}) + "\n").encode())
+        return
     import gsi_amd as gsi
 
     # rehearsal of the N > 1 run on a ONE-GPU box: every rank a process on device 0, joined by the library's shared-memory
@@ -495,33 +655,28 @@ def main():
     if one_gpu:
         local_rank = 0
         os.environ["GSI_SHM_COMM"] = "1"
-    dist = None
     use_dist = world > 1 or bool(os.environ.get("GSI_BENCH_FORCE_DIST"))   # the latter: rehearse the N > 1 code on one GPU
+    rdv = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: no hostname resolution for the rendezvous group
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # rendezvous / barrier only
 
     ctx = gsi.Context(local_rank)
     if use_dist:
-        ids = [ctx.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(world, rank, ids[0])                  # RCCL communicator over xGMI
+        # rank 0 makes the communicator id and ships it as a file; from comm_init on, every barrier and reduction of this
+        # harness goes through the library's communicator (RCCL over xGMI; shared memory in the one-GPU rehearsal)
+        rdv = Rendezvous(rank, world)
+        uid = rdv.broadcast("uid", bytes(ctx.unique_id()) if rank == 0 else None)
+        ctx.comm_init(world, rank, uid)
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            dist.barrier()
+        if use_dist:
+            ctx.barrier()
 
     def max_over_ranks(x):
-        if dist is None:
+        if not use_dist:
             return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(ctx.host_allgather([x]).max())
 
     # ---------------- headline: n = 1e6 LowRankCovMatrix, rank 256 -------------------------------------------
     n = args.n if args.scaling == "strong" else args.n * world
@@ -536,6 +691,14 @@ def main():
     elapsed, phases, Sv = run_steps(gsi, ctx, op, n, K, p, q, args.steps, args.warmup, barrier, keep=keep, rows=use_dist)
     elapsed = max_over_ranks(elapsed)
     counters = ctx.counters()
+    pinfo = run_steps.last_path_info
+    counters.update({"lu_form": pinfo["lu_form"], "lu_forms_run_in_timed_steps": pinfo["lu_forms_run"],
+                     "lu_selftest_mask": pinfo["lu_selftest_mask"],
+                     "collectives_per_step": pinfo["collectives"] / max(args.steps, 1), "n_ranks_seen": pinfo["n_ranks_seen"],
+                     "lu_timeouts": pinfo["lu_timeouts"], "lu_timeouts_recovered": pinfo["lu_timeouts_recovered"]})
+    if use_dist:                         # every rank must have run the same form: a rank that fell back alone is a bug
+        forms = ctx.host_allgather([float(gsi.Context.LU_FORMS.index(pinfo["lu_form"])), float(pinfo["lu_selftest_mask"])])
+        counters["lu_form_same_on_all_ranks"] = bool((forms == forms[0]).all())
     dev_bytes = ctx.device_bytes()
     host = None
     Z0_rows = None
@@ -565,7 +728,7 @@ def main():
     traffic = None
     panel_traffic = {}
     traffic_source = None
-    for tname in TRAFFIC_FILES if world == 1 else []:
+    for tname in TRAFFIC_FILES if world == 1 and not use_dist else []:
         tpath = os.path.join(ROOT, "profiles", tname)
         if not os.path.exists(tpath):
             continue
@@ -640,6 +803,15 @@ def main():
             except Exception as exc:                        # noqa: BLE001 -- the check must not take the line down
                 out["multi_rank_vs_one_gpu"] = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # ---------------- N > 1: ONE row-sharded step of the operator north_star's ">= 6x at 8 GPUs" names ---------------
+    if world > 1 and not args.no_implicit and not args.no_secondary:
+        try:
+            imp = secondary_implicit(gsi, ctx, barrier, rows=True, max_over_ranks=max_over_ranks)
+        except gsi.GsiError as exc:                     # a library error on this rank: the other ranks see theirs or time out
+            imp = {"error": f"{type(exc).__name__}: {exc}"}
+        if rank == 0:
+            out["secondary"] = {"implicit_dense_1e6": imp}
+
     # ---------------- secondary workloads (one GPU only) -------------------------------------------------------
     if world == 1 and not args.no_secondary:
         sec = {}
@@ -691,9 +863,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if use_dist:
+        ctx.barrier()
+        rdv.close()
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -34,6 +34,7 @@ SIGNATURES = {
     "gsi_comm_unique_id": (C.c_int, [c_vp]),
     "gsi_ctx_comm_init": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp]),
     "gsi_ctx_rank": (C.c_int, [c_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gsi_ctx_host_allgather": (C.c_int, [c_vp, c_dp, c_i64, c_dp]),
     "gsi_op_dense": (C.c_int, [c_vp, C.POINTER(c_vp), c_dp, c_i64, c_i64, c_i64, c_i64, c_i64]),
     "gsi_op_lowrank": (C.c_int, [c_vp, C.POINTER(c_vp), c_dp, c_i64, c_i64, c_i64, C.c_int, c_i64, c_i64]),
     "gsi_op_lowrank_synthetic": (C.c_int, [c_vp, C.POINTER(c_vp), c_i64, c_i64, C.c_uint64, C.c_double, c_i64, c_i64]),
@@ -88,6 +89,7 @@ SIGNATURES = {
     "gsi_ctx_phase_reset": (C.c_int, [c_vp]),
     "gsi_ctx_phase_times": (C.c_int, [c_vp, c_dp, C.POINTER(c_i64)]),
     "gsi_ctx_counters": (C.c_int, [c_vp, C.POINTER(c_i64)]),
+    "gsi_ctx_path_info": (C.c_int, [c_vp, C.POINTER(c_i64), c_i64]),
     "gsi_ctx_release_cache": (C.c_int, [c_vp]),
     "gsi_ctx_device_bytes": (C.c_int, [c_vp, C.POINTER(c_i64)]),
 }

@@ -49,6 +49,17 @@ class Context:
         L.check(self.lib.gsi_ctx_rank(self.h, C.byref(r), C.byref(n)), self.lib)
         return r.value, n.value
 
+    def host_allgather(self, values):
+        """Every rank's `values` (a few host doubles) on every rank, rank-major (`gsi_ctx_host_allgather`): the job's barrier
+        and its way to the slowest rank's time -- no second communication layer beside the library's communicator."""
+        v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64)
+        out = np.empty((self.rank()[1], v.size))
+        L.check(self.lib.gsi_ctx_host_allgather(self.h, L.dptr(v), v.size, L.dptr(out)), self.lib)
+        return out
+
+    def barrier(self):
+        self.host_allgather([0.0])
+
     def shard(self, m):
         """Block-row layout the library expects: pad = ceil(m/nranks), row0 = rank*pad."""
         r, n = self.rank()
@@ -73,6 +84,20 @@ class Context:
         out = (C.c_int64 * 4)()
         L.check(self.lib.gsi_ctx_counters(self.h, out), self.lib)
         return {"cholqr2": out[0], "householder": out[1], "jacobi_sweeps": out[2], "scholqr3": out[3]}
+
+    LU_FORMS = ["none", "replicated", "per-step", "persistent-1hop", "persistent-2hop", "persistent-ov"]
+
+    def path_info(self):
+        """Which path ran under the communicator (`gsi_ctx_path_info`): the form of the panel LUs (and how many ran in each
+        form since the last phase_reset), the self-test mask of the in-kernel pivot exchange, collectives entered since the
+        last phase_reset, the ranks the communicator joined, LU time-outs seen / hidden by a transparent re-run."""
+        n = 12
+        out = (C.c_int64 * n)()
+        L.check(self.lib.gsi_ctx_path_info(self.h, out, n), self.lib)
+        forms = {self.LU_FORMS[f]: int(out[6 + f]) for f in range(1, 6) if out[6 + f]}
+        return {"lu_form": self.LU_FORMS[out[0]] if 0 <= out[0] < 6 else int(out[0]), "lu_forms_run": forms,
+                "lu_selftest_mask": int(out[1]), "collectives": int(out[2]), "n_ranks_seen": int(out[3]),
+                "lu_timeouts": int(out[4]), "lu_timeouts_recovered": int(out[5])}
 
     def release_cache(self):
         """Return cached device memory (released panels, idle workspaces) to the driver (`gsi_ctx_release_cache`)."""

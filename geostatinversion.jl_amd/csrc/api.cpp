@@ -76,6 +76,7 @@ void with_retry(Context& c, F&& f) {
     // GSI_NO_RETRY: tests of the error path.  With a communicator the ranks must agree on what runs next: no silent re-run
     // (every rank saw the same time-out and has switched paths; the caller repeats the collective call)
     if (!c.be->retryable_failure() || c.comm || getenv("GSI_NO_RETRY") != nullptr) throw;
+    c.lu_timeouts_recovered += 1;      // visible in gsi_ctx_path_info: the re-run must not hide that a time-out happened
     f();
   }
 }
@@ -149,6 +150,52 @@ int gsi_ctx_comm_init(gsi_ctx* ctx, int nranks, int rank, const void* id) {
     // path (library loading, stream-ordered collectives) can be exercised on a single GPU
     if (nranks == 1 && getenv("GSI_FORCE_COMM") == nullptr) return;
     ctx->c.comm.reset(make_comm(ctx->c.be.get(), nranks, rank, id));
+    // how many ranks the communicator really joins: one per rank, summed through it
+    Context& c = ctx->c;
+    const double one = 1.0;
+    double seen = 0.0;
+    Buf b(c.be.get(), 1);
+    c.be->upload2d(b.p, 1, &one, 1, 1, 1);
+    c.comm->allreduce_sum(b.p, 1);
+    c.be->download2d(&seen, 1, b.p, 1, 1, 1);
+    c.ranks_seen = (int64_t)(seen + 0.5);
+    c.comm->ncollectives = 0;
+  });
+}
+
+int gsi_ctx_host_allgather(gsi_ctx* ctx, const double* mine, int64_t count, double* all_out) {
+  return guarded([&] {
+    REQUIRE(ctx && mine && all_out && count >= 1, "bad argument");
+    Context& c = ctx->c;
+    c.be->sync();
+    if (!c.comm) {
+      std::memcpy(all_out, mine, sizeof(double) * (size_t)count);
+      return;
+    }
+    const int G = c.nranks();
+    Buf send(c.be.get(), (size_t)count), recv(c.be.get(), (size_t)count * G);
+    c.be->upload2d(send.p, count, mine, count, count, 1);
+    const int64_t before = c.comm->ncollectives;
+    c.comm->allgather(send.p, recv.p, (size_t)count);
+    c.comm->ncollectives = before;          // a host-side barrier / exchange of the caller's is not part of the data path
+    c.be->download2d(all_out, count, recv.p, count, count, G);
+  });
+}
+
+int gsi_ctx_path_info(gsi_ctx* ctx, int64_t* out, int64_t n_out) {
+  return guarded([&] {
+    REQUIRE(ctx && out && n_out >= 1, "bad argument");
+    Context& c = ctx->c;
+    int64_t v[GSI_PATH_INFO_COUNT] = {0};
+    v[GSI_PATH_LU_FORM_LAST] = c.lu_form_last;
+    v[GSI_PATH_LU_SELFTEST_MASK] = c.lus_mr_selftest;
+    v[GSI_PATH_COLLECTIVES] = c.comm ? c.comm->ncollectives : 0;
+    v[GSI_PATH_RANKS_SEEN] = c.ranks_seen;
+    v[GSI_PATH_LU_TIMEOUTS] = c.be->lu_timeouts();
+    v[GSI_PATH_LU_TIMEOUTS_RECOVERED] = c.lu_timeouts_recovered;
+    for (int f = 0; f < (int)Context::LU_FORMS && GSI_PATH_LU_FORM_COUNTS + f < GSI_PATH_INFO_COUNT; ++f)
+      v[GSI_PATH_LU_FORM_COUNTS + f] = c.lu_form_count[f];
+    for (int64_t i = 0; i < n_out; ++i) out[i] = i < GSI_PATH_INFO_COUNT ? v[i] : 0;
   });
 }
 
@@ -952,6 +999,8 @@ int gsi_ctx_phase_reset(gsi_ctx* ctx) {
   return guarded([&] {
     REQUIRE(ctx, "ctx is NULL");
     ctx->c.be->phase_reset();
+    if (ctx->c.comm) ctx->c.comm->ncollectives = 0;
+    for (int f = 0; f < (int)Context::LU_FORMS; ++f) ctx->c.lu_form_count[f] = 0;
   });
 }
 int gsi_ctx_phase_times(gsi_ctx* ctx, double* ms_out, int64_t* count_out) {

@@ -105,6 +105,23 @@ class Backend {
   // ones must take (1, 2) or the natural choice again (0).
   virtual int lus_mr_mode() { return 0; }
   virtual void lus_mr_force(int mode) { (void)mode; }
+  // Launch geometry of the form the last successful lus_mr_begin chose, packed into one number (block size, rows per
+  // thread, grid, hops, overflow rows): it depends on rank-local facts (CUs, ranks sharing the device), and ranks with
+  // different geometries would address different record slots -- pipeline.cpp lets the path run only if all ranks report
+  // the same number.  lus_mr_reason: why the last lus_mr_begin said no (for the error text of GSI_LU_MR_REQUIRE).
+  virtual int64_t lus_mr_signature() { return 0; }
+  virtual const char* lus_mr_reason() { return ""; }
+  // Bumped whenever something that lus_mr_begin's answer depends on changes on this rank (a time-out switched the path
+  // off, ...): agreements the ranks reached before are void and must be reached again.  Time-outs are made global
+  // (lu_flag_export / _import below), so the ranks' counters move together.
+  virtual int64_t lus_mr_generation() { return 0; }
+  // Before the first kernel that spins for its peers: launch every kernel the persistent-leaf factorization uses once on
+  // dummies, so that no code object is loaded (a runtime call that may wait for the device) while peers spin.
+  virtual void lus_mr_warmup() {}
+  // The LU's asynchronous time-out flag (info = -1) made GLOBAL without a host round trip: export writes 1.0 / 0.0 into a
+  // backend double, the caller all-reduces it on the stream, import raises the flag on this rank if any rank had it up.
+  virtual void lu_flag_export(double* flag) { (void)flag; }
+  virtual void lu_flag_import(const double* flag) { (void)flag; }
   virtual void lus_leaf_mr(double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, const double*) {}
   virtual bool lus_mr_swaps_done() { return false; }   // lus_leaf_mr also moved the rows in the other columns (peer pushes)
   virtual void lus_swap_pack(const double*, int64_t, int64_t, int64_t, int64_t, int64_t, int, double*) {}
@@ -197,20 +214,24 @@ class Backend {
   // [0] CholeskyQR2 factorizations, [1] Householder factorizations (incl. fallbacks), [2] Jacobi sweeps of
   // the last small SVD, [3] shifted CholeskyQR3 factorizations
   virtual void counters(int64_t* out4) { out4[0] = out4[1] = out4[2] = out4[3] = 0; }
+  // [0] LU pivot-exchange time-outs seen by this backend since creation (take_error mapped info = -1)
+  virtual int64_t lu_timeouts() { return 0; }
 };
 
 class Comm {
  public:
   int rank = 0, nranks = 1;
+  int64_t ncollectives = 0;       // collectives entered since creation (gsi_ctx_path_info reports the count per timed region)
   virtual ~Comm() {}
-  virtual void allreduce_sum(double* buf, size_t count) = 0;
+  // The four collectives.  Callers use these; implementations override the do_* hooks below.
+  void allreduce_sum(double* buf, size_t count) { ++ncollectives; do_allreduce_sum(buf, count); }
   // every rank contributes `count` doubles; recv holds nranks*count, rank-major
-  virtual void allgather(const double* send, double* recv, size_t count) = 0;
+  void allgather(const double* send, double* recv, size_t count) { ++ncollectives; do_allgather(send, recv, count); }
   // send holds nranks blocks of `count` doubles (block g is destined for rank g); recv (count) = sum over ranks
   // of their block `rank`
-  virtual void reduce_scatter_sum(const double* send, double* recv, size_t count) = 0;
+  void reduce_scatter_sum(const double* send, double* recv, size_t count) { ++ncollectives; do_reduce_scatter_sum(send, recv, count); }
   // send holds nranks blocks of `count` doubles, block g for rank g; recv block s = what rank s sent to this rank
-  virtual void alltoall(const double* send, double* recv, size_t count) = 0;
+  void alltoall(const double* send, double* recv, size_t count) { ++ncollectives; do_alltoall(send, recv, count); }
   // every rank hands in a device buffer; all[g] = rank g's buffer as THIS rank can address it (same process: the pointer
   // itself; other processes: an IPC mapping).  false: not supported by this communicator.  Collective.
   virtual bool share_pointers(void* mine, size_t bytes, void** all) { (void)mine; (void)bytes; (void)all; return false; }
@@ -222,6 +243,12 @@ class Comm {
   // hipMalloc that has to map new memory was seen to) waits for the other ranks' kernels too.  Before a rank launches a
   // kernel that spins for its peers, all ranks meet here with their allocations done.  No-op for ranks in processes.
   virtual void host_barrier() {}
+
+ protected:
+  virtual void do_allreduce_sum(double* buf, size_t count) = 0;
+  virtual void do_allgather(const double* send, double* recv, size_t count) = 0;
+  virtual void do_reduce_scatter_sum(const double* send, double* recv, size_t count) = 0;
+  virtual void do_alltoall(const double* send, double* recv, size_t count) = 0;
 };
 
 // Provided by whichever backend is linked into the library.

@@ -17,8 +17,10 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <map>
 #include <memory>
+#include <set>
 #include <vector>
 #include "../../include/gsi_hip.h"
 #include "backend.hpp"
@@ -75,7 +77,9 @@ class HipBackend : public Backend {
     ncus_ = prop.multiProcessorCount;
     if (arch_.find("gfx950") == std::string::npos)
       throw Error(GSI_ERR_HIP, "libgsi_hip is built for gfx950 (MI355X); device reports " + arch_);
-    HIP_CHECK(hipStreamCreate(&st_));
+    // non-blocking: nothing of this library uses the NULL stream, and a runtime-internal or foreign NULL-stream operation
+    // must never wait for (or be waited for by) a persistent kernel of ours that spins for its peers
+    HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     HIP_CHECK(hipMalloc(&flags_, 16 * sizeof(int32_t)));
     HIP_CHECK(hipMemsetAsync(flags_, 0, 16 * sizeof(int32_t), st_));
     HIP_CHECK(hipMalloc(&scal_, (64 + 8 + 256) * sizeof(double)));   // scalars + partial sums of long dot products
@@ -264,7 +268,7 @@ class HipBackend : public Backend {
     pr = std::max<int64_t>(128, (pr / 128) * 128);
     if (pr > m) pr = ((m + 1) / 2) * 2;                      // even leading dimension: 16-byte loads in the contraction
     if (!st2_) {
-      HIP_CHECK(hipStreamCreate(&st2_));
+      HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
       for (int i = 0; i < 2; ++i) { HIP_CHECK(hipEventCreateWithFlags(&ev_gen_[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_used_[i], hipEventDisableTiming)); }
     }
     double* P[2] = {nullptr, nullptr};
@@ -541,10 +545,40 @@ class HipBackend : public Backend {
   }
   bool lus_mr_begin(Comm* comm, int64_t m, int64_t l) override {
     bind();
+    auto no = [&](const std::string& why) { mr_reason_ = why; return false; };
+    if (comm == nullptr) return no("no communicator");
+    // First use over this communicator: the record buffer is created and exchanged BEFORE any rank-local veto below, so
+    // that every rank enters the collective inside share_pointers (a rank that skipped it would leave its peers in it).
+    if (mr_comm_ != comm && !mr_share_tried_) {
+      mr_share_tried_ = true;
+      if (comm->nranks <= hipk::LU2_MAX_RANKS) {
+        if (mr_recs_ == nullptr) {
+          const size_t bytes = sizeof(unsigned long long) * hipk::lu2_mr_record_granules(1, 256);   // 256 records + mailboxes
+          if (hipExtMallocWithFlags((void**)&mr_recs_, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_CHECK(hipMalloc((void**)&mr_recs_, bytes));
+          }
+          HIP_CHECK(hipMemsetAsync(mr_recs_, 0, bytes, st_));
+          HIP_CHECK(hipStreamSynchronize(st_));
+          mr_epoch_ = 0;
+        }
+        void* all[hipk::LU2_MAX_RANKS] = {nullptr};
+        if (comm->share_pointers(mr_recs_, 0, all)) {
+          for (int g = 0; g < comm->nranks; ++g) mr_peer_[g] = (unsigned long long*)all[g];
+          mr_comm_ = comm;
+        } else {
+          mr_disabled_ = true;
+          mr_why_disabled_ = "the ranks' record buffers could not be mapped into each other (share_pointers)";
+        }
+      }
+      lus_ws(1, 1);                        // the pivot / partial-arg-max workspace exists before any leaf is launched
+    }
     static const bool off = (getenv("GSI_LU_NO_MR") != nullptr);
-    if (off || mr_disabled_ || comm == nullptr || comm->nranks > hipk::LU2_MAX_RANKS || m >= ((int64_t)1 << 28) ||
-        l > hipk::LU2_MR_MAXL)
-      return false;
+    if (off) return no("GSI_LU_NO_MR is set");
+    if (mr_disabled_) return no("switched off on this context: " + mr_why_disabled_);
+    if (mr_comm_ != comm) return no("another communicator owns this context's record buffers");
+    if (comm->nranks > hipk::LU2_MAX_RANKS) return no("more than " + std::to_string(hipk::LU2_MAX_RANKS) + " ranks");
+    if (m >= ((int64_t)1 << 28) || l > hipk::LU2_MR_MAXL) return no("panel too tall (2^28 rows) or too wide (" + std::to_string(hipk::LU2_MR_MAXL) + " columns)");
     const int G = comm->nranks;
     const int64_t pad = (m + G - 1) / G;
     hipk::Lu2MrWork w{};
@@ -556,38 +590,73 @@ class HipBackend : public Backend {
     const int sharing = std::max(comm->ranks_on_my_device(), 1);
     const int se_cus = std::max(ncus_ / 32, 1);                        // CUs per shader engine (8)
     const int per_se = sharing > 1 ? std::max(se_cus / sharing, 0) : se_cus;
-    if (per_se < 1) return false;
-    if (!hipk::lu2_mr_config(pad, G, sharing > 1 ? per_se * 32 : ncus_, &w.bs, &w.rpt, &w.grid, &w.hier, &w.ov, mr_force_)) return false;
+    if (per_se < 1)
+      return no(std::to_string(sharing) + " ranks share this device, more than the " + std::to_string(se_cus) +
+                " CUs of a shader engine: their persistent leaf grids cannot all be resident");
+    if (!hipk::lu2_mr_config(pad, G, sharing > 1 ? per_se * 32 : ncus_, &w.bs, &w.rpt, &w.grid, &w.hier, &w.ov, mr_force_))
+      return no("no launch geometry for shards of " + std::to_string(pad) + " rows on " + std::to_string(G) + " ranks (" +
+                std::to_string(sharing) + " sharing this device)");
     const int key = 1000000 + w.bs * 16 + w.rpt + (w.ov ? 100000 : 0);
     auto it = lu2_resident_.find(key);
     if (it == lu2_resident_.end())
       it = lu2_resident_.emplace(key, w.ov ? hipk::lu2_mr_resident_per_cu_ov() : hipk::lu2_mr_resident_per_cu(w.bs, w.rpt)).first;
-    if ((int64_t)it->second * ncus_ < w.grid) return false;
-    if (mr_comm_ != comm) {                                 // first use over this communicator: record buffer, exchanged once
-      if (mr_recs_ == nullptr) {
-        const size_t bytes = sizeof(unsigned long long) * hipk::lu2_mr_record_granules(1, 256);   // 256 records + mailboxes
-        if (hipExtMallocWithFlags((void**)&mr_recs_, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-          (void)hipGetLastError();
-          HIP_CHECK(hipMalloc((void**)&mr_recs_, bytes));
-        }
-        HIP_CHECK(hipMemsetAsync(mr_recs_, 0, bytes, st_));
-        HIP_CHECK(hipStreamSynchronize(st_));
-        mr_epoch_ = 0;
-      }
-      void* all[hipk::LU2_MAX_RANKS] = {nullptr};
-      if (!comm->share_pointers(mr_recs_, 0, all)) { mr_disabled_ = true; return false; }
-      for (int g = 0; g < G; ++g) mr_peer_[g] = (unsigned long long*)all[g];
-      mr_comm_ = comm;
-    }
     if (sharing > 1 ? (int64_t)sharing * ((((w.grid + 7) / 8) + 3) / 4) > (int64_t)se_cus * it->second
                     : (int64_t)it->second * ncus_ < (int64_t)w.grid)
-      return false;
+      return no("the leaf grids (" + std::to_string(w.grid) + " workgroups per rank, " + std::to_string(sharing) +
+                " ranks on this device) would not all be resident");
     w.rank = comm->rank; w.nranks = G;
     for (int g = 0; g < G; ++g) w.peer[g] = mr_peer_[g];
     w.info = flags_ + 0;
     if (const char* e = getenv("GSI_LU_POLL_LIMIT")) w.poll_limit = atoi(e);
     mr_work_ = w;
+    mr_reason_.clear();
     return true;
+  }
+  int64_t lus_mr_signature() override {
+    return ((((int64_t)mr_work_.bs * 64 + mr_work_.rpt) * 1024 + mr_work_.grid) * 2 + mr_work_.hier) * 2 + mr_work_.ov;
+  }
+  const char* lus_mr_reason() override { return mr_reason_.c_str(); }
+  int64_t lus_mr_generation() override { return mr_gen_; }
+  // Every kernel of the persistent-leaf factorization once, on private dummies (a 64-row panel, a record buffer of its
+  // own, its own info word), with the geometry flags of the form that is about to run: what a first launch may cost the
+  // runtime -- loading the code object, growing the queue's scratch (the overflow-row leaves spill) -- happens here,
+  // before the ranks' barrier, and not while a peer's leaf spins for this rank's launch.  Once per instantiation.
+  void lus_mr_warmup() override {
+    bind();
+    const int64_t key = (((int64_t)mr_work_.bs * 64 + mr_work_.rpt) * 2 + mr_work_.hier) * 2 + mr_work_.ov;
+    if (mr_warm_.count(key)) return;
+    mr_warm_.insert(key);
+    const int64_t R = 256, Cc = 128;
+    const size_t rec_doubles = hipk::lu2_mr_record_granules(1, 4);
+    Scratch D(this, (size_t)R * Cc + 64), U(this, (size_t)64 * 128), recs(this, rec_doubles);
+    hipk::randn_fill(st_, D.p, (size_t)R * Cc, 0x77a12eull);
+    HIP_CHECK(hipMemsetAsync(D.p + R * Cc, 0, 64 * sizeof(double), st_));
+    HIP_CHECK(hipMemsetAsync(recs.p, 0, rec_doubles * sizeof(double), st_));
+    hipk::Lu2MrWork w = mr_work_;
+    w.rank = 0; w.nranks = 1; w.grid = 1;
+    w.peer[0] = (unsigned long long*)recs.p;
+    w.info = (int32_t*)(D.p + R * Cc);
+    w.ipiv = (int32_t*)(D.p + R * Cc + 16);
+    hipk::lu2_leaf_mr(st_, w, D.p, R, 64, 0, 64, 8, 0, 0, 8, nullptr, 0);
+    hipk::lus_swap_peer(st_, w, D.p, R, 64, 0, 64, 8, 0, 8, 0);
+    hipk::lus_u12_block(st_, D.p, R, 0, 0, 64, 64, 128, U.p);
+    hipk::lus_rankk(st_, D.p, R, R, 0, 0, 64, 64, 64, U.p);
+    hipk::lus_u12_block(st_, D.p, R, 0, 0, 32, 32, 64, U.p);
+    hipk::lus_rankk(st_, D.p, R, R, 0, 0, 32, 32, 32, U.p);
+    hipk::lus_finish(st_, D.p, R, R, 0, 8);
+    hipk::lu_flag_export(st_, w.info, U.p);
+    hipk::lu_flag_import(st_, w.info, U.p);
+    check_launch("lus_mr_warmup");
+    HIP_CHECK(hipStreamSynchronize(st_));
+  }
+  void lu_flag_export(double* flag) override {
+    bind();
+    hipk::lu_flag_export(st_, flags_ + 0, flag);
+  }
+  void lu_flag_import(const double* flag) override {
+    bind();
+    hipk::lu_flag_import(st_, flags_ + 0, flag);
+    check_launch("lu_flag_import");
   }
   void lus_leaf_mr(double* Yloc, int64_t mloc, int64_t ld, int64_t row0, int64_t m, int64_t l, int64_t jb, int64_t j0, int w,
                    const double* U12) override {
@@ -599,6 +668,7 @@ class HipBackend : public Backend {
     mr_peer_swaps_ = !host_swaps;
     if (mr_peer_swaps_) hipk::lus_swap_peer(st_, mr_work_, Yloc, ld, mloc, row0, m, l, j0, w, mr_epoch_);
     mr_epoch_ += (uint32_t)hipk::LU2_LEAF;
+    mr_in_flight_ = true;
     check_launch("lu2_leaf_mr");
   }
   bool lus_mr_swaps_done() override { return mr_peer_swaps_; }
@@ -917,6 +987,7 @@ class HipBackend : public Backend {
     HIP_CHECK(hipStreamSynchronize(st_));
     HIP_CHECK(hipGetLastError());
     if (!garbage_.empty()) collect_garbage();
+    if (h[0] >= 0) mr_in_flight_ = false;
     if (h[0] != 0 || h[1] != 0) {
       HIP_CHECK(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), st_));
       if (h[0] < 0) {
@@ -925,7 +996,15 @@ class HipBackend : public Backend {
         // streamed leaves (no spin-waits between workgroups) from now on, and the entry point may be re-run on its inputs.
         lu2_lost_ = true;
         lu2_retry_ = true;
-        mr_disabled_ = true;
+        ++n_lu_timeouts_;
+        if (mr_in_flight_) {
+          // a multi-rank factorization: the flag was made global on the stream (pipeline.cpp: lu_flag_export / _import), so
+          // EVERY rank is here in the same call, switches the in-kernel exchange off and voids the ranks' agreements
+          mr_disabled_ = true;
+          mr_why_disabled_ = "a pivot exchange between the ranks' kernels timed out";
+          ++mr_gen_;
+        }
+        mr_in_flight_ = false;
         if (msg) *msg = "lu(): the pivot exchange between workgroups timed out (GPU shared with another job?); "
                         "this context now streams its leaves (no spin-waits) [waited for: phase " + std::to_string(h[2]) +
                         ", slot " + std::to_string(h[3]) + ", epoch " + std::to_string(h[4]) + ", by rank*1024+workgroup " +
@@ -982,9 +1061,17 @@ class HipBackend : public Backend {
   void counters(int64_t* out4) override {
     out4[0] = n_cholqr_; out4[1] = n_householder_; out4[2] = last_svd_sweeps_; out4[3] = n_scholqr3_;
   }
+  int64_t lu_timeouts() override { return n_lu_timeouts_; }
   int device() const { return device_; }
 
  private:
+  struct Scratch {                 // a pooled temporary that goes back to the block cache on every exit path
+    HipBackend* be; double* p;
+    Scratch(HipBackend* b, size_t doubles) : be(b), p(b->alloc(doubles)) {}
+    ~Scratch() { be->release(p); }
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+  };
   struct Rec { Phase phase; hipEvent_t a, b; };
   hipEvent_t get_event() {
     if (!ev_pool_.empty()) { hipEvent_t e = ev_pool_.back(); ev_pool_.pop_back(); return e; }
@@ -1086,6 +1173,10 @@ class HipBackend : public Backend {
   Comm* mr_comm_ = nullptr;
   uint32_t mr_epoch_ = 0;
   bool mr_disabled_ = false, mr_peer_swaps_ = true;
+  bool mr_share_tried_ = false, mr_in_flight_ = false;
+  int64_t mr_gen_ = 0, n_lu_timeouts_ = 0;
+  std::string mr_reason_, mr_why_disabled_;
+  std::set<int64_t> mr_warm_;
   hipk::Lu2MrWork mr_work_{};
   int64_t lus_part_col_ = -1, lus_part_mloc_ = 0;     // sharded LU: column whose arg-max partials the last apply kernel left
   const double* lus_part_Y_ = nullptr;
@@ -1168,20 +1259,20 @@ class RcclComm : public Comm {
       rccl().CommDestroy(comm_);
     }
   }
-  void allreduce_sum(double* buf, size_t count) override {
+  void do_allreduce_sum(double* buf, size_t count) override {
     be_->bind();
     RCCL_CHECK(rccl().AllReduce(buf, buf, count, ncclDouble, ncclSum, comm_, be_->stream()));
   }
-  void allgather(const double* send, double* recv, size_t count) override {
+  void do_allgather(const double* send, double* recv, size_t count) override {
     be_->bind();
     RCCL_CHECK(rccl().AllGather(send, recv, count, ncclDouble, comm_, be_->stream()));
   }
-  void reduce_scatter_sum(const double* send, double* recv, size_t count) override {
+  void do_reduce_scatter_sum(const double* send, double* recv, size_t count) override {
     be_->bind();
     RCCL_CHECK(rccl().ReduceScatter(send, recv, count, ncclDouble, ncclSum, comm_, be_->stream()));
   }
   // point-to-point xGMI: every pair of GPUs has a direct link, so the grouped sends / receives use all 7 links at once
-  void alltoall(const double* send, double* recv, size_t count) override {
+  void do_alltoall(const double* send, double* recv, size_t count) override {
     be_->bind();
     RcclApi& r = rccl();
     if (!r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) throw Error(GSI_ERR_RCCL, "librccl has no ncclSend / ncclRecv");
@@ -1239,8 +1330,13 @@ struct LocalGroup {
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const uint64_t gen = generation;
-    if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
-    else cv.wait(lk, [&] { return generation != gen; });
+    if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); return; }
+    // a rank thread that died (an exception on its way out, a caller that returned) must not hang the others for ever
+    static const int timeout_s = getenv("GSI_SHM_TIMEOUT_S") ? std::max(1, atoi(getenv("GSI_SHM_TIMEOUT_S"))) : 300;
+    if (!cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return generation != gen; })) {
+      --arrived;
+      throw Error(GSI_ERR_RCCL, "local communicator: a rank did not reach the barrier (GSI_SHM_TIMEOUT_S)");
+    }
   }
 };
 static std::mutex g_local_mu;
@@ -1274,7 +1370,7 @@ class LocalComm : public Comm {
     HIP_CHECK(hipStreamSynchronize(be_->stream()));
     grp_->barrier();
   }
-  void allreduce_sum(double* buf, size_t count) override {
+  void do_allreduce_sum(double* buf, size_t count) override {
     publish(buf);
     double* tmp = be_->alloc(count);
     hipStream_t st = be_->stream();
@@ -1284,21 +1380,21 @@ class LocalComm : public Comm {
     HIP_CHECK(hipMemcpyAsync(buf, tmp, count * sizeof(double), hipMemcpyDeviceToDevice, st));
     be_->release(tmp);
   }
-  void allgather(const double* send, double* recv, size_t count) override {
+  void do_allgather(const double* send, double* recv, size_t count) override {
     publish(send);
     for (int g = 0; g < nranks; ++g)
       HIP_CHECK(hipMemcpyAsync(recv + (size_t)g * count, grp_->src[(size_t)g], count * sizeof(double), hipMemcpyDeviceToDevice,
                                be_->stream()));
     finish();
   }
-  void reduce_scatter_sum(const double* send, double* recv, size_t count) override {
+  void do_reduce_scatter_sum(const double* send, double* recv, size_t count) override {
     publish(send);
     hipStream_t st = be_->stream();
     HIP_CHECK(hipMemcpyAsync(recv, grp_->src[0] + (size_t)rank * count, count * sizeof(double), hipMemcpyDeviceToDevice, st));
     for (int g = 1; g < nranks; ++g) hipk::axpy(st, (int64_t)count, 1.0, grp_->src[(size_t)g] + (size_t)rank * count, recv);
     finish();
   }
-  void alltoall(const double* send, double* recv, size_t count) override {
+  void do_alltoall(const double* send, double* recv, size_t count) override {
     publish(send);
     for (int g = 0; g < nranks; ++g)
       HIP_CHECK(hipMemcpyAsync(recv + (size_t)g * count, grp_->src[(size_t)g] + (size_t)rank * count, count * sizeof(double),
@@ -1397,7 +1493,7 @@ class ShmComm : public Comm {
     (void)hipStreamSynchronize(be_->stream());
     cleanup();
   }
-  void allreduce_sum(double* buf, size_t count) override {
+  void do_allreduce_sum(double* buf, size_t count) override {
     hipStream_t st = be_->stream();
     for (size_t off = 0; off < count || off == 0; off += cap_) {
       const size_t c = std::min(cap_, count - off);
@@ -1408,7 +1504,7 @@ class ShmComm : public Comm {
       if (count == 0) break;
     }
   }
-  void allgather(const double* send, double* recv, size_t count) override {
+  void do_allgather(const double* send, double* recv, size_t count) override {
     for (size_t off = 0; off < count || off == 0; off += cap_) {
       const size_t c = std::min(cap_, count - off);
       stage_in(send + off, c);
@@ -1419,7 +1515,7 @@ class ShmComm : public Comm {
     }
   }
   // blocks of `count` doubles per destination: the staging buffer holds nranks segments of one chunk
-  void reduce_scatter_sum(const double* send, double* recv, size_t count) override {
+  void do_reduce_scatter_sum(const double* send, double* recv, size_t count) override {
     hipStream_t st = be_->stream();
     const size_t cc = std::max<size_t>(cap_ / (size_t)nranks, 1);
     for (size_t off = 0; off < count || off == 0; off += cc) {
@@ -1431,7 +1527,7 @@ class ShmComm : public Comm {
       if (count == 0) break;
     }
   }
-  void alltoall(const double* send, double* recv, size_t count) override {
+  void do_alltoall(const double* send, double* recv, size_t count) override {
     const size_t cc = std::max<size_t>(cap_ / (size_t)nranks, 1);
     for (size_t off = 0; off < count || off == 0; off += cc) {
       const size_t c = std::min(cc, count - off);

@@ -136,6 +136,10 @@ void lus_u12_block(hipStream_t st, const double* Y, int64_t ld, int64_t row0, in
 void lus_rankk(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t jb, int b, int64_t c0, int64_t t,
                const double* U12);
 void lus_finish(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l);
+// the factorization's time-out flag (info < 0) as a double (1.0 / 0.0) for an all-reduce on the stream, and back: raise
+// info = -1 here if any rank had it up
+void lu_flag_export(hipStream_t st, const int32_t* info, double* flag);
+void lu_flag_import(hipStream_t st, int32_t* info, const double* flag);
 
 // ---- lsqr_dev.hip: IterativeSolvers.lsqr's vector updates with device-resident scalars ----
 size_t lsqr_work_doubles();

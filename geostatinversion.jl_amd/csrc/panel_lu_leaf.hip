@@ -2039,6 +2039,12 @@ __global__ __launch_bounds__(256) void lus_pending_kernel(double* __restrict__ Y
       if (k < w) Y[li + (j0 + k) * ld] = a[k];
   }
 }
+__global__ void lu_flag_export_kernel(const int32_t* __restrict__ info, double* __restrict__ flag) {
+  flag[0] = (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) ? 1.0 : 0.0;
+}
+__global__ void lu_flag_import_kernel(int32_t* __restrict__ info, const double* __restrict__ flag) {
+  if (flag[0] > 0.0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) atomicExch(info, -1);
+}
 __global__ void lus_finish_kernel(double* __restrict__ Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l) {
   const int64_t total = l * l;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -2090,6 +2096,12 @@ void lus_rankk(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0
   const unsigned gr = (unsigned)((mr + 127) / 128);
   if (b == 64) launch_rankk<64>(st, gr, Y, ld, mloc, rbeg, jb, c0, t, U12);
   else launch_rankk<32>(st, gr, Y, ld, mloc, rbeg, jb, c0, t, U12);
+}
+void lu_flag_export(hipStream_t st, const int32_t* info, double* flag) {
+  hipLaunchKernelGGL(lu_flag_export_kernel, dim3(1), dim3(1), 0, st, info, flag);
+}
+void lu_flag_import(hipStream_t st, int32_t* info, const double* flag) {
+  hipLaunchKernelGGL(lu_flag_import_kernel, dim3(1), dim3(1), 0, st, info, flag);
 }
 void lus_finish(hipStream_t st, double* Y, int64_t ld, int64_t mloc, int64_t row0, int64_t l) {
   int eb = (int)((l * l + 255) / 256);

@@ -355,8 +355,14 @@ static Buf op_mul_t_sharded(const Operator& A, const double* Xloc, int64_t ldx, 
   return Wloc;
 }
 
+static void note_lu_form(Context& c, Context::LuForm f) {
+  c.lu_form_last = f;
+  c.lu_form_count[f] += 1;
+}
+
 static void lu_panel(Context& c, double* Y, int64_t rows, int64_t l) {
   ScopedPhase ph(c.be.get(), PH_LU);
+  if (c.comm) note_lu_form(c, Context::LU_REPLICATED);
   c.be->lu_L(Y, rows, l, rows, nullptr);   // F = lu(Y); Q = F.L   RandMatFact.jl:60-61,68-69,72-73
 }
 
@@ -369,16 +375,20 @@ static bool all_shards_tall(int64_t m, int G, int64_t l);
 // rows) reach the other ranks by an all-reduce with zeros.
 static void lu_panel_sharded_impl(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l, bool mr);
 
-// do ALL ranks answer yes?  (one all-reduced flag: a rank that cannot take a path would leave the others polling)
-static bool all_ranks_agree(Context& c, bool mine) {
+// do ALL ranks answer yes -- and, when they do, with the same `sig`?  (one all-gathered pair per rank: a rank that cannot
+// take a path, or would take it with another launch geometry, would leave the others polling)
+static bool all_ranks_agree(Context& c, bool mine, int64_t sig = 0) {
   Backend* be = c.be.get();
-  const double v = mine ? 1.0 : 0.0;
-  Buf flag(be, 1);
-  be->upload2d(flag.p, 1, &v, 1, 1, 1);
-  c.comm->allreduce_sum(flag.p, 1);
-  double all = 0.0;
-  be->download2d(&all, 1, flag.p, 1, 1, 1);
-  return all == (double)c.nranks();
+  const int G = c.nranks();
+  const double v[2] = {mine ? 1.0 : 0.0, (double)sig};
+  Buf send(be, 2), recv(be, (size_t)2 * G);
+  be->upload2d(send.p, 2, v, 2, 2, 1);
+  c.comm->allgather(send.p, recv.p, 2);
+  std::vector<double> all((size_t)2 * G);
+  be->download2d(all.data(), 2, recv.p, 2, 2, G);
+  for (int g = 0; g < G; ++g)
+    if (all[(size_t)2 * g] != 1.0 || all[(size_t)2 * g + 1] != all[1]) return false;
+  return true;
 }
 
 // The in-kernel pivot exchange relies on things a build box with one GPU cannot prove about the machine it later runs on
@@ -395,7 +405,8 @@ static int lus_mr_selftest(Context& c) {
     const int64_t rows = (form == 2) ? 12288 : 2048, lt = 24, mt = rows * G;
     be->lus_mr_force(form);
     bool mine = false;
-    if (all_ranks_agree(c, be->lus_mr_begin(c.comm.get(), mt, lt) && be->lus_mr_mode() == form)) {
+    const bool can = be->lus_mr_begin(c.comm.get(), mt, lt) && be->lus_mr_mode() == form;
+    if (all_ranks_agree(c, can, can ? be->lus_mr_signature() : 0)) {
       Buf A(be, (size_t)rows * lt), B(be, (size_t)rows * lt);
       be->randn(A.p, (size_t)rows * lt, 0x5e1f7e57ull + (uint64_t)rank + 131ull * (uint64_t)form);
       be->copy2d(B.p, rows, A.p, rows, rows, lt);
@@ -426,21 +437,32 @@ void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t
     throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: the first rank must hold the first l rows");
   // One persistent launch per leaf and rank, pivot exchange inside the kernels (peer-written records), when the backend
   // and the communicator can do it -- decided by ALL ranks together, after the self-test above has passed on this
-  // communicator.
+  // communicator.  The agreement for a panel height is cached, and it is void as soon as anything it rested on changes:
+  // Backend::lus_mr_generation() moves on every rank at once (a time-out is made global below), and a moved generation
+  // empties the cache, so the next call re-agrees through a collective instead of trusting a rank-local answer.
   bool mr = false;
   if (c.comm) {
     if (c.lus_mr_selftest < 0) c.lus_mr_selftest = lus_mr_selftest(c);
+    if (c.lus_mr_gen != be->lus_mr_generation()) {
+      c.lus_mr_ok.clear();
+      c.lus_mr_gen = be->lus_mr_generation();
+    }
     if (c.lus_mr_selftest != 0) {
       auto it = c.lus_mr_ok.find(m);
-      if (it == c.lus_mr_ok.end())
-        it = c.lus_mr_ok.emplace(m, all_ranks_agree(c, be->lus_mr_begin(c.comm.get(), m, l) &&
-                                                         ((c.lus_mr_selftest >> be->lus_mr_mode()) & 1) != 0)).first;
-      mr = it->second && be->lus_mr_begin(c.comm.get(), m, l);
+      if (it == c.lus_mr_ok.end()) {
+        const bool can = be->lus_mr_begin(c.comm.get(), m, l) && ((c.lus_mr_selftest >> be->lus_mr_mode()) & 1) != 0;
+        it = c.lus_mr_ok.emplace(m, all_ranks_agree(c, can, can ? be->lus_mr_signature() : 0)).first;
+      }
+      mr = it->second;
     }
     if (!mr && getenv("GSI_LU_MR_REQUIRE") != nullptr)      // tests: the in-kernel exchange must be what runs
-      throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: the multi-rank persistent leaf path is not available (GSI_LU_MR_REQUIRE)");
+      throw Error(GSI_ERR_INTERNAL, std::string("lu_panel_sharded: the multi-rank persistent leaf path is not available "
+                                                "(GSI_LU_MR_REQUIRE): ") + be->lus_mr_reason() +
+                                        " [self-test mask " + std::to_string(c.lus_mr_selftest) + "]");
   }
   lu_panel_sharded_impl(c, Yloc, m, row0, mloc, l, mr);
+  if (c.comm) note_lu_form(c, !mr ? Context::LU_PER_STEP
+                                  : (Context::LuForm)((int)Context::LU_MR_1HOP + be->lus_mr_mode()));
 }
 
 static void lu_panel_sharded_impl(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l, bool mr) {
@@ -449,13 +471,20 @@ static void lu_panel_sharded_impl(Context& c, double* Yloc, int64_t m, int64_t r
   ScopedPhase ph(be, PH_LU);
   const int64_t reclen = 4 + 2 * l, ld = std::max<int64_t>(mloc, 1);
   const int nb = be->lus_block();
-  if (mr && !be->lus_mr_begin(c.comm.get(), m, l)) throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: persistent leaves refused");
+  // (a rank that refuses here although the ranks agreed would leave its peers polling until their time-out, which the flag
+  // exchange at the end then reports on every rank; it cannot happen while the generation rule of lu_panel_sharded holds)
+  if (mr && !be->lus_mr_begin(c.comm.get(), m, l))
+    throw Error(GSI_ERR_INTERNAL, std::string("lu_panel_sharded: persistent leaves refused: ") + be->lus_mr_reason());
   Buf rec(be, (size_t)reclen), recs(be, (size_t)reclen * G), u12leaf(be, (size_t)nb * 8), u12blk(be, (size_t)nb * l);
-  Buf swaps;
+  Buf swaps, eflag;
   if (mr) {
     swaps = Buf(be, (size_t)16 * l);
-    // everything this factorization allocates exists now (lus_mr_begin sized the backend's own workspaces): from here on
-    // kernels spin for their peers, and with ranks as threads of one process no rank may still be inside an allocation
+    eflag = Buf(be, 1);
+    // Everything this factorization allocates exists now (lus_mr_begin sized the backend's own workspaces) and every
+    // kernel it launches has run once (lus_mr_warmup: code objects loaded): from here on kernels spin for their peers,
+    // and with ranks as threads of one process no rank may be inside a runtime call that waits for the device.
+    // DESIGN.md section 6 lists what is reachable between this barrier and the last leaf.
+    be->lus_mr_warmup();
     c.comm->host_barrier();
   }
   for (int64_t jb = 0; jb < l; jb += nb) {
@@ -495,6 +524,14 @@ static void lu_panel_sharded_impl(Context& c, double* Yloc, int64_t m, int64_t r
     }
   }
   be->lus_finish(Yloc, mloc, ld, row0, l);
+  if (mr) {
+    // A workgroup that gave up polling raised info = -1 on ITS rank only, while its peers may have finished on records it
+    // kept publishing: the time-out is made global on the stream (no host round trip), so that every rank's take_error
+    // reports it, every rank switches the path off and bumps its generation in the same call.
+    be->lu_flag_export(eflag.p);
+    c.comm->allreduce_sum(eflag.p, 1);
+    be->lu_flag_import(eflag.p);
+  }
 }
 
 // The same factorization with G VIRTUAL ranks on one device: shard g = rows [row0_g, row0_g + mloc_g) of the panel in a

@@ -34,6 +34,16 @@ struct Context {
   std::map<int64_t, bool> lus_mr_ok;   // panel height -> all ranks can run the sharded LU with in-kernel pivot exchange
   int lus_mr_selftest = -1;            // -1 not run yet; else bit f set: form f of the in-kernel exchange (0 one hop, 1 two hops,
                                        // 2 two hops + overflow rows) reproduced the per-step factors on this communicator
+  int64_t lus_mr_gen = -1;             // Backend::lus_mr_generation() the entries of lus_mr_ok were agreed under
+  // ---- which path ran (gsi_ctx_path_info) ----
+  // form of a panel LU under a communicator: 0 none yet, 1 replicated (gathered panel, every rank factors it), 2 row-sharded
+  // with one collective per pivot step, 3 / 4 / 5 row-sharded persistent leaves with the in-kernel exchange in one hop / two
+  // hops / two hops + overflow rows
+  enum LuForm { LU_NONE = 0, LU_REPLICATED = 1, LU_PER_STEP = 2, LU_MR_1HOP = 3, LU_MR_2HOP = 4, LU_MR_OV = 5, LU_FORMS = 6 };
+  int64_t lu_form_last = LU_NONE;
+  int64_t lu_form_count[LU_FORMS] = {0, 0, 0, 0, 0, 0};
+  int64_t ranks_seen = 1;              // sum over the communicator of one per rank, taken when it was created
+  int64_t lu_timeouts_recovered = 0;   // entry points re-run transparently after a lost co-residency (api.cpp:with_retry)
   int rank() const { return comm ? comm->rank : 0; }
   int nranks() const { return comm ? comm->nranks : 1; }
 };

@@ -453,21 +453,21 @@ class CpuBackend : public Backend {
 class CallbackComm : public Comm {
  public:
   CallbackComm(int n, int r) { nranks = n; rank = r; }
-  void allreduce_sum(double* buf, size_t count) override {
+  void do_allreduce_sum(double* buf, size_t count) override {
     if (!g_allreduce) throw Error(GSI_ERR_RCCL, "cpuref: collectives not registered");
     g_allreduce(buf, (int64_t)count);
   }
-  void allgather(const double* send, double* recv, size_t count) override {
+  void do_allgather(const double* send, double* recv, size_t count) override {
     if (!g_allgather) throw Error(GSI_ERR_RCCL, "cpuref: collectives not registered");
     g_allgather(send, recv, (int64_t)count);
   }
-  void reduce_scatter_sum(const double* send, double* recv, size_t count) override {   // all-reduce, keep own block
+  void do_reduce_scatter_sum(const double* send, double* recv, size_t count) override {   // all-reduce, keep own block
     if (!g_allreduce) throw Error(GSI_ERR_RCCL, "cpuref: collectives not registered");
     std::vector<double> tmp(send, send + count * (size_t)nranks);
     g_allreduce(tmp.data(), (int64_t)tmp.size());
     std::memcpy(recv, tmp.data() + count * (size_t)rank, count * sizeof(double));
   }
-  void alltoall(const double* send, double* recv, size_t count) override {             // all-gather, keep the blocks meant for me
+  void do_alltoall(const double* send, double* recv, size_t count) override {             // all-gather, keep the blocks meant for me
     if (!g_allgather) throw Error(GSI_ERR_RCCL, "cpuref: collectives not registered");
     std::vector<double> all(count * (size_t)nranks * (size_t)nranks);
     g_allgather(send, all.data(), (int64_t)(count * (size_t)nranks));
