@@ -68,6 +68,24 @@ end
 comm_init!(c::Context, nranks::Integer, rank::Integer, id::Vector{UInt8}) =
 	check(ccall((:gsi_ctx_comm_init, libgsi), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), c.h, nranks, rank, id))
 
+"Every rank's `values` on every rank (`gsi_ctx_host_allgather`): a `nranks x length(values)` matrix, row r = rank r - 1.  Also
+the job's barrier (it waits for the context's stream first): what a Distributed.jl host needs around the hot path."
+function host_allgather(c::Context, values::Vector{Float64}, nranks::Integer)
+	out = Matrix{Float64}(undef, length(values), nranks)
+	check(ccall((:gsi_ctx_host_allgather, libgsi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}), c.h, values, length(values), out))
+	return Matrix(out')
+end
+
+const LU_FORMS = ["none", "replicated", "per-step", "persistent-1hop", "persistent-2hop", "persistent-ov"]
+"Which path ran under the communicator (`gsi_ctx_path_info`): LU form, self-test mask of the in-kernel pivot exchange,
+collectives since the last phase reset, ranks joined, LU time-outs seen / hidden by a transparent re-run."
+function path_info(c::Context)
+	out = zeros(Int64, 12)
+	check(ccall((:gsi_ctx_path_info, libgsi), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64), c.h, out, length(out)))
+	return (lu_form = LU_FORMS[out[1] + 1], lu_selftest_mask = out[2], collectives = out[3], n_ranks_seen = out[4],
+		lu_timeouts = out[5], lu_timeouts_recovered = out[6], lu_forms_run = Dict(LU_FORMS[f + 1] => out[7 + f] for f = 1:5 if out[7 + f] > 0))
+end
+
 # ---- operators ------------------------------------------------------------------------------------
 mutable struct DeviceOperator
 	h::Ptr{Cvoid}
@@ -233,6 +251,34 @@ function Base.:*(At::AdjointOperator, X::Matrix{Float64})
 	return Y
 end
 Base.:*(A::DeviceOperator, x::Vector{Float64}) = vec(A * reshape(x, :, 1))            # lowrank.jl:135-139
+
+"`mul!(v, A, x)`  (lowrank.jl:75-81): v = A x into the caller's vector -- what IterativeSolvers.lsqr calls on the operator."
+function LinearAlgebra.mul!(v::Vector{Float64}, A::DeviceOperator, x::Vector{Float64})
+	length(v) == A.m && length(x) == A.n || throw(DimensionMismatch("mul!: A is $(A.m)x$(A.n), x has $(length(x)), v has $(length(v))"))
+	check(ccall((:gsi_op_mul, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
+		A.c.h, A.h, 0, x, A.n, 1, v, A.m))
+	return v
+end
+function LinearAlgebra.mul!(v::Vector{Float64}, At::AdjointOperator, x::Vector{Float64})
+	A = At.parent
+	length(v) == A.n && length(x) == A.m || throw(DimensionMismatch("mul!: A' is $(A.n)x$(A.m), x has $(length(x)), v has $(length(v))"))
+	check(ccall((:gsi_op_mul, libgsi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
+		A.c.h, A.h, 1, x, A.m, 1, v, A.n))
+	return v
+end
+
+"`B * A` for a plain matrix B  (lowrank.jl:123-129; `I * lrcm` at test/testrpcga.jl:49,90): B A = (A' B')', one device
+product on the transposed panel."
+function Base.:*(B::Matrix{Float64}, A::DeviceOperator)
+	size(B, 2) == A.m || throw(DimensionMismatch("B has $(size(B, 2)) columns, A has $(A.m) rows"))
+	return Matrix((adjoint(A) * Matrix(B'))')
+end
+"`B' * A` for an adjoint matrix  (lowrank.jl:131-133, RandMatFact.jl:85 `Q' * A`): (A' B)' -- for the symmetric
+LowRankCovMatrix this is the reference's `(A * B.parent)'`."
+function Base.:*(B::LinearAlgebra.Adjoint{Float64, Matrix{Float64}}, A::DeviceOperator)
+	size(B, 2) == A.m || throw(DimensionMismatch("B' has $(size(B, 2)) columns, A has $(A.m) rows"))
+	return (adjoint(A) * B.parent)'
+end
 
 "`\\(A::LowRankCovMatrix, b::Vector)`  (lowrank.jl:141-144): lsqr(A, b; maxiter=length(A.samples)) on the device."
 function Base.:\(A::DeviceOperator, b::Vector{Float64})

@@ -46,7 +46,10 @@ function lowrankcov_three_samples()
 	samples = Vector{Float64}[[-.5, 0., .5], [1., -1., 0.], [-.5, 1., -.5]]
 	lrcm = GH.LowRankCovMatrix(samples)
 	Id = Matrix{Float64}(LinearAlgebra.I, 3, 3)
-	full = lrcm * Id
+	full = Id * lrcm                                              # test/testrpcga.jl:49: Matrix{Float64}(I, 3, 3) * lrcm
+	Test.@test full ≈ lrcm * Id && full ≈ Id * lrcm && full ≈ Id' * lrcm      # lowrank.jl:115-133: A*B, B*A, B'*A
+	v = zeros(3)
+	Test.@test LinearAlgebra.mul!(v, lrcm, [1., 2., 3.]) ≈ full * [1., 2., 3.]   # lowrank.jl:75-81
 	Test.@test full ≈ sum(s * s' for s in samples) / (length(samples) - 1)
 	Test.@test full ≈ [.75 -.75 0; -.75 1 -.25; 0 -.25 .25]
 	Test.@test size(lrcm) == (3, 3) && size(lrcm, 1) == 3
@@ -97,7 +100,7 @@ function getxis_lowrank_vs_dense(; numfields=100, numxis=30, p=20, Ns=[25, 25])
 	samplefield = samplefield_factory(Ns)
 	lrcmxis, fields = GH.getxis(Val{:iwantfields}, samplefield, numfields, numxis, p, 3, 0)
 	lrcm = GH.LowRankCovMatrix(fields)
-	full = lrcm * Matrix{Float64}(LinearAlgebra.I, size(lrcm, 1), size(lrcm, 1))
+	full = Matrix{Float64}(LinearAlgebra.I, size(lrcm, 1), size(lrcm, 1)) * lrcm      # test/testrpcga.jl:90
 	fullxis = GH.getxis(full, numxis, p, 3, 0)                    # same seed -> same Omega in both calls
 	for i = eachindex(fullxis)
 		Test.@test min(LinearAlgebra.norm(fullxis[i] - lrcmxis[i]), LinearAlgebra.norm(fullxis[i] + lrcmxis[i])) < 1e-6
