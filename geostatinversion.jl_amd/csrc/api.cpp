@@ -159,6 +159,7 @@ int gsi_ctx_comm_init(gsi_ctx* ctx, int nranks, int rank, const void* id) {
     c.comm->allreduce_sum(b.p, 1);
     c.be->download2d(&seen, 1, b.p, 1, 1, 1);
     c.ranks_seen = (int64_t)(seen + 0.5);
+    c.be->set_ranks_sharing_device(c.comm->ranks_on_my_device());
     c.comm->ncollectives = 0;
   });
 }

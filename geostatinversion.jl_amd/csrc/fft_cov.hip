@@ -46,9 +46,21 @@ __device__ __forceinline__ void st2(double2* p, double2 v) { p->x = v.x; p->y = 
 enum { FFT_AXIS0 = 1, FFT_LOADX = 2, FFT_FUSED = 4, FFT_STOREY = 8, FFT_INVERSE = 16 };
 constexpr int FFT_TW_LEN = 8192;     // longest supported line; the plan stores exp(-2 pi i k / 8192), k < 4096
 constexpr int FFT_MAX_TILE = 8192;   // points of a tile (T lines): 16 per thread, 512 threads, 128 KB of LDS
+// Layout of the intermediate array W between the passes (round 4).  NATURAL: axis 0 fastest, element (k0, k1, k2) at
+// k0 + M0 (k1 + M1 k2): a strided pass over T neighbouring lines moves T x 16-byte segments that sit a whole axis-0 line
+// (a power of two of KB) apart.  BLOCKED (lb = log2 Tb > 0): axis 0 is cut into blocks of Tb points and the index ALONG
+// THE LAST AXIS comes next,
+//     element (k0, k1, k2)  at  ((k0 >> lb) D1 + k1) (N2 Tb) + k2 Tb + (k0 & (Tb - 1))        [2-D: (k0 >> lb) (N1 Tb) + k1 Tb + ...]
+// so the fused last-axis pass reads and writes ONE contiguous run per Tb lines (tiles of T <= Tb lines interleave
+// T x 16-byte pieces of it, completed in L2 by the neighbouring workgroups of the XCD), the axis-0 passes move Tb x 16-byte
+// runs (256 B at Tb = 16) instead of whole lines, and a middle axis (3-D) keeps T x 16-byte segments at a stride of N2 Tb
+// elements.  Every pass stays in place.  The padding of the last axis is still neither stored nor read.
 struct FftPass {
   int Ma, log2Ma, nin, nout, T, log2T, lstride, log2es;
   int64_t estride, R1, S1, R2, S2;
+  int lb, log2M0;           // lb = 0: natural layout
+  int kind;                 // strided passes: 0 natural, 1 blocked / lines along axis 1, 2 blocked / lines along axis 2
+  int64_t BK0, OS, ks;      // block stride of k0 >> lb; stride of the tile's other index; stride between consecutive k of a line
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt -- every global load and store in
@@ -267,7 +279,13 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
     } else {
       it.o0 = tile / tiles_per_outer;
       it.i0 = (tile - it.o0 * tiles_per_outer) << ps.log2T;
-      it.off0 = off(it.o0);
+      if (ps.kind == 0) {
+        it.off0 = off(it.o0) + it.i0;
+      } else {                                   // blocked: (k0 >> lb) BK0 + (other index) OS + (k0 & (Tb - 1))
+        const int k0 = (ps.kind == 1) ? it.i0 : (it.i0 & ((1 << ps.log2M0) - 1));
+        const int64_t other = (ps.kind == 1) ? (int64_t)it.o0 : (int64_t)(it.i0 >> ps.log2M0);
+        it.off0 = (int64_t)(k0 >> ps.lb) * ps.BK0 + other * ps.OS + (k0 & ((1 << ps.lb) - 1));
+      }
       it.nlines = T;
       it.lamoff = (int64_t)it.i0 * Ma;           // the spectrum of the last axis is stored line by line (transposed)
     }
@@ -285,18 +303,18 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
 #pragma unroll
       for (int r = 0; r < NPRE; ++r) {
         const int pos = f.jt + r * f.tpl;
-        const int64_t i = lo + (pos < ps.nin ? pos : ps.nin - 1);
-        if (LOADX) pre[r] = make_double2(X[i + ca * ldx], X[i + cb * ldx]);
-        else pre[r] = ld2(&Wb[i]);
+        const int pc = (pos < ps.nin ? pos : ps.nin - 1);
+        if (LOADX) { const int64_t i = lo + pc; pre[r] = make_double2(X[i + ca * ldx], X[i + cb * ldx]); }
+        else pre[r] = ld2(&Wb[lo + (int64_t)(pc >> ps.lb) * ps.BK0 + (pc & ((1 << ps.lb) - 1))]);      // natural: lb = 0, BK0 = 1
       }
     } else {
-      const double2* Wb = W + (int64_t)it.pair * Mtot + it.off0 + it.i0;
+      const double2* Wb = W + (int64_t)it.pair * Mtot + it.off0;
       const int t0 = opaque(tid);
 #pragma unroll
       for (int i = 0; i < NPRE; ++i) {
         const int e = t0 + i * nth;
         const int j = e & (T - 1), k = e >> ps.log2T;
-        pre[i] = ld2(&Wb[j + ((int64_t)(k < ps.nin ? k : ps.nin - 1) << ps.log2es)]);
+        pre[i] = ld2(&Wb[j + (int64_t)(k < ps.nin ? k : ps.nin - 1) * ps.ks]);
       }
     }
   };
@@ -371,19 +389,19 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
               Y[i + ca * ldy] = v[s].x;
               if (cb < l) Y[i + cb * ldy] = v[s].y;
             } else {
-              st2(&Wb[pos], v[s]);
+              st2(&Wb[(int64_t)(pos >> ps.lb) * ps.BK0 + (pos & ((1 << ps.lb) - 1))], v[s]);
             }
           }
         }
       }
     } else {
-      double2* Wb = W + (int64_t)it.pair * Mtot + it.off0 + it.i0;
+      double2* Wb = W + (int64_t)it.pair * Mtot + it.off0;
       const int t0 = opaque(tid);
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
         const int e = t0 + i * nth;
         const int j = e & (T - 1), k = e >> ps.log2T;
-        if (k < ps.nout) st2(&Wb[j + ((int64_t)k << ps.log2es)], ld2(&buf[j * ps.lstride + swz(k)]));
+        if (k < ps.nout) st2(&Wb[j + (int64_t)k * ps.ks], ld2(&buf[j * ps.lstride + swz(k)]));
       }
       lds_barrier();      // the lines are free for the next item (the stores above are not waited for)
     }
@@ -558,6 +576,27 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
   if (axis == 0) { ps.R1 = N[1]; ps.S1 = stride[1]; ps.R2 = N[2]; ps.S2 = stride[2]; }
   else if (axis == 1) { ps.R1 = N[2]; ps.S1 = stride[2]; }
   const int64_t nouter = ps.R1 * ps.R2;
+  // ---- the layout of W (see FftPass): blocked unless switched off or the grid has no strided pass / a short axis 0
+  const int d = (M[2] > 1) ? 3 : ((M[1] > 1) ? 2 : 1);
+  static const int tb_env = getenv("GSI_FFT_TB") ? atoi(getenv("GSI_FFT_TB")) : 16;
+  int lb = 0;
+  if (d >= 2 && tb_env >= 4 && M[0] >= 64) { while ((2 << lb) <= tb_env && (2 << lb) <= 16) ++lb; }
+  const int Tb = 1 << lb;
+  ps.lb = lb; ps.log2M0 = ilog2(M[0]); ps.kind = 0; ps.BK0 = 1; ps.OS = 0; ps.ks = ps.estride;
+  if (lb > 0) {
+    // element (k0, k1, k2) at ((k0 >> lb) D1 + k1) (N2 Tb) + k2 Tb + (k0 & (Tb - 1)); 2-D: D1 = 1, "k2" = k1, N2 -> N1
+    const int64_t Nl = (d == 3) ? N[2] : N[1], D1 = (d == 3) ? M[1] : 1;
+    ps.BK0 = D1 * Nl * Tb;
+    if (axis == 0) {                       // lines o = (k1, k2) restricted to the grid: off(o) = k1 S1 + k2 S2
+      if (d == 3) { ps.S1 = Nl * Tb; ps.S2 = Tb; } else { ps.S1 = Tb; ps.S2 = 0; }
+    } else if (axis == 1 && d == 3) {      // tile = T neighbours in k0 at fixed k2 = o; k = k1
+      ps.kind = 1; ps.OS = Tb; ps.ks = Nl * Tb;
+    } else if (axis == 1) {                // 2-D: the last axis; k = k1, no outer index
+      ps.kind = 1; ps.OS = 0; ps.ks = Tb;
+    } else {                               // axis 2: tile = T neighbours in k0 at fixed k1 = inner / M0; k = k2
+      ps.kind = 2; ps.OS = Nl * Tb; ps.ks = Tb;
+    }
+  }
   // lines per workgroup, within 8192 points (16 per thread, 512 threads, 128 KB).  Contiguous lines need no neighbours:
   // GSI_FFT_B0 KB of LDS so that several workgroups share a CU.  Strided lines want long segments: a power of two of
   // neighbouring lines, up to 16 (256 bytes) within GSI_FFT_B1 KB, but at least 4 (64 bytes) whatever that costs.
@@ -579,10 +618,16 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
     ps.lstride = ps.Ma;
   } else {
     int want = (int)((int64_t)b1 * 1024 / line_bytes);
-    if (want < 4) want = 4;
+    // at least 4 lines (64-byte segments) whatever that costs -- unless the layout is blocked, where the pieces of the
+    // tiles of one block are neighbours in memory and GSI_FFT_MIN_T=2 lets two half-size workgroups share a CU (A/B)
+    static const int min_t = getenv("GSI_FFT_MIN_T") ? atoi(getenv("GSI_FFT_MIN_T")) : 4;
+    const int floor_t = (lb > 0 && min_t >= 1 && min_t < 4) ? min_t : 4;
+    if (want < floor_t) want = floor_t;
     if (want > 16) want = 16;
     if (want > tmax) want = tmax;
     if (want > ps.estride) want = (int)ps.estride;   // estride is a power of two >= 4
+    if (lb > 0 && want > Tb) want = Tb;              // a tile never leaves its block of Tb lines
+    if (lb > 0 && want > M[0]) want = (int)M[0];
     T = 1; ps.log2T = 0;
     while (2 * T <= want) { T *= 2; ++ps.log2T; }
     ps.lstride = ps.Ma + (T >= 2 ? 16 / T : 0);      // line-fastest fills and drains: T lines x 16/T neighbours = 16 banks rows apart

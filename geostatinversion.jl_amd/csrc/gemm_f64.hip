@@ -44,6 +44,7 @@
 #include <type_traits>
 #include <algorithm>
 #include "hip_common.hpp"
+#include "pointcov.hpp"
 
 namespace gsi { namespace hipk {
 
@@ -70,13 +71,39 @@ static_assert(A_PAIRS * 2 * NTHREADS == BMT * BK, "tile does not divide over the
 // the lookups are L1 hits.  (A first version kept separable kernels as two 1-D tables and multiplied; one 2-D lookup
 // covers the non-separable kernels too -- exponential, Matern -- and costs one load instead of two and a multiply.)
 struct GenA {
-  const double* t2;   // nx * ny entries
-  int32_t ny;
-  int32_t pad_;
+  const double* t2;   // GEN 1: nx * ny entries of the kernel over grid offsets.  GEN 2: the points, 4 doubles each (x, y, z, 0)
+  int32_t ny;         // GEN 2: number of points
+  int32_t kind;       // GEN 2: pointcov::GAUSSIAN ...
   int64_t roff;       // global index of row 0 of the product
   int64_t koff;       // global index of reduction index 0
+  double inv_ell2, sigma2, nugget;   // GEN 2
 };
 
+// GEN 2: the covariance of SCATTERED points, A(i, j) = sigma2 k(|p_i - p_j| / ell) (+ nugget on the diagonal), evaluated where
+// the stored-operand kernel would write a staged tile into LDS (round 4; SURVEY.md 8b "entries generated in the tile loader").
+// Round 3 generated row panels of A into HBM on a second stream and contracted them with the stored-operand kernel; the two
+// never overlapped (the contraction fills the register file of every CU), so a panel cost generation + contraction:
+// 46.6 TFLOP/s against 62.6 for the table-based operator.  Here a thread owns two rows (their coordinates stay in
+// registers for the whole kernel), the column point of a pair slot is wave-uniform (scalar loads of 32-byte records), and
+// the ~35 VALU instructions per entry issue in the shadow of the partner wave's MFMAs (an entry feeds 2 l flops of matrix
+// work).  Nothing is prefetched for A -- there is no latency to hide -- so the staging registers of the stored operand are free
+// for the coordinates and the polynomial.  One definition of the kernels: pointcov.hpp.
+// every kind as  v = sigma2 (1 + p1 a + p2 a^2) exp(-arg),  a = c1 r:  Gaussian arg = r^2 / 2 (no square root), the others
+// arg = a; (c1, p1, p2) = exponential (1, 0, 0), Matern 3/2 (sqrt 3, 1, 0), Matern 5/2 (sqrt 5, 1, 1/3).  The same
+// association as pointcov::kernel: (1 + a) + (a a) / 3.  One straight-line body for all kinds, parameters in SGPRs.
+struct GenPointK { double inv_ell2, sigma2, c1, p1, p2; int gauss; };
+__device__ __forceinline__ double gen_point_entry(const GenPointK& q, double d2) {
+  const double r2 = d2 * q.inv_ell2;
+  double arg, poly = 1.0;
+  if (q.gauss) {                                   // uniform
+    arg = 0.5 * r2;
+  } else {
+    const double a = q.c1 * sqrt(r2);
+    arg = a;
+    poly = (1.0 + q.p1 * a) + (a * a) * q.p2;
+  }
+  return poly * pointcov::exp_nonpos(-arg) * q.sigma2;
+}
 // RAGGED: the "irregular X" instantiation.  Either the sketch width is not a multiple of 16 (K + p is the
 // caller's choice), so the last columns of the X tile do not exist, or X is only 8-byte aligned (n odd as its
 // leading dimension).  It keeps the 16-byte stream of the operator and loads the X pairs per column, predicated,
@@ -84,12 +111,12 @@ struct GenA {
 // second fast path cost the regular case 2.7 %, hence the template parameter.
 // XMODE 2 = irregular X with 64-bit per-thread offsets: leading dimensions beyond the reach of the 32-bit tile
 // offsets (160 columns * ld * 8 B >= 4 GiB, i.e. panels of more than ~3.3 million rows).  Slower addressing, same code.
-template <int NT, bool TRANS_A, bool GEN, int XMODE>
+template <int NT, bool TRANS_A, int GEN, int XMODE>
 __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     int64_t M, int64_t L, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* __restrict__ C, int64_t ldc, double alpha,
     double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, int wide, int tri, GenA gen) {
-  static_assert(!(GEN && TRANS_A), "the generated operand is symmetric: only the NN form exists");
+  static_assert(!(GEN != 0 && TRANS_A), "the generated operand is symmetric: only the NN form exists");
   constexpr bool RAGGED = XMODE != 0;
   constexpr bool BIG = XMODE == 2;
   using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
@@ -190,7 +217,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   // index the NEXT prefetched pair slot covers.  The latter is wave-uniform (a_k = wave index), lives in
   // SGPRs and is advanced incrementally -- prefetch() is called on consecutive tiles, in order.
   int g_x0 = 0, g_y0 = 0, g_x1 = 0, g_y1 = 0, g_kx = 0, g_ky = 0;
-  if constexpr (GEN) {
+  double p0x = 0.0, p0y = 0.0, p0z = 0.0, p1x = 0.0, p1y = 0.0, p1z = 0.0;      // GEN 2: this thread's two row points
+  int64_t g_row0 = 0;
+  GenPointK gq{};
+  if constexpr (GEN == 2) {                        // the points ride in the (otherwise unused) A argument: const __restrict__
+    g_row0 = gen.roff + r0 + a_r;
+    const int64_t i0 = (g_row0 < gen.ny) ? g_row0 : (int64_t)gen.ny - 1, i1 = (g_row0 + 1 < gen.ny) ? g_row0 + 1 : (int64_t)gen.ny - 1;
+    p0x = A[4 * i0]; p0y = A[4 * i0 + 1]; p0z = A[4 * i0 + 2];
+    p1x = A[4 * i1]; p1y = A[4 * i1 + 1]; p1z = A[4 * i1 + 2];
+    gq.inv_ell2 = gen.inv_ell2; gq.sigma2 = gen.sigma2; gq.gauss = (gen.kind == pointcov::GAUSSIAN) ? 1 : 0;
+    gq.c1 = (gen.kind == pointcov::MATERN32) ? 1.7320508075688772 : ((gen.kind == pointcov::MATERN52) ? 2.23606797749979 : 1.0);
+    gq.p1 = (gen.kind == pointcov::MATERN32 || gen.kind == pointcov::MATERN52) ? 1.0 : 0.0;
+    gq.p2 = (gen.kind == pointcov::MATERN52) ? (1.0 / 3.0) : 0.0;
+  }
+  if constexpr (GEN == 1) {
     const int64_t gr = gen.roff + r0 + a_r;
     g_x0 = (int)(gr / gen.ny); g_y0 = (int)(gr % gen.ny);
     g_x1 = g_x0; g_y1 = g_y0 + 1;
@@ -202,7 +242,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 
   auto prefetch = [&](int64_t k0, auto SET) {
     constexpr int set = decltype(SET)::value;
-    if constexpr (GEN) {
+    if constexpr (GEN == 1) {
       const int64_t kfirst = k0 + __builtin_amdgcn_readfirstlane(a_k);
       auto advance = [&]() {
         g_ky += KSTEP_NN;
@@ -234,7 +274,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     off_t a_step = a_step_c, b_step = b_step_c;
     if constexpr (!BIG) asm volatile("" : "+s"(a_step), "+s"(b_step));
     if (wide && wg_full && k0 + BK <= kend) {
-      if constexpr (!GEN) {
+      if constexpr (GEN == 0) {
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it)
         {   // A is streamed once: non-temporal, to keep it out of the way of the X tiles in L2
@@ -264,7 +304,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
       return;
     }
     // general path: element-wise, predicated (edges, odd leading dimensions, unaligned views)
-    if constexpr (!GEN) {
+    if constexpr (GEN == 0) {
 #pragma unroll
     for (int it = 0; it < A_PAIRS; ++it) {
       const char* p = Ab + (a_off0 + (off_t)it * a_step);
@@ -288,10 +328,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     }
   };
 
-  auto stage = [&](int buf, auto SET) {
+  auto stage = [&](int buf, auto SET, int64_t k0) {
     constexpr int set = decltype(SET)::value;
     double* a_s = smem + buf * BUF_ELEMS;
     double* b_s = a_s + A_ELEMS;
+    (void)k0;
+    if constexpr (GEN == 2) {
+      const bool ok_r0 = r0 + a_r < M, ok_r1 = r0 + a_r + 1 < M;
+      const int kw = __builtin_amdgcn_readfirstlane(a_k);                   // wave index: the pair slot's k is wave-uniform
+#pragma unroll
+      for (int it = 0; it < A_PAIRS; ++it) {
+        const int64_t kc = k0 + kw + KSTEP_NN * it;
+        const bool okk = kc < kend;
+        const int64_t gj = gen.koff + (okk ? kc : kbeg);
+        // provably uniform index -> scalar loads of the 32-byte record of the column point
+        const int64_t gju = ((int64_t)__builtin_amdgcn_readfirstlane((int)(gj >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(gj & 0xffffffff));
+        const double qx = A[4 * gju], qy = A[4 * gju + 1], qz = A[4 * gju + 2];
+        double dx = p0x - qx, dy = p0y - qy, dz = p0z - qz;
+        double v0 = gen_point_entry(gq, fma(dx, dx, fma(dy, dy, dz * dz)));
+        dx = p1x - qx; dy = p1y - qy; dz = p1z - qz;
+        double v1 = gen_point_entry(gq, fma(dx, dx, fma(dy, dy, dz * dz)));
+        v0 += (g_row0 == gju) ? gen.nugget : 0.0;
+        v1 += (g_row0 + 1 == gju) ? gen.nugget : 0.0;
+        double2 pr;
+        pr.x = (okk && ok_r0) ? v0 : 0.0;
+        pr.y = (okk && ok_r1) ? v1 : 0.0;
+        *reinterpret_cast<double2*>(a_s + (a_k + KSTEP_NN * it) * BMP + a_r) = pr;
+      }
+    } else
     if (TRANS_A) {
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it)
@@ -338,7 +403,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     // pipe (measured +1.5..2 %; a static priority for waves 4-7 alone measured -1 %).
     auto chores = [&]() {
       __builtin_amdgcn_s_setprio(0);
-      if (t + 1 < ntiles) stage(cur ^ 1, NextSet{});                                 // tile t+1: registers -> other LDS buffer
+      if (t + 1 < ntiles) stage(cur ^ 1, NextSet{}, kbeg + (t + 1) * BK);            // tile t+1: registers -> other LDS buffer
       if (t + 1 + NSETS < ntiles) prefetch(kbeg + (t + 1 + NSETS) * BK, NextSet{});  // HBM -> the set just drained
       __builtin_amdgcn_s_setprio(1);
     };
@@ -374,7 +439,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   if (ntiles > 0) {
     prefetch(kbeg, Set0{});
     if (NSETS == 2 && ntiles > 1) prefetch(kbeg + BK, Set1{});
-    stage(0, Set0{});
+    stage(0, Set0{}, kbeg);
     if (ntiles > NSETS) prefetch(kbeg + NSETS * BK, Set0{});
     __syncthreads();
 #pragma unroll
@@ -433,7 +498,7 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t L, int nsplit, const dou
   }
 }
 
-template <int NT, bool TRANS_A, bool GEN, int XMODE>
+template <int NT, bool TRANS_A, int GEN, int XMODE>
 static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A,
                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha,
                       double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide, int tri, const GenA& gen) {
@@ -446,7 +511,7 @@ static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K
                      ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen);
 }
 
-template <bool TRANS_A, bool GEN>
+template <bool TRANS_A, int GEN>
 static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K,
                             const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
                             int64_t ldc, double alpha, double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide,
@@ -461,8 +526,12 @@ static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_
       launch_nt<N, TRANS_A, GEN, 0>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen); \
     break;
   switch (nt) {
+#ifdef GSI_GEMM_DEV_ONLY_NT10      // developer builds (resource-usage remarks of one instantiation in seconds); never set by build.py
+    GSI_CASE(10)
+#else
     GSI_CASE(1) GSI_CASE(2) GSI_CASE(3) GSI_CASE(4) GSI_CASE(5)
     GSI_CASE(6) GSI_CASE(7) GSI_CASE(8) GSI_CASE(9) GSI_CASE(10)
+#endif
     default: break;
   }
 #undef GSI_CASE
@@ -515,7 +584,7 @@ static int gemm_chunk_tiles(int) { return NTMAX; }
 
 static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M, int64_t L, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
-                        int64_t ldc, double* ws, int tri = 0) {
+                        int64_t ldc, double* ws, int tri = 0, int gen_mode = 1) {
   if (M <= 0 || L <= 0) return;
   // The kernel addresses a tile with one uniform 64-bit base per operand plus per-thread byte offsets spanning up to
   // 160 columns of B, 128 rows of a transposed A or 32 columns of a plain A: 32 bits reach panels of ~3.3 million
@@ -552,13 +621,15 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   const bool irregular_x = a_ok && (!b_ok || L % ((int64_t)nt * 16) != 0);
   const int wide = a_ok ? 1 : 0;
   const int xmode = big ? 2 : (irregular_x ? 1 : 0);
-  const GenA none = {nullptr, 1, 0, 0, 0};
-  if (gen != nullptr)
-    launch_dispatch<false, true>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, *gen);
+  const GenA none = {nullptr, 1, 0, 0, 0, 0.0, 0.0, 0.0};
+  if (gen != nullptr && gen_mode == 2)
+    launch_dispatch<false, 2>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, *gen);
+  else if (gen != nullptr)
+    launch_dispatch<false, 1>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, *gen);
   else if (transA)
-    launch_dispatch<true, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none);
+    launch_dispatch<true, 0>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none);
   else
-    launch_dispatch<false, false>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none);
+    launch_dispatch<false, 0>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none);
   if (ns_eff > 1) {
     const int64_t total = M * L;
     int blocks = (int)((total + 255) / 256);
@@ -592,9 +663,28 @@ void gemm_f64_trmm_upper(hipStream_t st, int64_t M, int64_t L, int64_t K, const 
 void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* tab, int64_t nx, int64_t ny,
                       int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws) {
   (void)nx;
-  GenA g = {tab, (int32_t)ny, 0, roff, koff};
+  GenA g = {tab, (int32_t)ny, 0, roff, koff, 0.0, 0.0, 0.0};
   // A / lda only feed the 16-byte-load test for the stored operand: pass aligned dummies
   gemm_launch(st, false, &g, M, L, K, 1.0, nullptr, 2, B, ldb, 0.0, C, ldc, ws);
+}
+
+// C (M x L) = G * B with G(i, k) = sigma2 kfun(|p_i - p_k| / ell) (+ nugget if i == k), i = roff + row, k = koff + reduction
+// index; pts4 = the points as 32-byte records (x, y, z, 0), npts of them, in device memory.  G is generated in the tile
+// loader, never stored (GEN 2 above).
+void gemm_f64_pointcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int kind, double inv_ell,
+                       double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
+                       int64_t ldc, double* ws) {
+  GenA g = {pts4, (int32_t)npts, kind, roff, koff, inv_ell * inv_ell, sigma2, nugget};
+  gemm_launch(st, false, &g, M, L, K, 1.0, pts4, 2, B, ldb, 0.0, C, ldc, ws, 0, 2);      // A = the points (16-byte aligned records)
+}
+// pts (d x n, point i = column i) -> 32-byte records (x, y, z, 0)
+__global__ __launch_bounds__(256) void pointcov_pad_kernel(const double* __restrict__ pts, int d, int64_t n, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  for (int a = 0; a < 4; ++a) out[4 * i + a] = (a < d) ? pts[i * d + a] : 0.0;
+}
+void pointcov_pad_points(hipStream_t st, const double* pts, int d, int64_t n, double* out4) {
+  hipLaunchKernelGGL(pointcov_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pts, d, n, out4);
 }
 
 }}  // namespace gsi::hipk

@@ -259,6 +259,18 @@ class HipBackend : public Backend {
                         int64_t ldc) override {
     bind();
     if (m <= 0 || l <= 0 || k <= 0) return;
+    // Default (round 4): the entries are generated inside the contraction's tile loader (gemm_f64.hip, GEN 2) -- nothing of A
+    // ever exists in HBM.  GSI_POINTCOV_PANELS=1 keeps round 3's row panels generated on a second stream (A/B).
+    static const bool panels = (getenv("GSI_POINTCOV_PANELS") != nullptr && getenv("GSI_POINTCOV_PANELS")[0] == '1');
+    if (!panels) {
+      const int64_t npts = std::max(roff + m, koff + k);
+      Scratch p4(this, (size_t)4 * npts);                  // the points as 32-byte records (x, y, z, 0): one scalar load each
+      hipk::pointcov_pad_points(st_, pts, d, npts, p4.p);
+      double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, k));
+      hipk::gemm_f64_pointcov(st_, m, l, k, p4.p, npts, kind, 1.0 / ell, sigma2, nugget, roff, koff, B, ldb, C, ldc, ws);
+      check_launch("gemm_nn_pointcov (in-loader generator)");
+      return;
+    }
     pointcov::Params prm{d, kind, 1.0 / ell, sigma2, nugget};
     // panel height: a multiple of 128 rows (the contraction's row block), <= m.  Tall panels keep the contraction efficient
     // (its output tile count grows with the panel height: measured 35 TFLOP/s with 4 GB panels, 39 with 16 GB at n = 2e5):
@@ -404,9 +416,12 @@ class HipBackend : public Backend {
     // win (measured cross-over: 6e6 rows at l = 320).  GSI_LU_OV=0 switches it off (A/B).
     static const int64_t ov_max = getenv("GSI_LU_OV_MAX") ? atoll(getenv("GSI_LU_OV_MAX")) : ((int64_t)5 << 20);
     static const bool ov_off = (getenv("GSI_LU_OV") != nullptr && getenv("GSI_LU_OV")[0] == '0');
-    bool fits = !force_sweeps && !tall_first && !lu2_lost_ && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid) &&
-                lu2_fits(w2.bs, w2.rpt, w2.grid);
-    if (!fits && !force_sweeps && !tall_first && !lu2_lost_ && !ov_off && m <= ov_max && ncus_ >= 1) {
+    // Ranks that SHARE this device (the RCCL-free communicators, one-GPU rehearsals of a multi-GPU job) each factor their
+    // replicated panel with a whole-chip grid of their own: the grids cannot all be resident, so the persistent kernel is
+    // not a candidate at all (seen: 2 rank processes on one GPU, gathered 10^6 x 320 panel: a poll time-out on some runs).
+    const bool resident_ok = !force_sweeps && !tall_first && !lu2_lost_ && ranks_sharing_device_ <= 1;
+    bool fits = resident_ok && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid) && lu2_fits(w2.bs, w2.rpt, w2.grid);
+    if (!fits && resident_ok && !ov_off && m <= ov_max && ncus_ >= 1) {
       const int g = std::min(ncus_, 256);
       if (m > (int64_t)g * 4096) {
         if (lu2_ov_resident_ < 0) lu2_ov_resident_ = hipk::lu2_resident_per_cu_ov();
@@ -1062,6 +1077,7 @@ class HipBackend : public Backend {
     out4[0] = n_cholqr_; out4[1] = n_householder_; out4[2] = last_svd_sweeps_; out4[3] = n_scholqr3_;
   }
   int64_t lu_timeouts() override { return n_lu_timeouts_; }
+  void set_ranks_sharing_device(int n) override { ranks_sharing_device_ = n; }
   int device() const { return device_; }
 
  private:
@@ -1174,6 +1190,7 @@ class HipBackend : public Backend {
   uint32_t mr_epoch_ = 0;
   bool mr_disabled_ = false, mr_peer_swaps_ = true;
   bool mr_share_tried_ = false, mr_in_flight_ = false;
+  int ranks_sharing_device_ = 1;
   int64_t mr_gen_ = 0, n_lu_timeouts_ = 0;
   std::string mr_reason_, mr_why_disabled_;
   std::set<int64_t> mr_warm_;

@@ -39,6 +39,11 @@ void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const dou
                       int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws);
 
 // ---- pointcov.hip: row panels of a scattered-point covariance ----
+// the scattered-point covariance generated inside the contraction's tile loader (gemm_f64.hip, GEN 2); pts4: 32-byte records
+void gemm_f64_pointcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int kind, double inv_ell,
+                       double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
+                       int64_t ldc, double* ws);
+void pointcov_pad_points(hipStream_t st, const double* pts, int d, int64_t n, double* out4);
 void pointcov_panel(hipStream_t st, double* P, int64_t ldp, int64_t rows, int64_t cols, const double* pts,
                     const pointcov::Params& prm, int64_t roff, int64_t koff);
 

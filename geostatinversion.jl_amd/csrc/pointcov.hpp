@@ -16,7 +16,8 @@ struct Params { int d, kind; double inv_ell, sigma2, nugget; };
 // exp with its special cases -- the generator evaluates it once per matrix entry (1e12 times per pass at n = 1e6).
 GSI_PC_HD inline double exp_nonpos(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (x < -745.2) return 0.0;
+  const bool under = x < -745.2;                   // (a select at the end, not an early return: no divergent branch per entry)
+  x = under ? 0.0 : x;
   const double n = rint(x * 1.4426950408889634);
   double r = fma(-n, 6.93147180369123816490e-01, x);
   r = fma(-n, 1.90821492927058770002e-10, r);
@@ -33,7 +34,8 @@ GSI_PC_HD inline double exp_nonpos(double x) {
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(p, (int)n);
+  const double e = ldexp(p, (int)n);
+  return under ? 0.0 : e;
 #else
   return exp(x);
 #endif
