@@ -131,11 +131,22 @@ class Backend {
   // (stacked R factors of the TSQR, gathered panels): the backend must then not let anything rank-local
   // (e.g. which algorithm tier an earlier rank-local panel needed) steer the choice of algorithm.
   virtual void qr_thinQ(double* Y, int64_t m, int64_t l, int64_t ld, double* R, bool replicated = false) = 0;
+  // The thin Q of Y UP TO A RIGHT FACTOR: on success *Q1 (m x l, ld *ldq1, in backend workspace: valid until this
+  // backend's next factorization call) and X2 (l x l upper triangular, caller's buffer) with Q = Q1 X2 orthonormal and
+  // range(Q) = range(Y); Y is untouched.  What CholeskyQR2 has after its second Gram matrix, one tall product short of
+  // Q.  A caller that only ever multiplies Q from the left (B = Q'A in randsvd) folds X2 into the l x l factor behind
+  // it and never pays that product.  false: not available for this panel (the caller runs qr_thinQ).
+  virtual bool qr_thinQ_deferred(const double* Y, int64_t m, int64_t l, int64_t ld, const double** Q1, int64_t* ldq1,
+                                 double* X2) { (void)Y; (void)m; (void)l; (void)ld; (void)Q1; (void)ldq1; (void)X2; return false; }
   // thin SVD of a tall W (n x l, ld) in one go, W untouched: V (n x l, ldv) = left singular vectors (scaled by sqrt(S_i)
   // for i < K_scale, zero beyond, when K_scale >= 0), S (l).  A backend may decline (false): the caller then runs
   // qr_thinQ + svd_small + the l x l product itself.  The HIP backend fuses the last product of CholeskyQR2 with the
   // product by the small factor: Z = T (R2^-1 U sqrt(S)) -- one tall product instead of two.
-  virtual bool svd_tall_fused(const double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, double*) { return false; }
+  // Xr (may be null): an l x l right factor -- the SVD is that of W Xr (the X2 a deferred thin Q left behind).
+  virtual bool svd_tall_fused(const double*, int64_t, int64_t, int64_t, int64_t, double*, int64_t, double*, const double* Xr = nullptr) {
+    (void)Xr;
+    return false;
+  }
   // G (l x l, ld l), columns orthogonalised in place by one-sided Jacobi; on return
   // U (l x l) = left singular vectors sorted by descending S, S (l) singular values.
   virtual void svd_small(double* G, int64_t l, double* U, double* S) = 0;

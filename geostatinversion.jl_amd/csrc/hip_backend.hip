@@ -791,11 +791,46 @@ class HipBackend : public Backend {
     hipk::qr_thinQ(st_, Y, m, l, ld, R, w, ws);
     check_launch("qr_thinQ");
   }
+  // CholeskyQR2 stopped one tall product short (Backend::qr_thinQ_deferred): T = Y R1^-1 stays in the QR workspace, X2 = R2^-1
+  // goes to the caller.  Only the first tier (the guard of qr_thinQ decides: a panel that needs the shifted tier or
+  // Householder gets its Q the ordinary way), and only while the workspace is one this backend keeps between calls.
+  bool qr_thinQ_deferred(const double* Y, int64_t m, int64_t l, int64_t ld, const double** Q1, int64_t* ldq1, double* X2) override {
+    bind();
+    static const bool off = (getenv("GSI_NO_CHOLQR") != nullptr) || (getenv("GSI_NO_QR_DEFER") != nullptr);
+    if (off || l > 1024 || m < 2 * l) return false;
+    const int64_t ldt = (m + 1) & ~(int64_t)1;
+    if ((size_t)ldt * l * sizeof(double) > ((size_t)8 << 30)) return false;       // trimmed on return: nothing would be left to hand out
+    int& skip_tier1 = skip_tier1_by_height_[std::make_pair(m, false)];
+    if (skip_tier1 > 0) return false;
+    size_t cnt = 0;
+    auto take = [&](size_t c) { size_t o = cnt; cnt += (c + 7) & ~(size_t)7; return o; };
+    const size_t o_small = take(hipk::cholqr_small_doubles(l)), o_T = take((size_t)ldt * l);
+    grow(ws_qr_, cnt * sizeof(double));
+    double* base = (double*)ws_qr_.p;
+    size_t gmax = hipk::gemm_workspace_doubles(l, l, m);
+    gmax = std::max(gmax, hipk::gemm_syrk_workspace_doubles(l, m));
+    gmax = std::max(gmax, hipk::syrk_upper_workspace_doubles(l, m));
+    gmax = std::max(gmax, hipk::gemm_workspace_doubles(m, l, l));
+    gmax = std::max(gmax, hipk::gemm_workspace_doubles(l, 32, l));
+    double* ws = gemm_ws(gmax + 64);
+    int32_t f = 0;
+    HIP_CHECK(hipMemsetAsync(flags_ + 9, 0, sizeof(int32_t), st_));
+    hipk::cholqr2_factor(st_, Y, m, l, ld, base + o_T, ldt, base + o_small, flags_ + 9, ws);
+    check_launch("cholqr2_factor");
+    HIP_CHECK(hipMemcpyAsync(&f, flags_ + 9, sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    if (f != 0) { skip_tier1 = 8; return false; }
+    HIP_CHECK(hipMemcpyAsync(X2, hipk::cholqr2_X2(base + o_small, l), sizeof(double) * (size_t)l * l, hipMemcpyDeviceToDevice, st_));
+    *Q1 = base + o_T;
+    *ldq1 = ldt;
+    ++n_cholqr_;
+    return true;
+  }
   // svd(B) for B = W' (RandMatFact.jl:86-88) without forming the thin Q of W: CholeskyQR2's first round leaves
   // T = W R1^-1 and R2, R2^-1; R = R2 R1 goes to the Jacobi SVD, and Z = T (R2^-1 (U sqrt(S))) is ONE tall product
   // (the generic path runs Y = T R2^-1 and Z = Y (U sqrt(S)): two).  Declines when CholeskyQR2 does not apply.
   bool svd_tall_fused(const double* W, int64_t m, int64_t l, int64_t ld, int64_t K_scale, double* V, int64_t ldv,
-                      double* S) override {
+                      double* S, const double* Xr) override {
     bind();
     static const bool off = (getenv("GSI_NO_CHOLQR") != nullptr) || (getenv("GSI_NO_SVD_FUSION") != nullptr);
     if (off || l > 1024 || m < 2 * l) return false;
@@ -829,6 +864,10 @@ class HipBackend : public Backend {
       return false;                                         // W is untouched: the caller's generic path takes over
     }
     hipk::cholqr2_R(st_, l, base + o_small, base + o_R);    // R = R2 R1
+    if (Xr != nullptr) {                                    // the SVD wanted is that of W Xr = Q (R Xr): one l x l product
+      hipk::gemm_f64(st_, false, l, l, l, 1.0, base + o_R, l, Xr, l, 0.0, base + o_M, l, ws);
+      HIP_CHECK(hipMemcpyAsync(base + o_R, base + o_M, sizeof(double) * (size_t)l * l, hipMemcpyDeviceToDevice, st_));
+    }
     phase_end(PH_QR);
     ++n_cholqr_;
     phase_begin(PH_SVD);

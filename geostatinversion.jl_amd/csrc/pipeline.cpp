@@ -674,7 +674,13 @@ static Buf rangefinder_rows(const Operator& A, const double* Omega_loc, int64_t 
   return Yloc;
 }
 
-Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
+// `defer` (randsvd on one rank): the final thin Q may come back one tall product short -- Q = Q1 X2 with Q1 in backend
+// workspace (Backend::qr_thinQ_deferred); the returned Buf is then empty and defer->Q1 / ldq / X2 are set.
+struct DeferredQ { const double* Q1 = nullptr; int64_t ldq = 0; Buf X2; };
+static Buf rangefinder_impl(const Operator& A, const double* Omega, int64_t l, int64_t q, DeferredQ* defer);
+Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) { return rangefinder_impl(A, Omega, l, q, nullptr); }
+
+static Buf rangefinder_impl(const Operator& A, const double* Omega, int64_t l, int64_t q, DeferredQ* defer) {
   Context& c = *A.ctx;
   Backend* be = c.be.get();
   if (q < 0)   // RandMatFact.jl:62-64
@@ -683,9 +689,19 @@ Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
   if (l < 1 || l > A.m || l > A.n) throw Error(GSI_ERR_ARG, "rangefinder: need 1 <= l <= min(size(A))");
   const bool single = (c.nranks() == 1);
   const int64_t m = A.m, n = A.n;
+  auto final_q_single = [&](Buf& Y) -> bool {               // true: deferred, Y is no longer needed
+    if (defer == nullptr || !single) return false;
+    ScopedPhase ph(be, PH_QR);
+    defer->X2 = Buf(be, (size_t)l * l);
+    if (be->qr_thinQ_deferred(Y.p, m, l, m, &defer->Q1, &defer->ldq, defer->X2.p)) return true;
+    defer->X2.reset();
+    defer->Q1 = nullptr;
+    return false;
+  };
   if (q == 0) {
     Buf Yloc(be, (size_t)std::max<int64_t>(A.mloc, 1) * l);
     op_mul(A, Omega, n, l, Yloc.p, A.mloc);                 // Y = A*Omega            :55
+    if (final_q_single(Yloc)) return Buf();
     tsqr(c, A, Yloc, l);                                    //                        :57-58
     return Yloc;
   }
@@ -717,6 +733,7 @@ Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
   }
   Z.reset();                                                // the QR below wants a panel of its own (512^3: each is tens of GB)
   if (single) {
+    if (final_q_single(Yfull)) return Buf();
     tsqr(c, A, Yfull, l);                                   // pivoted-QR range       :75-76
     return Yfull;
   }
@@ -725,9 +742,16 @@ Buf rangefinder(const Operator& A, const double* Omega, int64_t l, int64_t q) {
   return Yloc;
 }
 
-void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, double* V, double* S) {
+void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, double* V, double* S, const double* Xr) {
   Backend* be = c.be.get();
-  if (!c.comm && V != W && be->svd_tall_fused(W, n, l, n, K_scale, V, n, S)) return;   // :86-88 in one pass (single rank)
+  if (!c.comm && V != W && be->svd_tall_fused(W, n, l, n, K_scale, V, n, S, Xr)) return;   // :86-88 in one pass (single rank)
+  Buf WX;
+  if (Xr != nullptr) {                                       // the fused path declined: form W Xr after all
+    ScopedPhase ph(be, PH_SMALL_GEMM);
+    WX = Buf(be, (size_t)n * l);
+    be->gemm_nn(n, l, l, 1.0, W, n, Xr, l, 0.0, WX.p, n);
+    W = WX.p;
+  }
   Buf R(be, (size_t)l * l), U(be, (size_t)l * l);
   {
     ScopedPhase ph(be, PH_QR);
@@ -771,7 +795,16 @@ void randsvd(const Operator& A, const double* Omega, int64_t K, int64_t p, int64
   Backend* be = c.be.get();
   if (K < 0 || p < 0 || K + p < 1) throw Error(GSI_ERR_ARG, "randsvd: need K >= 0, p >= 0, K + p >= 1");
   const int64_t l = K + p;
-  Buf Q = rangefinder(A, Omega, l, q);                      // Q = rangefinder(A, K+p, q)     :84
+  // One rank, no communicator: the thin Q is only ever used as B = Q'A (:85), so its last tall product is deferred into the
+  // l x l factor of svd(B) -- Q = Q1 X2, W = A'Q1, svd(W X2) -- when CholeskyQR2 applies (the usual case).
+  DeferredQ dq;
+  Buf Q = rangefinder_impl(A, Omega, l, q, c.comm ? nullptr : &dq);   // Q = rangefinder(A, K+p, q)     :84
+  if (dq.Q1 != nullptr) {
+    Buf W(be, (size_t)A.n * l);
+    op_mul_t(A, dq.Q1, dq.ldq, l, W.p, A.n);                // B = Q'*A  (held as A'Q1; X2 follows in svd_tall)   :85
+    svd_tall(c, W.p, A.n, l, K, Z, S, dq.X2.p);             // (), S, V = svd(B); Z = V*Sh    :86-88
+    return;
+  }
   const int G = c.nranks();
   if (c.comm && all_shards_tall(A.n, G, l) && (A.kind != OP_LOWRANK || A.m == A.n)) {   // any communicator, also 1 rank
     int64_t r0n, nloc;

@@ -102,7 +102,8 @@ void cols_to_rows(Context& c, int64_t n, int64_t l, const double* Cloc, double* 
 void eig_nystrom(const Operator& A, const double* Q, int64_t j, double* U, double* Sigma);
 // thin SVD of a replicated tall W (n x l, destroyed): V (n x l, may alias W) = left singular
 // vectors scaled by `scale_K` rule (K < 0: plain V; else V*sqrt(S) for i<K, 0 otherwise)
-void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, double* V, double* S);
+// Xr (may be null): l x l right factor, the SVD is that of W Xr (a thin Q left one product short: Backend::qr_thinQ_deferred)
+void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, double* V, double* S, const double* Xr = nullptr);
 // rangefinder(A; epsilon, r)  RandMatFact.jl:15-48 (dense operator, single rank)
 typedef void (*randn_fn)(void* user, double* buf, int64_t count);
 int64_t rangefinder_adaptive(const Operator& A, randn_fn rn, void* user, double epsilon, int64_t r,

@@ -51,8 +51,41 @@ def phase(prefixes, count_name, per_unit):
             "traffic_over_one_read_plus_write": ((fb + wb) / units / (16.0 * n * l)) if units else None}
 
 res["lu"] = phase(["lu_leaf_kernel", "lu_rankk_kernel", "lu_u12_kernel", "lu2_extract"], "lu_leaf_kernel", l // 8)
+
+def per_kernel(prefixes, units):
+    """HBM bytes per factorization, kernel by kernel (sum over that kernel's launches / factorizations)."""
+    out = {}
+    for name in sorted(set(F) | set(W)):
+        if not any(p in name for p in prefixes):
+            continue
+        fb = sum(2.0 * 1024.0 * v for d, v in F.get(name, []))
+        wb = sum(1024.0 * v for d, v in W.get(name, []))
+        dur = sum(d for d, v in F.get(name, []))
+        out[name.split("::")[-1]] = {"launches_per_factorization": len(F.get(name, [])) / units, "read_bytes": fb / units,
+                                     "write_bytes": wb / units, "bytes": (fb + wb) / units, "ms": dur / units / 1e3,
+                                     "TB/s": (fb + wb) / max(dur, 1e-9) / 1e6}
+    return out
+
+if res["lu"]["factorizations"]:
+    # What the blocking MUST move (DESIGN.md 4.2), in passes over one 8 MB column of the panel: a leaf reads its 8 columns and
+    # the kp = 0, 8, .., 56 finished columns of its 64-column block and writes its 8 (352 per block); the rank-64 update of
+    # block b reads the block's 64 columns of L and reads + writes the t trailing columns (64 + 2 t).
+    col = 8.0 * n
+    nblk = (l + 63) // 64
+    leaf_r = sum(8 + 8 * i for b in range(nblk) for i in range(min(8, (l - 64 * b + 7) // 8)))
+    leaf_w = 8 * ((l + 7) // 8)
+    rk_r = sum(64 + max(l - 64 * (b + 1), 0) for b in range(nblk) if l - 64 * (b + 1) > 0)
+    rk_w = sum(max(l - 64 * (b + 1), 0) for b in range(nblk))
+    res["lu"]["per_kernel"] = per_kernel(["lu_leaf_kernel", "lu_rankk_kernel", "lu_u12_kernel", "lu2_extract"], res["lu"]["factorizations"])
+    res["lu"]["minimum_of_this_blocking"] = {
+        "column_passes": {"leaves_read": leaf_r, "leaves_write": leaf_w, "rank64_read": rk_r, "rank64_write": rk_w},
+        "bytes": {"leaves": (leaf_r + leaf_w) * col, "rank64_updates": (rk_r + rk_w) * col, "total": (leaf_r + leaf_w + rk_r + rk_w) * col},
+        "note": "64-column blocks, 8-column register-resident leaves, left-looking inside a block, one rank-64 update per block"}
+    res["lu"]["traffic_over_minimum_of_this_blocking"] = res["lu"]["hbm_bytes_per_factorization"] / res["lu"]["minimum_of_this_blocking"]["bytes"]["total"]
 # CholeskyQR2: two Gram matrices (sy_kernel: the panel is read once per half) + two triangular products per factorization;
 # the thin-SVD factorization's second product runs in the general kernel and is not counted here
 res["qr"] = phase(["sy_kernel", "sy_reduce_kernel", "tr_kernel", "cq_"], "sy_kernel", 2)
+if res["qr"]["factorizations"]:
+    res["qr"]["per_kernel"] = per_kernel(["sy_kernel", "sy_reduce_kernel", "tr_kernel", "cq_"], res["qr"]["factorizations"])
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res, indent=1))
