@@ -88,7 +88,11 @@ __device__ __forceinline__ void sy_mma_all(sy_double4 (&acc)[CNT], const double 
   (sy_mma<NB, H, W, CNT, I>(acc, F), ...);
 }
 
-template <int NB, int HALF, int W>
+// FAST (round 4): l == 16 NB and every chunk of every slab has its 16 rows (m % 16 == 0) -- the staging loads are a uniform
+// 64-bit base stepped by uniform strides plus a per-thread 32-bit offset computed once, no clamps, no selects, and the
+// fragments alternate between two register sets instead of being copied (F <- Fn): round 3's body issued ~400 VALU
+// instructions per 50 MFMAs, and on gfx950 an fp64 MFMA shares the vector ALU with them (tools/mfma_valu_f64_conflict.hip).
+template <int NB, int HALF, int W, bool FAST>
 __device__ __forceinline__ void sy_body(const double* __restrict__ Y, int64_t ld, int64_t row0, int64_t rend, int l,
                                         double* __restrict__ Pslab, double* smem) {
   using G = SyGeom<NB>;
@@ -96,6 +100,7 @@ __device__ __forceinline__ void sy_body(const double* __restrict__ Y, int64_t ld
   constexpr int CLO = G::col_lo(HALF), NCOL = 16 * NB - CLO;
   constexpr int NLD = (NCOL * SY_KC + SY_THREADS - 1) / SY_THREADS;      // staged elements per thread and chunk
   constexpr int BUF = SY_KC * G::LDW;
+  static_assert(SY_KC == 16, "the k-steps of a chunk are written out below");
   const int tid = threadIdx.x, lane = tid & 63, jl = lane & 15, kk = lane >> 4;
 
   sy_double4 acc[CNT > 0 ? CNT : 1];
@@ -106,27 +111,51 @@ __device__ __forceinline__ void sy_body(const double* __restrict__ Y, int64_t ld
   const int nchunks = nrows > 0 ? (int)((nrows + SY_KC - 1) / SY_KC) : 0;
   double stage[NLD];
   // element e of a chunk: k = e % 16 (fastest: 16 lanes cover the 128 contiguous bytes of one column), column CLO + e / 16
+  const int sk = tid & 15, sc = tid >> 4;
+  const uint32_t y_voff = (uint32_t)(8 * ((int64_t)sk + (int64_t)sc * ld)), y_voff_h = (uint32_t)(8 * ((int64_t)sk + (int64_t)(sc & 15) * ld));
+  const uint32_t s_off = (uint32_t)(sk * G::LDW + CLO + sc), s_off_h = (uint32_t)(sk * G::LDW + CLO + (sc & 15));
+  const int64_t y_step = 8 * 32 * ld;
+  const char* y_next = reinterpret_cast<const char*>(Y + row0 + (int64_t)CLO * ld);      // uniform; one chunk = 128 bytes further
   auto prefetch = [&](int c) {
-    const int64_t k0 = row0 + (int64_t)c * SY_KC;
+    if constexpr (FAST) {
+      (void)c;
+      const char* yb = y_next;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int e = tid + i * SY_THREADS;
-      const int k = e & (SY_KC - 1);
-      int col = CLO + (e >> 4);
-      const bool ok = (col < l) && (k0 + k < rend) && (e < NCOL * SY_KC);
-      if (col >= l) col = l - 1;
-      int64_t r = k0 + k;
-      if (r >= rend) r = rend - 1;
-      const double v = Y[r + (int64_t)col * ld];            // unconditional load of a clamped address
-      stage[i] = ok ? v : 0.0;
+      for (int i = 0; i < NLD; ++i) {
+        if (32 * i < NCOL) {                                // compile time; a last half slot re-loads its lower 16 columns
+          stage[i] = *reinterpret_cast<const double*>(yb + ((32 * i + 32 > NCOL) ? y_voff_h : y_voff));
+          yb += y_step;
+        }
+      }
+      y_next += 8 * SY_KC;
+    } else {
+      const int64_t k0 = row0 + (int64_t)c * SY_KC;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int e = tid + i * SY_THREADS;
+        const int k = e & (SY_KC - 1);
+        int col = CLO + (e >> 4);
+        const bool ok = (col < l) && (k0 + k < rend) && (e < NCOL * SY_KC);
+        if (col >= l) col = l - 1;
+        int64_t r = k0 + k;
+        if (r >= rend) r = rend - 1;
+        const double v = Y[r + (int64_t)col * ld];            // unconditional load of a clamped address
+        stage[i] = ok ? v : 0.0;
+      }
     }
   };
   auto store = [&](int buf) {
     double* s = smem + buf * BUF;
+    if constexpr (FAST) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int e = tid + i * SY_THREADS;
-      if (e < NCOL * SY_KC) s[(e & (SY_KC - 1)) * G::LDW + CLO + (e >> 4)] = stage[i];
+      for (int i = 0; i < NLD; ++i)
+        if (32 * i < NCOL) s[((32 * i + 32 > NCOL) ? s_off_h : s_off) + 32 * i] = stage[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int e = tid + i * SY_THREADS;
+        if (e < NCOL * SY_KC) s[(e & (SY_KC - 1)) * G::LDW + CLO + (e >> 4)] = stage[i];
+      }
     }
   };
   if (nchunks > 0) {
@@ -135,23 +164,24 @@ __device__ __forceinline__ void sy_body(const double* __restrict__ Y, int64_t ld
     if (nchunks > 1) prefetch(1);
   }
   __syncthreads();
-  double F[NB], Fn[NB];
+  double F0[NB], F1[NB];
   using Bs = std::make_integer_sequence<int, NB>;
   using Is = std::make_integer_sequence<int, CNT>;
   for (int c = 0; c < nchunks; ++c) {
     const double* s = smem + (c & 1) * BUF + kk * G::LDW + jl;       // fragment b of step st: s[4 st LDW + 16 b]
-    sy_ld_all<NB, HALF, W>(F, s, Bs{});
-#pragma unroll
-    for (int st = 0; st < SY_KC / 4; ++st) {
-      if (st + 1 < SY_KC / 4) sy_ld_all<NB, HALF, W>(Fn, s + 4 * (st + 1) * G::LDW, Bs{});
-      if constexpr (CNT > 0) sy_mma_all<NB, HALF, W, (CNT > 0 ? CNT : 1)>(acc, F, Is{});
-      if (st == 0 && c + 1 < nchunks) {
-        // the other buffer was last read in the previous iteration, behind its closing barrier
-        store((c + 1) & 1);
-        if (c + 2 < nchunks) prefetch(c + 2);
-      }
-      if (st + 1 < SY_KC / 4) sy_cp_all<NB, HALF, W>(F, Fn, Bs{});
+    sy_ld_all<NB, HALF, W>(F0, s, Bs{});
+    sy_ld_all<NB, HALF, W>(F1, s + 4 * G::LDW, Bs{});
+    if constexpr (CNT > 0) sy_mma_all<NB, HALF, W, (CNT > 0 ? CNT : 1)>(acc, F0, Is{});
+    if (c + 1 < nchunks) {
+      // the other buffer was last read in the previous iteration, behind its closing barrier
+      store((c + 1) & 1);
+      if (c + 2 < nchunks) prefetch(c + 2);
     }
+    sy_ld_all<NB, HALF, W>(F0, s + 8 * G::LDW, Bs{});
+    if constexpr (CNT > 0) sy_mma_all<NB, HALF, W, (CNT > 0 ? CNT : 1)>(acc, F1, Is{});
+    sy_ld_all<NB, HALF, W>(F1, s + 12 * G::LDW, Bs{});
+    if constexpr (CNT > 0) sy_mma_all<NB, HALF, W, (CNT > 0 ? CNT : 1)>(acc, F0, Is{});
+    if constexpr (CNT > 0) sy_mma_all<NB, HALF, W, (CNT > 0 ? CNT : 1)>(acc, F1, Is{});
     __syncthreads();
   }
   // lane holds D[i = kk + 4 reg][j = jl] = sum_k Y[k][16 bj + i] Y[k][16 bi + j]: stored as is, 512 contiguous bytes per register
@@ -161,7 +191,7 @@ __device__ __forceinline__ void sy_body(const double* __restrict__ Y, int64_t ld
     for (int reg = 0; reg < 4; ++reg) Pslab[((int64_t)(T0 + i) * 4 + reg) * 64 + lane] = acc[i][reg];
 }
 
-template <int NB>
+template <int NB, bool FAST>
 __global__ __launch_bounds__(SY_THREADS) void sy_kernel(const double* __restrict__ Y, int64_t ld, int64_t m, int l,
                                                         int64_t rows_per_slab, double* __restrict__ P) {
   extern __shared__ double sy_smem[];
@@ -171,7 +201,7 @@ __global__ __launch_bounds__(SY_THREADS) void sy_kernel(const double* __restrict
   if (rend > m) rend = m;
   double* Pslab = P + (int64_t)slab * SyGeom<NB>::NBLK * 256;
   const int wave = threadIdx.x >> 6;
-#define GSI_SY_CASE(H, Wv) case (H) * SY_WAVES + (Wv): sy_body<NB, H, Wv>(Y, ld, row0, rend, l, Pslab, sy_smem); break;
+#define GSI_SY_CASE(H, Wv) case (H) * SY_WAVES + (Wv): sy_body<NB, H, Wv, FAST>(Y, ld, row0, rend, l, Pslab, sy_smem); break;
   switch (half * SY_WAVES + wave) {
     GSI_SY_CASE(0, 0) GSI_SY_CASE(0, 1) GSI_SY_CASE(0, 2) GSI_SY_CASE(0, 3)
     GSI_SY_CASE(0, 4) GSI_SY_CASE(0, 5) GSI_SY_CASE(0, 6) GSI_SY_CASE(0, 7)
@@ -215,11 +245,18 @@ template <int NB>
 static void sy_launch(hipStream_t st, int64_t l, int64_t m, const double* Y, int64_t ld, double* Gm, int64_t ldg, double* ws) {
   static std::atomic<uint64_t> attr_mask{0};
   const size_t shmem = (size_t)2 * SY_KC * SyGeom<NB>::LDW * sizeof(double);
-  if (first_use_on_this_device(attr_mask))
-    (void)hipFuncSetAttribute((const void*)sy_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (first_use_on_this_device(attr_mask)) {
+    (void)hipFuncSetAttribute((const void*)sy_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void*)sy_kernel<NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  }
   int64_t rps = (m + SY_SLABS - 1) / SY_SLABS;
   rps = (rps + SY_KC - 1) / SY_KC * SY_KC;
-  hipLaunchKernelGGL((sy_kernel<NB>), dim3(2 * SY_SLABS), dim3(SY_THREADS), shmem, st, Y, ld, m, (int)l, rps, ws);
+  // FAST: exact fit of the instantiation, whole chunks everywhere, per-thread offsets within 32 bits
+  static const bool no_fast = (getenv("GSI_SY_NO_FAST") != nullptr);
+  if (!no_fast && l == 16 * NB && m % SY_KC == 0 && 31 * ld + 16 < ((int64_t)1 << 29))
+    hipLaunchKernelGGL((sy_kernel<NB, true>), dim3(2 * SY_SLABS), dim3(SY_THREADS), shmem, st, Y, ld, m, (int)l, rps, ws);
+  else
+    hipLaunchKernelGGL((sy_kernel<NB, false>), dim3(2 * SY_SLABS), dim3(SY_THREADS), shmem, st, Y, ld, m, (int)l, rps, ws);
   hipLaunchKernelGGL((sy_reduce_kernel<NB>), dim3(SyGeom<NB>::NBLK), dim3(256), 0, st, ws, SY_SLABS, (int)l, Gm, ldg);
 }
 
@@ -250,61 +287,117 @@ constexpr int TR_ROWS = 128;
 constexpr int TR_LDA = TR_ROWS + 1;
 constexpr int TR_G = 5;            // X fragments per group
 
-template <int NB>
+// FAST: all 128 rows of the block exist and l == 16 NB -- no clamps, no predicates, and every address is a
+// uniform 64-bit base (SGPRs) plus a per-thread 32-bit byte offset that is computed ONCE: round 3's staging code spent
+// ~25 integer VALU instructions per load on 64-bit index arithmetic and clamps (5179 VALU for 840 MFMAs in the <20>
+// instantiation), and on gfx950 nothing of that hides behind the fp64 MFMAs -- v_mfma_f64_16x16x4_f64 holds the SIMD's
+// vector ALU for all of its 64 cycles, also against the partner wave (tools/mfma_valu_f64_conflict.hip: both = sum).
+// It also loaded all 10 X slots of every chunk although chunk kb only has columns >= 16 kb: skipped now.
+template <int NB, bool FAST>
 __global__ __launch_bounds__(SY_THREADS) void tr_kernel(const double* __restrict__ A, int64_t lda, int64_t m,
                                                         const double* __restrict__ X, int64_t ldx, int l,
-                                                        double* __restrict__ C, int64_t ldc) {
+                                                        double* __restrict__ C, int64_t ldc, int64_t rb0) {
   constexpr int LDW = 16 * NB + 1;
   constexpr int ABUF = SY_KC * TR_LDA, XBUF = SY_KC * LDW, BUF = ABUF + XBUF;
   constexpr int NLA = TR_ROWS * SY_KC / SY_THREADS;                      // 4
   constexpr int NLX = (16 * NB * SY_KC + SY_THREADS - 1) / SY_THREADS;   // <= 10
   extern __shared__ double sy_smem[];
   const int tid = threadIdx.x, lane = tid & 63, jl = lane & 15, kk = lane >> 4, r = tid >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * TR_ROWS;
+  const int64_t r0 = (rb0 + (int64_t)blockIdx.x) * TR_ROWS;
   const int nkb = (l + 15) >> 4;
 
   sy_double4 acc[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) acc[b] = (sy_double4){0.0, 0.0, 0.0, 0.0};
   double sa[NLA], sx[NLX];
-  auto prefetch = [&](int kb) {
-    const int k0 = 16 * kb;
+  // per-thread pieces of the staging addresses, fixed for the kernel: A element (row = tid % 128, k = tid / 128 + 4 i + 16 kb),
+  // X element (k = tid % 16 + 16 kb, column = tid / 16 + 32 i + 16 kb)
+  const int arow = tid & (TR_ROWS - 1), akq = tid >> 7, xk = tid & 15, xc = tid >> 4;
+  const uint32_t a_voff = (uint32_t)(8 * ((int64_t)arow + (int64_t)akq * lda));      // FAST: fits (launcher checks 3 lda + 128 < 2^29)
+  const uint32_t x_voff = (uint32_t)(8 * ((int64_t)xk + (int64_t)xc * ldx));
+  const char* const Ab = reinterpret_cast<const char*>(A + r0);
+  const char* const Xb = reinterpret_cast<const char*>(X);
+  const uint32_t as_off = (uint32_t)(akq * TR_LDA + arow), xs_off = (uint32_t)(xk * LDW + xc);
+  // FAST also means l == 16 NB exactly (the launcher checks): with the chunk index a template argument, which X slots a
+  // chunk has (32 columns each; the last one of an odd chunk count is half a slot) is known at compile time -- no branch, no
+  // select.  The half slot's upper 16 x 16 lanes re-load and re-store the lower half's elements (same address, same value).
+  const uint32_t x_voff_h = (uint32_t)(8 * ((int64_t)xk + (int64_t)(xc & 15) * ldx));
+  const uint32_t xs_off_h = (uint32_t)(xk * LDW + (xc & 15));
+  const int64_t a_step = 8 * 4 * lda, x_step = 8 * 32 * ldx;              // uniform byte strides between the slots of a chunk
+  const char* a_next = Ab;                                                // chunk kb: A + r0 + 16 kb lda   (prefetch runs in order)
+  const char* x_next = Xb;                                                //           X(16 kb, 16 kb)
+  auto prefetch = [&](auto KBc) {
+    constexpr int kb = decltype(KBc)::value;
+    constexpr int k0 = 16 * kb;
+    if constexpr (FAST) {
+      constexpr int ncol = 16 * NB - k0;                                   // columns k0 .. l - 1
+      const char* ab = a_next;
 #pragma unroll
-    for (int i = 0; i < NLA; ++i) {                  // A: rows fastest (512 contiguous bytes per wave)
-      const int e = tid + i * SY_THREADS;
-      const int row = e & (TR_ROWS - 1), k = k0 + (e >> 7);
-      const bool ok = (r0 + row < m) && (k < l);
-      const int64_t rr = (r0 + row < m) ? r0 + row : m - 1;
-      const double v = A[rr + (int64_t)(k < l ? k : l - 1) * lda];
-      sa[i] = ok ? v : 0.0;
-    }
+      for (int i = 0; i < NLA; ++i) { sa[i] = *reinterpret_cast<const double*>(ab + a_voff); ab += a_step; }
+      const char* xb = x_next;
 #pragma unroll
-    for (int i = 0; i < NLX; ++i) {                  // X: rows k0..k0+15 of the columns right of the diagonal block
-      const int e = tid + i * SY_THREADS;
-      const int k = k0 + (e & 15), c = k0 + (e >> 4);
-      const bool ok = (k < l) && (c < l);
-      const double v = X[(k < l ? k : l - 1) + (int64_t)(c < l ? c : l - 1) * ldx];
-      sx[i] = ok ? v : 0.0;
+      for (int i = 0; i < NLX; ++i) {
+        if constexpr (true) {
+          if (32 * i < ncol) {                                            // compile time
+            const bool half = (32 * i + 32 > ncol);
+            sx[i] = *reinterpret_cast<const double*>(xb + (half ? x_voff_h : x_voff));
+            xb += x_step;
+          }
+        }
+      }
+      a_next += 8 * 16 * lda;
+      x_next += 8 * 16 * (1 + ldx);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) {                  // A: rows fastest (512 contiguous bytes per wave)
+        const int e = tid + i * SY_THREADS;
+        const int row = e & (TR_ROWS - 1), k = k0 + (e >> 7);
+        const bool ok = (r0 + row < m) && (k < l);
+        const int64_t rr = (r0 + row < m) ? r0 + row : m - 1;
+        const double v = A[rr + (int64_t)(k < l ? k : l - 1) * lda];
+        sa[i] = ok ? v : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < NLX; ++i) {                  // X: rows k0..k0+15 of the columns right of the diagonal block
+        const int e = tid + i * SY_THREADS;
+        const int k = k0 + (e & 15), c = k0 + (e >> 4);
+        const bool ok = (k < l) && (c < l);
+        const double v = X[(k < l ? k : l - 1) + (int64_t)(c < l ? c : l - 1) * ldx];
+        sx[i] = ok ? v : 0.0;
+      }
     }
   };
-  auto store = [&](int buf, int kb) {
+  auto store = [&](auto KBc) {
+    constexpr int kb = decltype(KBc)::value;
+    constexpr int buf = kb & 1;
     double* as = sy_smem + buf * BUF;
     double* xs = as + ABUF;
+    if constexpr (FAST) {
+      constexpr int ncol = 16 * NB - 16 * kb;
 #pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-      const int e = tid + i * SY_THREADS;
-      as[(e >> 7) * TR_LDA + (e & (TR_ROWS - 1))] = sa[i];
-    }
+      for (int i = 0; i < NLA; ++i) as[as_off + 4 * i * TR_LDA] = sa[i];
 #pragma unroll
-    for (int i = 0; i < NLX; ++i) {
-      const int e = tid + i * SY_THREADS;
-      const int c = 16 * kb + (e >> 4);
-      if (c < 16 * NB) xs[(e & 15) * LDW + c] = sx[i];
+      for (int i = 0; i < NLX; ++i)
+        if (32 * i < ncol) xs[((32 * i + 32 > ncol) ? xs_off_h : xs_off) + 16 * kb + 32 * i] = sx[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) {
+        const int e = tid + i * SY_THREADS;
+        as[(e >> 7) * TR_LDA + (e & (TR_ROWS - 1))] = sa[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NLX; ++i) {
+        const int e = tid + i * SY_THREADS;
+        const int c = 16 * kb + (e >> 4);
+        if (c < 16 * NB) xs[(e & 15) * LDW + c] = sx[i];
+      }
     }
   };
-  prefetch(0);
-  store(0, 0);
-  if (nkb > 1) prefetch(1);
+  using KB0 = std::integral_constant<int, 0>;
+  using KB1 = std::integral_constant<int, 1>;
+  prefetch(KB0{});
+  store(KB0{});
+  if (nkb > 1) prefetch(KB1{});
   __syncthreads();
   // The chunk index is a template argument: which column blocks a chunk touches (bb >= kb) is then known at compile
   // time -- as uniform branches around every load and MFMA the same loop ran no faster than the general kernel.
@@ -342,8 +435,8 @@ __global__ __launch_bounds__(SY_THREADS) void tr_kernel(const double* __restrict
       }
       if (st == ((r & 4) ? 2 : 0) && kb + 1 < nkb) {      // waves r and r + 4 share a SIMD: staging chores half a chunk apart,
         __builtin_amdgcn_s_setprio(0);                     // at low priority (one of the two is always in an MFMA stretch)
-        store((kb + 1) & 1, kb + 1);
-        if (kb + 2 < nkb) prefetch(kb + 2);
+        store(std::integral_constant<int, kb + 1>{});
+        if (kb + 2 < nkb) prefetch(std::integral_constant<int, kb + 2>{});
         __builtin_amdgcn_s_setprio(1);
       }
     }
@@ -352,13 +445,14 @@ __global__ __launch_bounds__(SY_THREADS) void tr_kernel(const double* __restrict
   sy_for_each(chunk, std::make_integer_sequence<int, NB>{});
   // lane holds D[i = kk + 4 reg][j = jl] = C[r0 + 16 r + jl][16 b + kk + 4 reg]
   const int64_t row = r0 + 16 * r + jl;
-  if (row < m) {
+  if (FAST || row < m) {
+    double* cp = C + row;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int col = 16 * b + kk + 4 * reg;
-        if (col < l) C[row + (int64_t)col * ldc] = acc[b][reg];
+        if (col < l) cp[(int64_t)col * ldc] = acc[b][reg];
       }
   }
 }
@@ -368,10 +462,21 @@ static void tr_launch(hipStream_t st, int64_t m, int64_t l, const double* A, int
                       double* C, int64_t ldc) {
   static std::atomic<uint64_t> attr_mask{0};
   const size_t shmem = (size_t)2 * SY_KC * (TR_LDA + 16 * NB + 1) * sizeof(double);
-  if (first_use_on_this_device(attr_mask))
-    (void)hipFuncSetAttribute((const void*)tr_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  hipLaunchKernelGGL((tr_kernel<NB>), dim3((unsigned)((m + TR_ROWS - 1) / TR_ROWS)), dim3(SY_THREADS), shmem, st, A, lda, m, X, ldx,
-                     (int)l, C, ldc);
+  if (first_use_on_this_device(attr_mask)) {
+    (void)hipFuncSetAttribute((const void*)tr_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void*)tr_kernel<NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  }
+  // whole row blocks through the FAST instantiation (no clamps, 32-bit per-thread offsets); the last partial block, odd
+  // sketch widths and leading dimensions beyond the 32-bit offsets through the general one
+  static const bool no_fast = (getenv("GSI_TR_NO_FAST") != nullptr);
+  const bool fast_ok = !no_fast && (l == 16 * NB) && (3 * lda + TR_ROWS < ((int64_t)1 << 29)) && (31 * ldx + 16 < ((int64_t)1 << 29));
+  const int64_t nfull = fast_ok ? m / TR_ROWS : 0, nblk = (m + TR_ROWS - 1) / TR_ROWS;
+  if (nfull > 0)
+    hipLaunchKernelGGL((tr_kernel<NB, true>), dim3((unsigned)nfull), dim3(SY_THREADS), shmem, st, A, lda, m, X, ldx, (int)l, C, ldc,
+                       (int64_t)0);
+  if (nblk > nfull)
+    hipLaunchKernelGGL((tr_kernel<NB, false>), dim3((unsigned)(nblk - nfull)), dim3(SY_THREADS), shmem, st, A, lda, m, X, ldx, (int)l, C,
+                       ldc, nfull);
 }
 
 // C = A X for square upper-triangular X (entries below the diagonal must be zero: the diagonal blocks are read whole).
