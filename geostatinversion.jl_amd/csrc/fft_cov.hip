@@ -57,10 +57,12 @@ constexpr int FFT_MAX_TILE = 8192;   // points of a tile (T lines): 16 per threa
 // elements.  Every pass stays in place.  The padding of the last axis is still neither stored nor read.
 struct FftPass {
   int Ma, log2Ma, nin, nout, T, log2T, lstride, log2es;
-  int64_t estride, R1, S1, R2, S2;
+  // element offsets within one column pair's array are 32-bit (the launcher checks Mtot < 2^31): 64-bit index arithmetic --
+  // and above all the 64-bit DIVISION of off() per thread and item -- cost the contiguous passes registers and VALU time
+  uint32_t estride, R1, S1, R2, S2;
   int lb, log2M0;           // lb = 0: natural layout
   int kind;                 // strided passes: 0 natural, 1 blocked / lines along axis 1, 2 blocked / lines along axis 2
-  int64_t BK0, OS, ks;      // block stride of k0 >> lb; stride of the tile's other index; stride between consecutive k of a line
+  uint32_t BK0, OS, ks;     // block stride of k0 >> lb; stride of the tile's other index; stride between consecutive k of a line
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt -- every global load and store in
@@ -261,10 +263,21 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
   }
   lds_barrier();
   const int nouter = (int)(ps.R1 * ps.R2);
+  // contiguous-axis passes: W position of slot s of this thread = a0_tb + s a0_ss (natural: jt + s tpl; blocked, tpl a multiple of
+  // Tb: (jt >> lb) BK0 + (jt & (Tb - 1)) + s (tpl >> lb) BK0)
+  const uint32_t a0_tb = (uint32_t)(f.jt >> ps.lb) * ps.BK0 + (uint32_t)(f.jt & ((1 << ps.lb) - 1));
+  const uint32_t a0_ss = (uint32_t)(f.tpl >> ps.lb) * ps.BK0;
+  // strided passes: W offset of element i of this thread = s_tofs + i s_kstep (line tid % T, position tid / T + i nth / T)
+  const uint32_t s_tofs = (uint32_t)(tid & (T - 1)) + (uint32_t)(tid >> ps.log2T) * ps.ks;
+  const uint32_t s_kstep = (uint32_t)(nth >> ps.log2T) * ps.ks;
   const int tiles_per_outer = AXIS0 ? 1 : (int)(ps.estride >> ps.log2T);
-  auto off = [&](int64_t o) -> int64_t { return (o % ps.R1) * ps.S1 + (o / ps.R1) * ps.S2; };
+  auto off = [&](uint32_t o) -> uint32_t {
+    if (ps.R2 == 1) return o * ps.S1;                     // uniform: one outer axis (2-D grids), no division at all
+    const uint32_t q = o / ps.R1;
+    return (o - q * ps.R1) * ps.S1 + q * ps.S2;
+  };
 
-  struct Item { int64_t off0, lamoff; int pair, o0, i0, nlines; };
+  struct Item { uint32_t off0, lamoff; int pair, o0, i0, nlines; };
   // item w of this workgroup's sequence; workgroups of one XCD walk neighbouring tiles
   const int G = gridDim.x;
   const int bperm = ((G & 7) == 0) ? ((int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
@@ -283,11 +296,11 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
         it.off0 = off(it.o0) + it.i0;
       } else {                                   // blocked: (k0 >> lb) BK0 + (other index) OS + (k0 & (Tb - 1))
         const int k0 = (ps.kind == 1) ? it.i0 : (it.i0 & ((1 << ps.log2M0) - 1));
-        const int64_t other = (ps.kind == 1) ? (int64_t)it.o0 : (int64_t)(it.i0 >> ps.log2M0);
-        it.off0 = (int64_t)(k0 >> ps.lb) * ps.BK0 + other * ps.OS + (k0 & ((1 << ps.lb) - 1));
+        const uint32_t other = (ps.kind == 1) ? (uint32_t)it.o0 : (uint32_t)(it.i0 >> ps.log2M0);
+        it.off0 = (uint32_t)(k0 >> ps.lb) * ps.BK0 + other * ps.OS + (uint32_t)(k0 & ((1 << ps.lb) - 1));
       }
       it.nlines = T;
-      it.lamoff = (int64_t)it.i0 * Ma;           // the spectrum of the last axis is stored line by line (transposed)
+      it.lamoff = (uint32_t)it.i0 * (uint32_t)Ma;      // the spectrum of the last axis is stored line by line (transposed)
     }
     return it;
   };
@@ -296,26 +309,29 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
   // between them -- serial HBM round trips.
   auto fetch = [&](const Item& it, double2 (&pre)[NPRE]) {
     if (AXIS0) {
-      const int64_t o = it.o0 + (jl < it.nlines ? jl : it.nlines - 1);
-      const int64_t lo = LOADX ? N0 * o : off(o);
+      const uint32_t o = (uint32_t)(it.o0 + (jl < it.nlines ? jl : it.nlines - 1));
+      const int64_t lo = LOADX ? N0 * (int64_t)o : (int64_t)off(o);
       const int64_t ca = col0 + 2 * it.pair, cb = (ca + 1 < l) ? ca + 1 : ca;
       const double2* Wb = W + (int64_t)it.pair * Mtot;
 #pragma unroll
       for (int r = 0; r < NPRE; ++r) {
         const int pos = f.jt + r * f.tpl;
-        const int pc = (pos < ps.nin ? pos : ps.nin - 1);
-        if (LOADX) { const int64_t i = lo + pc; pre[r] = make_double2(X[i + ca * ldx], X[i + cb * ldx]); }
-        else pre[r] = ld2(&Wb[lo + (int64_t)(pc >> ps.lb) * ps.BK0 + (pc & ((1 << ps.lb) - 1))]);      // natural: lb = 0, BK0 = 1
+        if (LOADX) {
+          const int64_t i = lo + (pos < ps.nin ? pos : ps.nin - 1);
+          pre[r] = make_double2(X[i + ca * ldx], X[i + cb * ldx]);
+        } else {
+          // an inverse pass (nin = Ma: every position exists).  Slot r of a thread sits r slot-strides behind its first
+          // point in BOTH layouts (blocked: tpl is a multiple of Tb): thread base + r * uniform stride, as cheap as natural
+          pre[r] = ld2(&Wb[(uint32_t)lo + a0_tb + (uint32_t)r * a0_ss]);
+        }
       }
     } else {
+      // element i of this thread: line j = tid % T, position k = tid / T + i (nth / T) -- a per-thread constant offset plus
+      // a uniform stride, no multiply and no clamp per element (a position past nin reads allocated words of W that the
+      // first gather replaces by zeros: forward lines are at most half full, see the layout bounds in fft_pass)
       const double2* Wb = W + (int64_t)it.pair * Mtot + it.off0;
-      const int t0 = opaque(tid);
 #pragma unroll
-      for (int i = 0; i < NPRE; ++i) {
-        const int e = t0 + i * nth;
-        const int j = e & (T - 1), k = e >> ps.log2T;
-        pre[i] = ld2(&Wb[j + (int64_t)(k < ps.nin ? k : ps.nin - 1) * ps.ks]);
-      }
+      for (int i = 0; i < NPRE; ++i) pre[i] = ld2(&Wb[s_tofs + (uint32_t)i * s_kstep]);
     }
   };
 
@@ -377,7 +393,7 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
     // ---- results
     if (AXIS0) {
       if (f.act) {
-        const int64_t o = it.o0 + jl;
+        const uint32_t o = (uint32_t)(it.o0 + jl);
         const int64_t ca = col0 + 2 * it.pair, cb = ca + 1;
         double2* Wb = W + (int64_t)it.pair * Mtot + off(o);
 #pragma unroll
@@ -385,11 +401,11 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
           const int pos = f.jt + s * f.tpl;
           if (pos < ps.nout) {
             if (STOREY) {
-              const int64_t i = pos + N0 * o;
+              const int64_t i = pos + N0 * (int64_t)o;
               Y[i + ca * ldy] = v[s].x;
               if (cb < l) Y[i + cb * ldy] = v[s].y;
             } else {
-              st2(&Wb[(int64_t)(pos >> ps.lb) * ps.BK0 + (pos & ((1 << ps.lb) - 1))], v[s]);
+              st2(&Wb[a0_tb + (uint32_t)s * a0_ss], v[s]);
             }
           }
         }
@@ -401,7 +417,7 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
       for (int i = 0; i < NOUT; ++i) {
         const int e = t0 + i * nth;
         const int j = e & (T - 1), k = e >> ps.log2T;
-        if (k < ps.nout) st2(&Wb[j + (int64_t)k * ps.ks], ld2(&buf[j * ps.lstride + swz(k)]));
+        if (k < ps.nout) st2(&Wb[s_tofs + (uint32_t)i * s_kstep], ld2(&buf[j * ps.lstride + swz(k)]));
       }
       lds_barrier();      // the lines are free for the next item (the stores above are not waited for)
     }
@@ -569,32 +585,35 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
   ps.log2Ma = ilog2(ps.Ma);
   ps.nin = inverse ? ps.Ma : (int)N[axis];
   ps.nout = (inverse || fused) ? (int)N[axis] : ps.Ma;
+  if (Mtot >= ((int64_t)1 << 31)) throw std::runtime_error("fft_pass: embedding grids of 2^31 points or more are not supported");
   const int64_t stride[3] = {1, M[0], M[0] * M[1]};
-  ps.estride = stride[axis];
+  ps.estride = (uint32_t)stride[axis];
   ps.log2es = ilog2(ps.estride);
   ps.R1 = 1; ps.S1 = 0; ps.R2 = 1; ps.S2 = 0;
-  if (axis == 0) { ps.R1 = N[1]; ps.S1 = stride[1]; ps.R2 = N[2]; ps.S2 = stride[2]; }
-  else if (axis == 1) { ps.R1 = N[2]; ps.S1 = stride[2]; }
-  const int64_t nouter = ps.R1 * ps.R2;
+  if (axis == 0) { ps.R1 = (uint32_t)N[1]; ps.S1 = (uint32_t)stride[1]; ps.R2 = (uint32_t)N[2]; ps.S2 = (uint32_t)stride[2]; }
+  else if (axis == 1) { ps.R1 = (uint32_t)N[2]; ps.S1 = (uint32_t)stride[2]; }
+  const int64_t nouter = (int64_t)ps.R1 * ps.R2;
   // ---- the layout of W (see FftPass): blocked unless switched off or the grid has no strided pass / a short axis 0
   const int d = (M[2] > 1) ? 3 : ((M[1] > 1) ? 2 : 1);
   static const int tb_env = getenv("GSI_FFT_TB") ? atoi(getenv("GSI_FFT_TB")) : 16;
   int lb = 0;
-  if (d >= 2 && tb_env >= 4 && M[0] >= 64) { while ((2 << lb) <= tb_env && (2 << lb) <= 16) ++lb; }
+  if (d >= 2 && tb_env >= 4 && M[0] >= 256) {      // 16 points per thread on the contiguous axis: tpl = M0 / 16 must be a multiple of Tb
+    while ((2 << lb) <= tb_env && (2 << lb) <= 64 && (2 << lb) <= M[0] / 16) ++lb;
+  }
   const int Tb = 1 << lb;
   ps.lb = lb; ps.log2M0 = ilog2(M[0]); ps.kind = 0; ps.BK0 = 1; ps.OS = 0; ps.ks = ps.estride;
   if (lb > 0) {
     // element (k0, k1, k2) at ((k0 >> lb) D1 + k1) (N2 Tb) + k2 Tb + (k0 & (Tb - 1)); 2-D: D1 = 1, "k2" = k1, N2 -> N1
     const int64_t Nl = (d == 3) ? N[2] : N[1], D1 = (d == 3) ? M[1] : 1;
-    ps.BK0 = D1 * Nl * Tb;
+    ps.BK0 = (uint32_t)(D1 * Nl * Tb);
     if (axis == 0) {                       // lines o = (k1, k2) restricted to the grid: off(o) = k1 S1 + k2 S2
-      if (d == 3) { ps.S1 = Nl * Tb; ps.S2 = Tb; } else { ps.S1 = Tb; ps.S2 = 0; }
+      if (d == 3) { ps.S1 = (uint32_t)(Nl * Tb); ps.S2 = (uint32_t)Tb; } else { ps.S1 = (uint32_t)Tb; ps.S2 = 0; }
     } else if (axis == 1 && d == 3) {      // tile = T neighbours in k0 at fixed k2 = o; k = k1
-      ps.kind = 1; ps.OS = Tb; ps.ks = Nl * Tb;
+      ps.kind = 1; ps.OS = (uint32_t)Tb; ps.ks = (uint32_t)(Nl * Tb);
     } else if (axis == 1) {                // 2-D: the last axis; k = k1, no outer index
-      ps.kind = 1; ps.OS = 0; ps.ks = Tb;
+      ps.kind = 1; ps.OS = 0; ps.ks = (uint32_t)Tb;
     } else {                               // axis 2: tile = T neighbours in k0 at fixed k1 = inner / M0; k = k2
-      ps.kind = 2; ps.OS = Nl * Tb; ps.ks = Tb;
+      ps.kind = 2; ps.OS = (uint32_t)(Nl * Tb); ps.ks = (uint32_t)Tb;
     }
   }
   // lines per workgroup, within 8192 points (16 per thread, 512 threads, 128 KB).  Contiguous lines need no neighbours:
@@ -625,7 +644,7 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
     if (want < floor_t) want = floor_t;
     if (want > 16) want = 16;
     if (want > tmax) want = tmax;
-    if (want > ps.estride) want = (int)ps.estride;   // estride is a power of two >= 4
+    if (want > (int64_t)ps.estride) want = (int)ps.estride;   // estride is a power of two >= 4
     if (lb > 0 && want > Tb) want = Tb;              // a tile never leaves its block of Tb lines
     if (lb > 0 && want > M[0]) want = (int)M[0];
     T = 1; ps.log2T = 0;
