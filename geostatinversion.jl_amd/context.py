@@ -91,13 +91,13 @@ class Context:
         """Which path ran under the communicator (`gsi_ctx_path_info`): the form of the panel LUs (and how many ran in each
         form since the last phase_reset), the self-test mask of the in-kernel pivot exchange, collectives entered since the
         last phase_reset, the ranks the communicator joined, LU time-outs seen / hidden by a transparent re-run."""
-        n = 12
+        n = 13
         out = (C.c_int64 * n)()
         L.check(self.lib.gsi_ctx_path_info(self.h, out, n), self.lib)
         forms = {self.LU_FORMS[f]: int(out[6 + f]) for f in range(1, 6) if out[6 + f]}
         return {"lu_form": self.LU_FORMS[out[0]] if 0 <= out[0] < 6 else int(out[0]), "lu_forms_run": forms,
                 "lu_selftest_mask": int(out[1]), "collectives": int(out[2]), "n_ranks_seen": int(out[3]),
-                "lu_timeouts": int(out[4]), "lu_timeouts_recovered": int(out[5])}
+                "lu_timeouts": int(out[4]), "lu_timeouts_recovered": int(out[5]), "svd_sweep_cap_hits": int(out[12])}
 
     def release_cache(self):
         """Return cached device memory (released panels, idle workspaces) to the driver (`gsi_ctx_release_cache`)."""

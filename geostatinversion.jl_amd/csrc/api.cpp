@@ -194,8 +194,8 @@ int gsi_ctx_path_info(gsi_ctx* ctx, int64_t* out, int64_t n_out) {
     v[GSI_PATH_RANKS_SEEN] = c.ranks_seen;
     v[GSI_PATH_LU_TIMEOUTS] = c.be->lu_timeouts();
     v[GSI_PATH_LU_TIMEOUTS_RECOVERED] = c.lu_timeouts_recovered;
-    for (int f = 0; f < (int)Context::LU_FORMS && GSI_PATH_LU_FORM_COUNTS + f < GSI_PATH_INFO_COUNT; ++f)
-      v[GSI_PATH_LU_FORM_COUNTS + f] = c.lu_form_count[f];
+    for (int f = 0; f < (int)Context::LU_FORMS; ++f) v[GSI_PATH_LU_FORM_COUNTS + f] = c.lu_form_count[f];
+    v[GSI_PATH_SVD_CAP_HITS] = c.be->svd_cap_hits();
     for (int64_t i = 0; i < n_out; ++i) out[i] = i < GSI_PATH_INFO_COUNT ? v[i] : 0;
   });
 }

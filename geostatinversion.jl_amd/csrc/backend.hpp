@@ -227,6 +227,8 @@ class Backend {
   virtual void counters(int64_t* out4) { out4[0] = out4[1] = out4[2] = out4[3] = 0; }
   // [0] LU pivot-exchange time-outs seen by this backend since creation (take_error mapped info = -1)
   virtual int64_t lu_timeouts() { return 0; }
+  // small SVDs that used up their sweep budget with rotatable column pairs left (the result is still the best available)
+  virtual int64_t svd_cap_hits() { return 0; }
   // how many ranks of the context's communicator run on this backend's device (Comm::ranks_on_my_device, told once the
   // communicator exists): kernels that need all their workgroups resident at once must not assume the whole chip
   virtual void set_ranks_sharing_device(int n) { (void)n; }

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
   // strided passes: W offset of element i of this thread = s_tofs + i s_kstep (line tid % T, position tid / T + i nth / T)
   const uint32_t s_tofs = (uint32_t)(tid & (T - 1)) + (uint32_t)(tid >> ps.log2T) * ps.ks;
   const uint32_t s_kstep = (uint32_t)(nth >> ps.log2T) * ps.ks;
+  const bool s_lin = (nth >> ps.log2T) * NPRE <= Ma;       // every slot of every thread lies inside its line (positions < Ma)
   const int tiles_per_outer = AXIS0 ? 1 : (int)(ps.estride >> ps.log2T);
   auto off = [&](uint32_t o) -> uint32_t {
     if (ps.R2 == 1) return o * ps.S1;                     // uniform: one outer axis (2-D grids), no division at all
@@ -330,8 +331,18 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
       // a uniform stride, no multiply and no clamp per element (a position past nin reads allocated words of W that the
       // first gather replaces by zeros: forward lines are at most half full, see the layout bounds in fft_pass)
       const double2* Wb = W + (int64_t)it.pair * Mtot + it.off0;
+      if (s_lin) {
 #pragma unroll
-      for (int i = 0; i < NPRE; ++i) pre[i] = ld2(&Wb[s_tofs + (uint32_t)i * s_kstep]);
+        for (int i = 0; i < NPRE; ++i) pre[i] = ld2(&Wb[s_tofs + (uint32_t)i * s_kstep]);
+      } else {                                   // short lines: more thread slots than the tile has elements -- clamp (uniform branch)
+        const int t0 = opaque(tid);
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+          const int e = t0 + i * nth;
+          const int j = e & (T - 1), k = e >> ps.log2T;
+          pre[i] = ld2(&Wb[(uint32_t)j + (uint32_t)(k < ps.nin ? k : ps.nin - 1) * ps.ks]);
+        }
+      }
     }
   };
 

@@ -574,7 +574,17 @@ size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K) {
 }
 // the symmetric product C = A'A (l x l, K = m): fewer active tiles, so possibly more splits; bound by the chooser's cap
 size_t gemm_syrk_workspace_doubles(int64_t l, int64_t m) {
-  return (m >= 8 * BK) ? (size_t)256 * (size_t)l * (size_t)l : 0;
+  if (m < 8 * BK) return 0;
+  // the split the launcher will actually choose for the tiles that touch the upper triangle (256 l^2 regardless
+  // of the split was 8 GB at l = 2000)
+  const int64_t tiles = (l + 15) / 16, nchunks = (tiles + NTMAX - 1) / NTMAX, nt = (tiles + nchunks - 1) / nchunks;
+  const int64_t rowblocks = (l + BMT - 1) / BMT;
+  int64_t active = 0;
+  for (int64_t rb = 0; rb < rowblocks; ++rb)
+    for (int64_t cb = 0; cb < nchunks; ++cb)
+      if (cb >= (rb * BMT) / (nt * 16)) ++active;
+  const int ns = gemm_choose_split(active, m);
+  return ns > 1 ? (size_t)ns * (size_t)l * (size_t)l : 0;
 }
 
 // number of 16-column tiles per workgroup pass.  (128-column chunks for the symmetric product, so that chunk and

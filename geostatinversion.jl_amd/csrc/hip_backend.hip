@@ -889,7 +889,9 @@ class HipBackend : public Backend {
     w.norms = (double*)ws_svd_.p;
     w.pairs = (int32_t*)((char*)ws_svd_.p + sizeof(double) * (l + 8) + 64);
     w.rotcount = flags_ + 8;
-    last_svd_sweeps_ = hipk::svd_small(st_, G, l, U, S, w);
+    const int sw = hipk::svd_small(st_, G, l, U, S, w);
+    last_svd_sweeps_ = sw < 0 ? -sw : sw;
+    if (sw < 0) ++n_svd_cap_hits_;          // 40 sweeps and rotatable pairs left (factors graded over > 1e10): gsi_ctx_path_info reports it
     check_launch("svd_small");
   }
   void chol_upper(double* B, int64_t j) override {
@@ -1116,6 +1118,7 @@ class HipBackend : public Backend {
     out4[0] = n_cholqr_; out4[1] = n_householder_; out4[2] = last_svd_sweeps_; out4[3] = n_scholqr3_;
   }
   int64_t lu_timeouts() override { return n_lu_timeouts_; }
+  int64_t svd_cap_hits() override { return n_svd_cap_hits_; }
   void set_ranks_sharing_device(int n) override { ranks_sharing_device_ = n; }
   int device() const { return device_; }
 
@@ -1216,6 +1219,7 @@ class HipBackend : public Backend {
   double acc_ms_[PH_COUNT] = {0};
   int64_t acc_n_[PH_COUNT] = {0};
   int last_svd_sweeps_ = 0;
+  int64_t n_svd_cap_hits_ = 0;
   int64_t n_cholqr_ = 0, n_householder_ = 0, n_scholqr3_ = 0;
   std::map<std::pair<int64_t, bool>, int> skip_tier1_by_height_;
   std::map<int, int> lu2_resident_;   // (bs, rpt) -> resident workgroups per CU of that leaf instantiation

@@ -341,6 +341,7 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
       int32_t* d_flags = w.pairs;
       int32_t* d_sched = w.pairs + npairs;
       bool sparse = false;
+      bool converged = false;
       for (; sweeps < max_sweeps;) {
         if (!sparse) {
           for (int r = 0; r < nblk - 1; ++r)
@@ -407,14 +408,15 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
         hipStreamSynchronize(st);
         int active = 0;
         for (int32_t f : flags) active += f ? 1 : 0;
-        if (active == 0) break;
+        if (active == 0) { converged = true; break; }
         sparse = (2 * active <= npairs);     // at least half of the pairs clean: a schedule beats the full tournament
       }
       hipLaunchKernelGGL(jacobi_norms_kernel, dim3((l + 3) / 4), dim3(256), 0, st, G, l, w.norms);
       hipLaunchKernelGGL(jacobi_finish_kernel, dim3(l), dim3(64), 0, st, G, l, w.norms, U, S);
-      return sweeps;
+      return converged ? sweeps : -sweeps;   // negative: the sweep cap was reached with rotatable pairs left (the caller counts it)
     }
   }
+  bool plain_converged = false;
   for (; sweeps < max_sweeps; ++sweeps) {
     hipMemsetAsync(w.rotcount, 0, sizeof(int32_t), st);
     if (nblk == 2) {
@@ -428,11 +430,11 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
     int32_t rot = 0;
     hipMemcpyAsync(&rot, w.rotcount, sizeof(int32_t), hipMemcpyDeviceToHost, st);
     hipStreamSynchronize(st);
-    if (rot == 0) { ++sweeps; break; }
+    if (rot == 0) { ++sweeps; plain_converged = true; break; }
   }
   hipLaunchKernelGGL(jacobi_norms_kernel, dim3((l + 3) / 4), dim3(256), 0, st, G, l, w.norms);
   hipLaunchKernelGGL(jacobi_finish_kernel, dim3(l), dim3(64), 0, st, G, l, w.norms, U, S);
-  return sweeps;
+  return plain_converged ? sweeps : -sweeps;
 }
 
 // 32 resident columns per workgroup up to l = 600, then 16 / 8 / 4 as the columns get longer

@@ -80,10 +80,10 @@ const LU_FORMS = ["none", "replicated", "per-step", "persistent-1hop", "persiste
 "Which path ran under the communicator (`gsi_ctx_path_info`): LU form, self-test mask of the in-kernel pivot exchange,
 collectives since the last phase reset, ranks joined, LU time-outs seen / hidden by a transparent re-run."
 function path_info(c::Context)
-	out = zeros(Int64, 12)
+	out = zeros(Int64, 13)
 	check(ccall((:gsi_ctx_path_info, libgsi), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64), c.h, out, length(out)))
 	return (lu_form = LU_FORMS[out[1] + 1], lu_selftest_mask = out[2], collectives = out[3], n_ranks_seen = out[4],
-		lu_timeouts = out[5], lu_timeouts_recovered = out[6], lu_forms_run = Dict(LU_FORMS[f + 1] => out[7 + f] for f = 1:5 if out[7 + f] > 0))
+		lu_timeouts = out[5], lu_timeouts_recovered = out[6], svd_sweep_cap_hits = out[13], lu_forms_run = Dict(LU_FORMS[f + 1] => out[7 + f] for f = 1:5 if out[7 + f] > 0))
 end
 
 # ---- operators ------------------------------------------------------------------------------------

@@ -225,6 +225,18 @@ def _worker(rank, world, port, q):
         results["pcgalsqr_sharded_basis"] = float(np.linalg.norm(s_full - s_ref) / np.linalg.norm(s_ref))
         results["pcgalsqr_sharded_fit"] = 0.0 if np.linalg.norm(s_full - truep) / np.linalg.norm(truep) < 2e-2 else 1.0
         basis.close(); Zp.close(); qop.close()
+        # round 4: host values through the library's communicator, and what gsi_ctx_path_info says about the run so far
+        got = ctx.host_allgather([rank + 0.5, 7.0])
+        results["host_allgather"] = float(np.abs(got - np.array([[r + 0.5, 7.0] for r in range(world)])).max())
+        pi = ctx.path_info()
+        results["path_ranks_seen"] = 0.0 if pi["n_ranks_seen"] == world else 1.0
+        # the CPU reference backend has no in-kernel exchange: sharded LUs ran per step, gathered ones replicated; the
+        # self-test was tried and found nothing (mask 0); no time-outs
+        ok = set(pi["lu_forms_run"]) <= {"replicated", "per-step"} and pi["lu_form"] in ("replicated", "per-step") \
+            and pi["lu_selftest_mask"] == 0 and pi["lu_timeouts"] == 0 and pi["collectives"] > 0
+        results["path_info_consistent"] = 0.0 if ok else 1.0
+        ctx.phase_reset()
+        results["path_reset"] = float(ctx.path_info()["collectives"]) + float(sum(ctx.path_info()["lu_forms_run"].values()))
         ctx.close()
         dist.barrier()
         dist.destroy_process_group()
