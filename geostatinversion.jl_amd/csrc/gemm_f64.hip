@@ -92,17 +92,52 @@ struct GenA {
 // arg = a; (c1, p1, p2) = exponential (1, 0, 0), Matern 3/2 (sqrt 3, 1, 0), Matern 5/2 (sqrt 5, 1, 1/3).  The same
 // association as pointcov::kernel: (1 + a) + (a a) / 3.  One straight-line body for all kinds, parameters in SGPRs.
 struct GenPointK { double inv_ell2, sigma2, c1, p1, p2; int gauss; };
+// sqrt(x), x >= 0, to within an ulp: v_rsq_f64 (2^-26) and two Goldschmidt steps -- 9 instructions where the correctly rounded
+// library routine (range scaling, special cases) takes ~20; x = 0 (coincident points: the diagonal) is patched by a select.
+__device__ __forceinline__ double gen_sqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  double g = x * y0, h = 0.5 * y0;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  const double d = fma(-g, g, x);                 // one correction with the residual: g += (x - g^2) h
+  g = fma(d, h, g);
+  return (x > 0.0) ? g : 0.0;
+}
+// exp(x), x <= 0, as pointcov::exp_nonpos but with the argument clamped instead of a select on the result (below -745 the
+// true value is below the smallest denormal; the clamped evaluation returns < 5e-324 x 2: zero or one denormal ulp)
+__device__ __forceinline__ double gen_exp_nonpos(double x) {
+  x = fmax(x, -745.0);
+  const double n = rint(x * 1.4426950408889634);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = 2.08767569878681e-09;
+  p = fma(p, r, 2.505210838544172e-08);
+  p = fma(p, r, 2.755731922398589e-07);
+  p = fma(p, r, 2.7557319223985893e-06);
+  p = fma(p, r, 2.48015873015873e-05);
+  p = fma(p, r, 1.984126984126984e-04);
+  p = fma(p, r, 1.3888888888888889e-03);
+  p = fma(p, r, 8.333333333333333e-03);
+  p = fma(p, r, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
 __device__ __forceinline__ double gen_point_entry(const GenPointK& q, double d2) {
   const double r2 = d2 * q.inv_ell2;
   double arg, poly = 1.0;
   if (q.gauss) {                                   // uniform
     arg = 0.5 * r2;
   } else {
-    const double a = q.c1 * sqrt(r2);
+    const double a = q.c1 * gen_sqrt(r2);
     arg = a;
     poly = (1.0 + q.p1 * a) + (a * a) * q.p2;
   }
-  return poly * pointcov::exp_nonpos(-arg) * q.sigma2;
+  return poly * gen_exp_nonpos(-arg) * q.sigma2;
 }
 // RAGGED: the "irregular X" instantiation.  Either the sketch width is not a multiple of 16 (K + p is the
 // caller's choice), so the last columns of the X tile do not exist, or X is only 8-byte aligned (n odd as its
@@ -230,6 +265,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     gq.p1 = (gen.kind == pointcov::MATERN32 || gen.kind == pointcov::MATERN52) ? 1.0 : 0.0;
     gq.p2 = (gen.kind == pointcov::MATERN52) ? (1.0 / 3.0) : 0.0;
   }
+  // GEN 1 (round 4): everything in BYTE offsets into the table, x coordinates pre-multiplied by the row length -- the offset of
+  // an entry is |px - qx| + |py - qy| = two v_sad_u32 (sum of absolute differences) instead of eleven integer instructions
+  // with a quarter-rate multiply: on gfx950 every VALU instruction of this loop is matrix time lost (fp64 MFMAs hold the
+  // vector ALU), and the table operator ran at 0.80 of the peak where the stored one reaches 0.865.
+  uint32_t t_px0 = 0, t_py0 = 0, t_px1 = 0, t_py1 = 0, t_qx = 0, t_qy = 0, t_ny8 = 0;
   if constexpr (GEN == 1) {
     const int64_t gr = gen.roff + r0 + a_r;
     g_x0 = (int)(gr / gen.ny); g_y0 = (int)(gr % gen.ny);
@@ -238,22 +278,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     const int64_t gk = gen.koff + kbeg + __builtin_amdgcn_readfirstlane(a_k);
     g_kx = __builtin_amdgcn_readfirstlane((int)(gk / gen.ny));
     g_ky = __builtin_amdgcn_readfirstlane((int)(gk % gen.ny));
+    t_ny8 = 8u * (uint32_t)gen.ny;
+    t_px0 = (uint32_t)g_x0 * t_ny8; t_py0 = 8u * (uint32_t)g_y0;
+    t_px1 = (uint32_t)g_x1 * t_ny8; t_py1 = 8u * (uint32_t)g_y1;
+    t_qx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)g_kx * t_ny8));
+    t_qy = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8u * (uint32_t)g_ky));
   }
 
-  auto prefetch = [&](int64_t k0, auto SET) {
+  auto prefetch = [&](int64_t k0, auto SET) __attribute__((always_inline)) {
     constexpr int set = decltype(SET)::value;
     if constexpr (GEN == 1) {
       const int64_t kfirst = k0 + __builtin_amdgcn_readfirstlane(a_k);
-      auto advance = [&]() {
-        g_ky += KSTEP_NN;
-        while (g_ky >= gen.ny) { g_ky -= gen.ny; ++g_kx; }
+      auto advance = [&]() {                       // scalar: the reduction index of the next pair slot, in table bytes
+        t_qy += 8u * KSTEP_NN;
+        while (t_qy >= t_ny8) { t_qy -= t_ny8; t_qx += t_ny8; }
       };
-      auto entry = [&](int gx, int gy) -> double { return gen.t2[abs(gx - g_kx) * gen.ny + abs(gy - g_ky)]; };
+      const char* const tb = reinterpret_cast<const char*>(gen.t2);
+      auto sad = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return ((a > b) ? a - b : b - a) + c; };   // v_sad_u32
+      auto entry = [&](uint32_t px, uint32_t py) -> double {
+        return *reinterpret_cast<const double*>(tb + sad(py, t_qy, sad(px, t_qx, 0u)));
+      };
       if (r0 + BMT <= M && k0 + BK <= kend) {      // interior: no predicates (workgroup-uniform branch)
 #pragma unroll
         for (int it = 0; it < A_PAIRS; ++it) {
-          a_reg[set][it].x = entry(g_x0, g_y0);
-          a_reg[set][it].y = entry(g_x1, g_y1);
+          a_reg[set][it].x = entry(t_px0, t_py0);
+          a_reg[set][it].y = entry(t_px1, t_py1);
           advance();
         }
       } else {
@@ -261,8 +310,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 #pragma unroll
         for (int it = 0; it < A_PAIRS; ++it) {
           const bool okk = kfirst + KSTEP_NN * it < kend;   // uniform
-          a_reg[set][it].x = (okk && ok_r0) ? entry(g_x0, g_y0) : 0.0;
-          a_reg[set][it].y = (okk && ok_r1) ? entry(g_x1, g_y1) : 0.0;
+          a_reg[set][it].x = (okk && ok_r0) ? entry(t_px0, t_py0) : 0.0;
+          a_reg[set][it].y = (okk && ok_r1) ? entry(t_px1, t_py1) : 0.0;
           advance();
         }
       }
@@ -328,14 +377,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     }
   };
 
-  auto stage = [&](int buf, auto SET, int64_t k0) {
+  auto stage = [&](int buf, auto SET, int64_t k0) __attribute__((always_inline)) {
     constexpr int set = decltype(SET)::value;
     double* a_s = smem + buf * BUF_ELEMS;
     double* b_s = a_s + A_ELEMS;
     (void)k0;
     if constexpr (GEN == 2) {
-      const bool ok_r0 = r0 + a_r < M, ok_r1 = r0 + a_r + 1 < M;
       const int kw = __builtin_amdgcn_readfirstlane(a_k);                   // wave index: the pair slot's k is wave-uniform
+      // ONE code path for interior and edge tiles: a second, select-free copy for interior tiles was measured SLOWER (633 vs
+      // 584 ms per product at n = 2e5: the kernel outgrew the 64 KB instruction cache, 9040 instructions)
+      const bool ok_r0 = r0 + a_r < M, ok_r1 = r0 + a_r + 1 < M;
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it) {
         const int64_t kc = k0 + kw + KSTEP_NN * it;
@@ -393,7 +444,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
   // one tile of the pipeline; PAR = parity of t (compile time: selects LDS buffer and register set)
-  auto do_tile = [&](int64_t t, auto PAR) {
+  auto do_tile = [&](int64_t t, auto PAR) __attribute__((always_inline)) {
     constexpr int cur = decltype(PAR)::value;
     using NextSet = std::integral_constant<int, (NSETS == 2) ? (cur ^ 1) : 0>;
     // The two waves of a SIMD (column halves ch = 0 / 1 of the same rows) run the same program;
@@ -401,7 +452,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     // a pure MFMA stretch (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  The chores run at priority 0 and
     // everything else at priority 1, so the SIMD's arbiter always prefers the partner that is feeding the matrix
     // pipe (measured +1.5..2 %; a static priority for waves 4-7 alone measured -1 %).
-    auto chores = [&]() {
+    auto chores = [&]() __attribute__((always_inline)) {
       __builtin_amdgcn_s_setprio(0);
       if (t + 1 < ntiles) stage(cur ^ 1, NextSet{}, kbeg + (t + 1) * BK);            // tile t+1: registers -> other LDS buffer
       if (t + 1 + NSETS < ntiles) prefetch(kbeg + (t + 1 + NSETS) * BK, NextSet{});  // HBM -> the set just drained

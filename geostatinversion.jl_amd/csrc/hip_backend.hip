@@ -296,6 +296,8 @@ class HipBackend : public Backend {
         pr = std::max<int64_t>(128, ((pr / 2) / 128) * 128);
       }
     }
+    // the panels go back to the block cache on every exit path (a HIP_CHECK or an allocation below may throw)
+    struct PanelGuard { HipBackend* be; double** P; ~PanelGuard() { for (int i = 0; i < 2; ++i) if (P[i]) { be->release(P[i]); P[i] = nullptr; } } } guard{this, P};
     double* ws = gemm_ws(hipk::gemm_workspace_doubles(std::min(pr, m), l, k));
     // the generator must not overwrite a panel buffer that earlier work on st_ may still read (pooled memory)
     HIP_CHECK(hipEventRecord(ev_used_[0], st_));
@@ -311,9 +313,7 @@ class HipBackend : public Backend {
       hipk::gemm_f64(st_, false, rows, l, k, 1.0, P[b], pr, B, ldb, 0.0, C + r0, ldc, ws);
       HIP_CHECK(hipEventRecord(ev_used_[b], st_));
     }
-    check_launch("gemm_nn_pointcov");
-    release(P[0]);                                          // stream-ordered pool: the next user is ordered after st_'s work
-    if (P[1]) release(P[1]);
+    check_launch("gemm_nn_pointcov");     // (the guard releases the panels: stream-ordered pool, the next user is ordered after st_'s work)
   }
 
   // ---- matrix-free FFT covariance ----
@@ -354,23 +354,28 @@ class HipBackend : public Backend {
       int64_t cur[3] = {1, 1, 1};
       for (int a = 0; a < d; ++a) cur[a] = 2 * p->N[a];
       int64_t tot = cur[0] * cur[1] * cur[2];
-      double* buf = alloc((size_t)tot);
+      // every temporary of the re-embedding goes back to the block cache on every exit path (a throwing HIP_CHECK
+      // or allocation between alloc and release leaked pooled blocks)
+      struct Hold { HipBackend* be; double* p; ~Hold() { if (p) be->release(p); } } bufh{this, nullptr};
+      bufh.p = alloc((size_t)tot);
+      double*& buf = bufh.p;
       hipk::fft_spectrum_natural(st_, buf, cur, beta, 1);
       auto rotate_apply = [&](int64_t rows_out, int64_t period, bool weighted) {
         // cur = (k, rest) column-major; B = k x rows_out; result (rest x rows_out) = the array with axis 0 replaced and last
         const int64_t k = cur[0], rest = (tot / k);
-        double* B = alloc((size_t)k * rows_out);
+        Hold Bh{this, alloc((size_t)k * rows_out)};
+        double* B = Bh.p;
         // B[kk + t k] : weighted (the D factors) is indexed [t = row of the INPUT, k' = output]; unweighted [k, t]
         if (!weighted) hipk::fft_cos_matrix(st_, B, k, rows_out, period, false);          // C_a^T: B[k, t]
         else hipk::fft_cos_matrix(st_, B, k, rows_out, period, true);                     // D_a^T: B[t, k'] = w_t cos(.)
-        double* out = nullptr;
-        try { out = alloc((size_t)rest * rows_out); } catch (...) { release(B); throw; }
+        Hold outh{this, alloc((size_t)rest * rows_out)};
+        double* out = outh.p;
         double* ws = gemm_ws(hipk::gemm_workspace_doubles(rest, rows_out, k));
         hipk::gemm_f64(st_, true, rest, rows_out, k, 1.0, buf, k, B, k, 0.0, out, rest, ws);
         check_launch("fft re-embedding product");
-        release(B);
         release(buf);
         buf = out;
+        outh.p = nullptr;
         tot = rest * rows_out;
         // rotate the dimension list: (k, c1, c2) -> (c1, c2, rows_out) over the d real axes
         int64_t nd[3] = {1, 1, 1};
@@ -384,6 +389,7 @@ class HipBackend : public Backend {
       hipk::fft_finish_plan(st_, p->lam, p->lam + Mtot, p->M);
       check_launch("fft re-embedded spectrum");
       release(buf);
+      buf = nullptr;                                          // (bufh's destructor must not release it a second time)
     } catch (...) {
       release(p->W); release(p->lam);
       throw;

@@ -1331,6 +1331,7 @@ print("pointcov-ok")
 """
     env = dict(os.environ)
     env["GSI_POINTCOV_PANEL_MB"] = "1"
+    env["GSI_POINTCOV_PANELS"] = "1"     # round 3's row panels (the default since round 4 generates in the tile loader): kept under test
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "pointcov-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
