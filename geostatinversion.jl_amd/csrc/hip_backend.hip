@@ -175,7 +175,10 @@ class HipBackend : public Backend {
     // Panels of the tall problems are GBs each and come back every pass: keep up to 160 GB of them (of 288 GB; a
     // failed hipMalloc empties the cache and retries, so nothing is ever refused because of it).  A tighter policy
     // cost 0.7 s of hipFree/hipMalloc per randsvd at n = 1.7e7 and 4.9 s at n = 1.3e8.
-    if (pooled_ > ((int64_t)160 << 30)) trim_pool((int64_t)104 << 30);
+    // (ranks that share this device -- one-GPU rehearsals -- share the budget: a co-tenant cannot reach into this cache, it
+    // would just see an out-of-memory error)
+    const int64_t cap = ((int64_t)160 << 30) / std::max(1, ranks_sharing_device_);
+    if (pooled_ > cap) trim_pool(cap / 3 * 2);
   }
   void trim_pool(int64_t keep_bytes) {
     hipStreamSynchronize(st_);
@@ -882,7 +885,11 @@ class HipBackend : public Backend {
     phase_end(PH_SVD);
     phase_begin(PH_SMALL_GEMM);
     hipk::gemm_f64(st_, false, l, l, l, 1.0, hipk::cholqr2_X2(base + o_small, l), l, base + o_U, l, 0.0, base + o_M, l, ws);
-    hipk::gemm_f64(st_, false, m, l, l, 1.0, base + o_T, ldt, base + o_M, l, 0.0, V, ldv, ws);
+    // Z = V sqrt(S) has its last p columns ZERO by definition (RandMatFact.jl:87): they are not multiplied out (a fifth of
+    // the product at K = 256, p = 64), they are cleared
+    const int64_t lz = (K_scale >= 0 && K_scale < l) ? K_scale : l;
+    hipk::gemm_f64(st_, false, m, lz, l, 1.0, base + o_T, ldt, base + o_M, l, 0.0, V, ldv, ws);
+    if (lz < l) HIP_CHECK(hipMemsetAsync(V + (size_t)lz * ldv, 0, sizeof(double) * ((size_t)(l - lz - 1) * ldv + m), st_));
     check_launch("svd_tall_fused");
     phase_end(PH_SMALL_GEMM);
     return true;

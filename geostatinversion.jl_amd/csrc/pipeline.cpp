@@ -764,7 +764,9 @@ void svd_tall(Context& c, double* W, int64_t n, int64_t l, int64_t K_scale, doub
   }
   {
     ScopedPhase ph(be, PH_SMALL_GEMM);
-    be->gemm_nn(n, l, l, 1.0, W, n, U.p, l, 0.0, V, n);     // Z = V*Sh = Q_B (U_R Sh)         :88
+    const int64_t lz = (K_scale >= 0 && K_scale < l) ? K_scale : l;      // the last p columns of Z are zero by definition (:87)
+    be->gemm_nn(n, lz, l, 1.0, W, n, U.p, l, 0.0, V, n);    // Z = V*Sh = Q_B (U_R Sh)         :88
+    if (lz < l) be->fill_zero(V + (size_t)lz * n, (size_t)(l - lz) * n);
   }
 }
 
@@ -787,7 +789,9 @@ static void svd_rows(const Operator& A, Buf& Q, int64_t K, int64_t l, double* Zl
     be->scale_cols_sqrt(U.p, l, S, K);                     // Sh = sqrt([S[1:K]; zeros(p)])        :87
   }
   ScopedPhase ph(be, PH_SMALL_GEMM);
-  be->gemm_nn(nloc, l, l, 1.0, Wloc.p, std::max<int64_t>(nloc, 1), U.p, l, 0.0, Zloc, std::max<int64_t>(nloc, 1));   // Z = V*Sh  :88
+  const int64_t ldz = std::max<int64_t>(nloc, 1), lz = (K < l) ? K : l;      // the last p columns of Z are zero by definition (:87)
+  be->gemm_nn(nloc, lz, l, 1.0, Wloc.p, ldz, U.p, l, 0.0, Zloc, ldz);       // Z = V*Sh  :88
+  if (lz < l) be->fill_zero(Zloc + (size_t)lz * ldz, (size_t)(l - lz) * ldz);
 }
 
 void randsvd(const Operator& A, const double* Omega, int64_t K, int64_t p, int64_t q, double* Z, double* S) {
