@@ -150,8 +150,18 @@ template <int NT, bool TRANS_A, int GEN, int XMODE>
 __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     int64_t M, int64_t L, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* __restrict__ C, int64_t ldc, double alpha,
-    double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, int wide, int tri, GenA gen) {
+    double beta, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, int wide, int tri, GenA gen, int64_t nitems) {
   static_assert(!(GEN != 0 && TRANS_A), "the generated operand is symmetric: only the NN form exists");
+  // PERSISTENT mode (round 4; nitems > 0: stored operand, regular X, one K split, no triangle): the grid is one workgroup
+  // per CU and a workgroup walks the output tiles blockIdx.x, + gridDim.x, ... < nitems.  Short reductions are what it is for
+  // (the S T product of a LowRankCovMatrix, K = N_s = 1024: 32 tiles per workgroup; Z = T M, K = 320: 10): per output tile a
+  // one-shot workgroup exposed its two-tile prologue and the 164 KB of result stores -- 0.54 ms of a 10.25 ms launch (time
+  // against K: slope 9.715 ms per 1024, `tools/bench_lrcm_products.py --samples 512 ... 4096`).  Here the next tile's first two
+  // operand tiles are requested BEFORE the result stores are issued (vmcnt retires in order on gfx9: loads queued behind 80
+  // stores would wait for all of them; the staging registers are dead at that point, so this costs no register), and the
+  // stores drain under the next tile's matrix work.
+  constexpr bool CANP = (GEN == 0 && XMODE == 0);
+  const bool persist = CANP && nitems > 0;
   constexpr bool RAGGED = XMODE != 0;
   constexpr bool BIG = XMODE == 2;
   using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
@@ -176,24 +186,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   //   column chunks of one row block (S T: 2 chunks): both read the same rows of the operator -> same XCD, 8 apart.
   int64_t tile_lin = blockIdx.x;
   int split = (int)blockIdx.y;
-  {
+  int64_t r0 = 0, c0 = 0;
+  // bx: the linear x id of the work item (blockIdx.x, or the item index of the persistent mode: gridDim.x is a multiple of 8
+  // there, so item id % 8 is still the XCD the workgroup runs on)
+  auto locate = [&](int64_t bx) __attribute__((always_inline)) {
+    tile_lin = bx;
     const int T = (int)gridDim.x, S = (int)gridDim.y;
     if (S > 1 && (S & 7) == 0) {
-      const int lin = (int)blockIdx.x + T * (int)blockIdx.y;
+      const int lin = (int)bx + T * (int)blockIdx.y;
       const int xcd = lin & 7, j = lin >> 3;
       split = xcd + 8 * (j / T);
       tile_lin = j % T;
     } else if (S == 1 && tri != 1 && nchunks_x > 1) {
       const int C8 = 8 * nchunks_x;
       const int nrb = (int)((M + BMT - 1) / BMT);
-      const int grp = (int)(blockIdx.x / C8), r = (int)(blockIdx.x % C8);
+      const int grp = (int)(bx / C8), r = (int)(bx % C8);
       const int rows_here = (grp * 8 + 8 <= nrb) ? 8 : (nrb - grp * 8);      // the last group may be short
       const int rb = grp * 8 + r % rows_here, chunk = r / rows_here;
       tile_lin = (int64_t)rb * nchunks_x + chunk;
     }
-  }
-  int64_t r0 = (int64_t)(tile_lin / nchunks_x) * BMT;
-  int64_t c0 = (int64_t)(tile_lin % nchunks_x) * (NT * 16);
+    r0 = (int64_t)(tile_lin / nchunks_x) * BMT;
+    c0 = (int64_t)(tile_lin % nchunks_x) * (NT * 16);
+  };
+  locate(blockIdx.x);
   if (tri == 1) {
     // symmetric product: the tile index counts only the tiles that touch the upper triangle (tiles entirely below the
     // diagonal are not part of the grid -- as idle workgroups they pushed the grid past one round of 256)
@@ -209,10 +224,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   // tri == 1 (TN, C = A'A symmetric): tiles entirely below the diagonal are not computed (the caller mirrors the
   //   upper triangle); tri == 2 (NN, B upper triangular): rows of B below the chunk's last column are zero, so the
   //   reduction stops there.  CholeskyQR spends 4 n l^2 flop instead of 8 n l^2 this way.
-  const int64_t kbeg = (int64_t)split * kchunk;
+  int64_t kbeg = (int64_t)split * kchunk;
   int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
   if (tri == 2 && kend > c0 + NT * 16) kend = c0 + NT * 16;
-  const int64_t ntiles = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+  int64_t ntiles = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
 
   double4_t acc[MT][NTW];
 #pragma unroll
@@ -242,11 +257,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   const off_t b_off0 = (off_t)8 * (off_t)(b_k + (int64_t)b_c * ldb);
   const off_t b_step_c = (off_t)8 * (off_t)(RSTEP * ldb);
   // byte distance between the two elements of a pair when they cannot be fetched as one 16-B load
-  const char* const Abase = reinterpret_cast<const char*>(TRANS_A ? A + r0 * lda : A + r0);
-  const char* const Bbase = reinterpret_cast<const char*>(B + c0 * ldb);
+  const char* Abase = reinterpret_cast<const char*>(TRANS_A ? A + r0 * lda : A + r0);
+  const char* Bbase = reinterpret_cast<const char*>(B + c0 * ldb);
   // interior workgroups (all 128 rows and all NT*16 columns in range) take an unpredicated
   // load path on full-depth tiles; the branch is workgroup-uniform
-  const bool wg_full = (r0 + BMT <= M) && (RAGGED || c0 + NT * 16 <= L);
+  bool wg_full = (r0 + BMT <= M) && (RAGGED || c0 + NT * 16 <= L);
+  auto setup_item = [&]() __attribute__((always_inline)) {      // persistent mode: everything that depends on the output tile
+    Abase = reinterpret_cast<const char*>(TRANS_A ? A + r0 * lda : A + r0);
+    Bbase = reinterpret_cast<const char*>(B + c0 * ldb);
+    wg_full = (r0 + BMT <= M) && (RAGGED || c0 + NT * 16 <= L);
+  };
 
   // GEN: grid coordinates of this thread's two rows (fixed for the whole kernel), and of the reduction
   // index the NEXT prefetched pair slot covers.  The latter is wave-uniform (a_k = wave index), lives in
@@ -487,50 +507,77 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     }
   };
 
-  if (ntiles > 0) {
-    prefetch(kbeg, Set0{});
-    if (NSETS == 2 && ntiles > 1) prefetch(kbeg + BK, Set1{});
-    stage(0, Set0{}, kbeg);
-    if (ntiles > NSETS) prefetch(kbeg + NSETS * BK, Set0{});
-    __syncthreads();
+  int64_t item = blockIdx.x;
+  bool primed = false;                 // the first two operand tiles of this item were requested at the end of the previous one
+  for (;;) {
+    if (ntiles > 0) {
+      if (!primed) {
+        prefetch(kbeg, Set0{});
+        if (NSETS == 2 && ntiles > 1) prefetch(kbeg + BK, Set1{});
+      }
+      stage(0, Set0{}, kbeg);
+      if (ntiles > NSETS) prefetch(kbeg + NSETS * BK, Set0{});
+      __syncthreads();
 #pragma unroll
-    for (int h = 0; h < MT; ++h) fa[h] = a_frag(0, 0, h);
+      for (int h = 0; h < MT; ++h) fa[h] = a_frag(0, 0, h);
 #pragma unroll
-    for (int t = 0; t < NTW; ++t)
-      if ((NT % 2 == 0) || t < ntw) fb[t] = b_frag(0, 0, t);
-    int64_t t = 0;
-    for (; t + 1 < ntiles; t += 2) {
-      do_tile(t, Set0{});
-      do_tile(t + 1, Set1{});
+      for (int t = 0; t < NTW; ++t)
+        if ((NT % 2 == 0) || t < ntw) fb[t] = b_frag(0, 0, t);
+      int64_t t = 0;
+      for (; t + 1 < ntiles; t += 2) {
+        do_tile(t, Set0{});
+        do_tile(t + 1, Set1{});
+      }
+      if (t < ntiles) do_tile(t, Set0{});
     }
-    if (t < ntiles) do_tile(t, Set0{});
-  }
+    const int64_t er0 = r0, ec0 = c0;                 // where this item's results go
+    bool more = false;
+    if constexpr (CANP) {
+      if (persist && item + (int64_t)gridDim.x < nitems) {
+        more = true;
+        item += gridDim.x;
+        __syncthreads();                              // every wave is done with this item's LDS images
+        locate(item);
+        setup_item();
+        if (ntiles > 0) {                             // (K, hence ntiles, is the same for every item of this mode)
+          prefetch(kbeg, Set0{});
+          if (NSETS == 2 && ntiles > 1) prefetch(kbeg + BK, Set1{});
+        }
+        primed = true;
+      }
+    }
 
-  // epilogue: lane holds D[i = kk + 4*reg][j = jl]  ->  C[row][col = c0 + 16*(t0+t) + kk + 4*reg]
+    // epilogue: lane holds D[i = kk + 4*reg][j = jl]  ->  C[row][col = c0 + 16*(t0+t) + kk + 4*reg]
 #pragma unroll
-  for (int h = 0; h < MT; ++h) {
-    const int64_t row = r0 + 16 * MT * rg + 16 * h + jl;
-    if (row < M) {
-      double* W = (slabs != nullptr) ? slabs + (int64_t)split * M * L : nullptr;
+    for (int h = 0; h < MT; ++h) {
+      const int64_t row = er0 + 16 * MT * rg + 16 * h + jl;
+      if (row < M) {
+        double* W = (slabs != nullptr) ? slabs + (int64_t)split * M * L : nullptr;
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        if ((NT % 2 == 0) || t < ntw) {
+        for (int t = 0; t < NTW; ++t) {
+          if ((NT % 2 == 0) || t < ntw) {
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int64_t col = c0 + 16 * (t0 + t) + kk + 4 * reg;
-            if (col < L) {
-              if (W != nullptr) {
-                W[row + col * M] = acc[h][t][reg];
-              } else {
-                double v = alpha * acc[h][t][reg];
-                if (beta != 0.0) v += beta * C[row + col * ldc];
-                C[row + col * ldc] = v;
+            for (int reg = 0; reg < 4; ++reg) {
+              const int64_t col = ec0 + 16 * (t0 + t) + kk + 4 * reg;
+              if (col < L) {
+                if (W != nullptr) {
+                  W[row + col * M] = acc[h][t][reg];
+                } else {
+                  double v = alpha * acc[h][t][reg];
+                  if (beta != 0.0) v += beta * C[row + col * ldc];
+                  C[row + col * ldc] = v;
+                }
               }
             }
           }
         }
       }
     }
+    if (!more) break;
+#pragma unroll
+    for (int h = 0; h < MT; ++h)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[h][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
   }
 }
 
@@ -552,29 +599,29 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t L, int nsplit, const dou
 template <int NT, bool TRANS_A, int GEN, int XMODE>
 static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A,
                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha,
-                      double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide, int tri, const GenA& gen) {
+                      double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide, int tri, const GenA& gen, int64_t nitems) {
   constexpr size_t shmem = 2 * ((TRANS_A ? BMT * BKP : BK * BMP) + NT * 16 * BKP) * sizeof(double);
   static std::atomic<uint64_t> attr_mask{0};
   if (first_use_on_this_device(attr_mask))
     (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<NT, TRANS_A, GEN, XMODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   hipLaunchKernelGGL((gemm_f64_kernel<NT, TRANS_A, GEN, XMODE>), grid, dim3(NTHREADS), shmem, st, M, L, K, A, lda, B, ldb, C,
-                     ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen);
+                     ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen, nitems);
 }
 
 template <bool TRANS_A, int GEN>
 static void launch_dispatch(int nt, dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K,
                             const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
                             int64_t ldc, double alpha, double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide,
-                            int xmode, int tri, const GenA& gen) {
+                            int xmode, int tri, const GenA& gen, int64_t nitems) {
 #define GSI_CASE(N)                                                                             \
   case N:                                                                                       \
     if (xmode == 2)                                                                               \
-      launch_nt<N, TRANS_A, GEN, 2>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen); \
+      launch_nt<N, TRANS_A, GEN, 2>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen, nitems); \
     else if (xmode == 1)                                                                          \
-      launch_nt<N, TRANS_A, GEN, 1>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen); \
+      launch_nt<N, TRANS_A, GEN, 1>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen, nitems); \
     else                                                                                          \
-      launch_nt<N, TRANS_A, GEN, 0>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen); \
+      launch_nt<N, TRANS_A, GEN, 0>(grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, nchunks_x, wide, tri, gen, nitems); \
     break;
   switch (nt) {
 #ifdef GSI_GEMM_DEV_ONLY_NT10      // developer builds (resource-usage remarks of one instantiation in seconds); never set by build.py
@@ -674,6 +721,10 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   const int ns_eff = (K > 0) ? (int)((K + kchunk - 1) / kchunk) : 1;
   dim3 grid((unsigned)active, (unsigned)ns_eff, 1);
   double* slabs = (ns_eff > 1) ? ws : nullptr;
+  // persistent mode (see the kernel): short reductions with several rounds of output tiles, stored operand, regular X
+  static const int ncus = [] { int dev = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+  static const bool persist_on = !(getenv("GSI_GEMM_PERSIST") != nullptr && getenv("GSI_GEMM_PERSIST")[0] == '0');
+  int64_t nitems = 0;
   // 16-byte loads need 16-B aligned bases and even leading dimensions (sub-panel views often are not)
   const bool a_ok = ((uintptr_t)A & 15) == 0 && (lda & 1) == 0;
   const bool b_ok = ((uintptr_t)B & 15) == 0 && (ldb & 1) == 0;
@@ -682,15 +733,20 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   const bool irregular_x = a_ok && (!b_ok || L % ((int64_t)nt * 16) != 0);
   const int wide = a_ok ? 1 : 0;
   const int xmode = big ? 2 : (irregular_x ? 1 : 0);
+  if (persist_on && gen == nullptr && xmode == 0 && tri == 0 && ns_eff == 1 && (ncus & 7) == 0 && active >= 2 * (int64_t)ncus &&
+      K <= 128 * BK) {
+    nitems = active;
+    grid.x = (unsigned)ncus;
+  }
   const GenA none = {nullptr, 1, 0, 0, 0, 0.0, 0.0, 0.0};
   if (gen != nullptr && gen_mode == 2)
-    launch_dispatch<false, 2>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, *gen);
+    launch_dispatch<false, 2>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, *gen, nitems);
   else if (gen != nullptr)
-    launch_dispatch<false, 1>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, *gen);
+    launch_dispatch<false, 1>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, *gen, nitems);
   else if (transA)
-    launch_dispatch<true, 0>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none);
+    launch_dispatch<true, 0>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none, nitems);
   else
-    launch_dispatch<false, 0>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none);
+    launch_dispatch<false, 0>(nt, grid, st, M, L, K, A, lda, B, ldb, C, ldc, alpha, beta, slabs, kchunk, (int)nchunks, wide, xmode, tri, none, nitems);
   if (ns_eff > 1) {
     const int64_t total = M * L;
     int blocks = (int)((total + 255) / 256);
