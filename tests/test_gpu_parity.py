@@ -38,6 +38,21 @@ def test_gemm_nn_tn(gsi, ctx, m, k, l):
     assert np.abs(Ct - ref).max() <= 1e-12 * np.abs(A).sum(axis=1).max() * np.abs(B).max()
 
 
+@pytest.mark.parametrize("m,k,l", [(70001, 96, 320), (66000, 130, 160), (131072, 33, 320)])
+def test_gemm_persistent_mode(gsi, ctx, m, k, l):
+    """Short reductions with more than two rounds of output tiles take the contraction kernel's PERSISTENT mode (one workgroup
+    per CU walking the tiles, the next tile's operands requested before the result stores): a ragged last row block, one and
+    two column chunks, K not a multiple of the tile depth -- both forms, against numpy."""
+    rng = np.random.default_rng(m + k)
+    A = np.asfortranarray(rng.standard_normal((m, k)))
+    B = np.asfortranarray(rng.standard_normal((k, l)))
+    ref = A @ B
+    bound = 1e-12 * np.abs(A).sum(axis=1).max() * np.abs(B).max()
+    assert np.abs(gsi.gemm(A, B) - ref).max() <= bound
+    At = np.asfortranarray(A.T)                                   # k x m stored: the transposed-operand instantiation
+    assert np.abs(gsi.gemm(At, B, trans=True) - ref).max() <= bound
+
+
 def test_gemm_exact_integer_layout(gsi, ctx):
     """asymmetric small-integer operands: any fragment-layout mistake shows up exactly."""
     m, k, l = 70, 37, 21
