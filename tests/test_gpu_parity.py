@@ -146,6 +146,29 @@ def test_svd_tall(gsi, ctx, n, l):
         assert min(np.linalg.norm(V[:, i] - Uref[:, i]), np.linalg.norm(V[:, i] + Uref[:, i])) < 1e-6
 
 
+@pytest.mark.parametrize("n,l", [(4000, 160), (6000, 320)])
+def test_svd_tall_clustered_spectrum(gsi, ctx, n, l):
+    """Clusters of (nearly) equal singular values -- where the activity-driven sweeps' flag threshold (4 x the rotation
+    threshold: pairs coupled below 4 sqrt(l) eps may stay unrotated) matters most for the VECTORS: the singular values must
+    still be dgesdd's, V orthonormal, every cluster's subspace the right one, and the factorization must reconstruct W."""
+    rng = np.random.default_rng(l)
+    U0, _ = np.linalg.qr(rng.standard_normal((n, l)))
+    V0, _ = np.linalg.qr(rng.standard_normal((l, l)))
+    sv = np.repeat(np.logspace(0, -5, l // 16), 16) * (1.0 + 1e-13 * rng.standard_normal(l))   # clusters of 16, equal to 1e-13
+    sv = np.sort(sv)[::-1]
+    W = (U0 * sv) @ V0.T
+    S, V = gsi.svd_tall(W)
+    Sref = np.linalg.svd(W, compute_uv=False)
+    assert np.abs(S - Sref).max() <= 1e-12 * Sref[0]
+    assert np.abs(V.T @ V - np.eye(l)).max() < 1e-11
+    for c in range(l // 16):                                  # each cluster's left subspace against the construction's
+        Vc, Uc = V[:, 16 * c:16 * c + 16], U0[:, 16 * c:16 * c + 16]
+        assert np.linalg.norm(Vc - Uc @ (Uc.T @ Vc)) < 1e-6, c
+    R = V.T @ W                                               # rows of V' W have norms S: W = V diag(S) (right vectors)'
+    assert np.abs(np.linalg.norm(R, axis=1) - S).max() <= 1e-11 * S[0]
+    assert np.linalg.norm(W - V @ R) <= 1e-11 * np.linalg.norm(W)
+
+
 @pytest.mark.parametrize("n,l", [(1400, 1300), (2800, 2600)])
 def test_svd_tall_very_wide(gsi, ctx, n, l):
     """Sketch widths beyond the 16- and 8-column LDS blockings of the Jacobi kernel (4 / 2 columns per block)."""
