@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 GPU call 12: final profiles -- the driver's command, its kernel trace, its PMC traffic passes; FFT kernel stats + PMC
+# the round-4 profile set -- the driver's command, its kernel trace, its PMC traffic passes; FFT kernel stats + PMC
 R=$GRAFT_REPO_ROOT; cd $R
 timeout -k 10 700 python bench.py > gpurun_out/r04_bench_line.json 2> gpurun_out/r04_bench_line.err; echo bench_rc=$?
 bash tools/profile_bench.sh r04 > /dev/null 2>&1 || exit 1
