@@ -695,7 +695,8 @@ def main():
     counters.update({"lu_form": pinfo["lu_form"], "lu_forms_run_in_timed_steps": pinfo["lu_forms_run"],
                      "lu_selftest_mask": pinfo["lu_selftest_mask"],
                      "collectives_per_step": pinfo["collectives"] / max(args.steps, 1), "n_ranks_seen": pinfo["n_ranks_seen"],
-                     "lu_timeouts": pinfo["lu_timeouts"], "lu_timeouts_recovered": pinfo["lu_timeouts_recovered"]})
+                     "lu_timeouts": pinfo["lu_timeouts"], "lu_timeouts_recovered": pinfo["lu_timeouts_recovered"],
+                     "svd_sweep_cap_hits": pinfo["svd_sweep_cap_hits"]})
     if use_dist:                         # every rank must have run the same form: a rank that fell back alone is a bug
         forms = ctx.host_allgather([float(gsi.Context.LU_FORMS.index(pinfo["lu_form"])), float(pinfo["lu_selftest_mask"])])
         counters["lu_form_same_on_all_ranks"] = bool((forms == forms[0]).all())
