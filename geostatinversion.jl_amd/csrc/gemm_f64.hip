@@ -45,6 +45,7 @@
 #include <algorithm>
 #include "hip_common.hpp"
 #include "pointcov.hpp"
+#include "pointcov_gen.hpp"
 
 namespace gsi { namespace hipk {
 
@@ -76,7 +77,8 @@ struct GenA {
   int32_t kind;       // GEN 2: pointcov::GAUSSIAN ...
   int64_t roff;       // global index of row 0 of the product
   int64_t koff;       // global index of reduction index 0
-  double inv_ell2, sigma2, nugget;   // GEN 2
+  double inv_ell2, sigma2, nugget;   // GEN 2 (inv_ell2: unused since the points arrive pre-scaled)
+  int32_t dim;        // GEN 2: coordinates per point (<= 3)
 };
 
 // GEN 2: the covariance of SCATTERED points, A(i, j) = sigma2 k(|p_i - p_j| / ell) (+ nugget on the diagonal), evaluated where
@@ -88,57 +90,7 @@ struct GenA {
 // the ~35 VALU instructions per entry issue in the shadow of the partner wave's MFMAs (an entry feeds 2 l flops of matrix
 // work).  Nothing is prefetched for A -- there is no latency to hide -- so the staging registers of the stored operand are free
 // for the coordinates and the polynomial.  One definition of the kernels: pointcov.hpp.
-// every kind as  v = sigma2 (1 + p1 a + p2 a^2) exp(-arg),  a = c1 r:  Gaussian arg = r^2 / 2 (no square root), the others
-// arg = a; (c1, p1, p2) = exponential (1, 0, 0), Matern 3/2 (sqrt 3, 1, 0), Matern 5/2 (sqrt 5, 1, 1/3).  The same
-// association as pointcov::kernel: (1 + a) + (a a) / 3.  One straight-line body for all kinds, parameters in SGPRs.
-struct GenPointK { double inv_ell2, sigma2, c1, p1, p2; int gauss; };
-// sqrt(x), x >= 0, to within an ulp: v_rsq_f64 (2^-26) and two Goldschmidt steps -- 9 instructions where the correctly rounded
-// library routine (range scaling, special cases) takes ~20; x = 0 (coincident points: the diagonal) is patched by a select.
-__device__ __forceinline__ double gen_sqrt(double x) {
-  const double y0 = __builtin_amdgcn_rsq(x);
-  double g = x * y0, h = 0.5 * y0;
-  double e = fma(-h, g, 0.5);
-  g = fma(g, e, g); h = fma(h, e, h);
-  e = fma(-h, g, 0.5);
-  g = fma(g, e, g);
-  const double d = fma(-g, g, x);                 // one correction with the residual: g += (x - g^2) h
-  g = fma(d, h, g);
-  return (x > 0.0) ? g : 0.0;
-}
-// exp(x), x <= 0, as pointcov::exp_nonpos but with the argument clamped instead of a select on the result (below -745 the
-// true value is below the smallest denormal; the clamped evaluation returns < 5e-324 x 2: zero or one denormal ulp)
-__device__ __forceinline__ double gen_exp_nonpos(double x) {
-  x = fmax(x, -745.0);
-  const double n = rint(x * 1.4426950408889634);
-  double r = fma(-n, 6.93147180369123816490e-01, x);
-  r = fma(-n, 1.90821492927058770002e-10, r);
-  double p = 2.08767569878681e-09;
-  p = fma(p, r, 2.505210838544172e-08);
-  p = fma(p, r, 2.755731922398589e-07);
-  p = fma(p, r, 2.7557319223985893e-06);
-  p = fma(p, r, 2.48015873015873e-05);
-  p = fma(p, r, 1.984126984126984e-04);
-  p = fma(p, r, 1.3888888888888889e-03);
-  p = fma(p, r, 8.333333333333333e-03);
-  p = fma(p, r, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)n);
-}
-__device__ __forceinline__ double gen_point_entry(const GenPointK& q, double d2) {
-  const double r2 = d2 * q.inv_ell2;
-  double arg, poly = 1.0;
-  if (q.gauss) {                                   // uniform
-    arg = 0.5 * r2;
-  } else {
-    const double a = q.c1 * gen_sqrt(r2);
-    arg = a;
-    poly = (1.0 + q.p1 * a) + (a * a) * q.p2;
-  }
-  return poly * gen_exp_nonpos(-arg) * q.sigma2;
-}
+// The entry itself (pre-scaled points, table-driven exponential, 27 vector instructions): pointcov_gen.hpp.
 // RAGGED: the "irregular X" instantiation.  Either the sketch width is not a multiple of 16 (K + p is the
 // caller's choice), so the last columns of the X tile do not exist, or X is only 8-byte aligned (n odd as its
 // leading dimension).  It keeps the 16-byte stream of the operator and loads the X pairs per column, predicated,
@@ -168,7 +120,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   constexpr int A_ELEMS = TRANS_A ? BMT * BKP : BK * BMP;
   constexpr int B_ELEMS = NT * 16 * BKP;
   constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
-  extern __shared__ double smem[];   // [2][A tile | B tile]
+  extern __shared__ double smem_raw[];   // [GEN 2: 64-entry table] [2][A tile | B tile]
+  double* const smem = smem_raw + (GEN == 2 ? 64 : 0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -275,15 +228,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   double p0x = 0.0, p0y = 0.0, p0z = 0.0, p1x = 0.0, p1y = 0.0, p1z = 0.0;      // GEN 2: this thread's two row points
   int64_t g_row0 = 0;
   GenPointK gq{};
+  double* const gtab = smem_raw;                    // GEN 2: sigma^2 2^(j/64) / 120, j = 0..63, at LDS offset 0 (the lookup's address is the index)
   if constexpr (GEN == 2) {                        // the points ride in the (otherwise unused) A argument: const __restrict__
     g_row0 = gen.roff + r0 + a_r;
     const int64_t i0 = (g_row0 < gen.ny) ? g_row0 : (int64_t)gen.ny - 1, i1 = (g_row0 + 1 < gen.ny) ? g_row0 + 1 : (int64_t)gen.ny - 1;
     p0x = A[4 * i0]; p0y = A[4 * i0 + 1]; p0z = A[4 * i0 + 2];
     p1x = A[4 * i1]; p1y = A[4 * i1 + 1]; p1z = A[4 * i1 + 2];
-    gq.inv_ell2 = gen.inv_ell2; gq.sigma2 = gen.sigma2; gq.gauss = (gen.kind == pointcov::GAUSSIAN) ? 1 : 0;
-    gq.c1 = (gen.kind == pointcov::MATERN32) ? 1.7320508075688772 : ((gen.kind == pointcov::MATERN52) ? 2.23606797749979 : 1.0);
-    gq.p1 = (gen.kind == pointcov::MATERN32 || gen.kind == pointcov::MATERN52) ? 1.0 : 0.0;
-    gq.p2 = (gen.kind == pointcov::MATERN52) ? (1.0 / 3.0) : 0.0;
+    gq = gen_point_setup(gen.dim, gen.kind);
+    gen_table_init(gtab, tid, gen.sigma2);
+    __syncthreads();
   }
   // GEN 1 (round 4): everything in BYTE offsets into the table, x coordinates pre-multiplied by the row length -- the offset of
   // an entry is |px - qx| + |py - qy| = two v_sad_u32 (sum of absolute differences) instead of eleven integer instructions
@@ -406,25 +359,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
       const int kw = __builtin_amdgcn_readfirstlane(a_k);                   // wave index: the pair slot's k is wave-uniform
       // ONE code path for interior and edge tiles: a second, select-free copy for interior tiles was measured SLOWER (633 vs
       // 584 ms per product at n = 2e5: the kernel outgrew the 64 KB instruction cache, 9040 instructions)
-      const bool ok_r0 = r0 + a_r < M, ok_r1 = r0 + a_r + 1 < M;
+      const int64_t row_first = gen.roff + r0;                                // uniform
+      const int krem = (kend - k0 < BK) ? (int)(kend - k0) : BK;              // reduction indices of this tile that exist
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it) {
         const int64_t kc = k0 + kw + KSTEP_NN * it;
-        const bool okk = kc < kend;
-        const int64_t gj = gen.koff + (okk ? kc : kbeg);
+        const bool okk = kw + KSTEP_NN * it < krem;                           // (32-bit: a scalar compare)
+        const int64_t gj = gen.koff + (okk ? kc : kbeg);                      // beyond the range: any valid point (the X rows there are zero)
         // provably uniform index -> scalar loads of the 32-byte record of the column point
         const int64_t gju = ((int64_t)__builtin_amdgcn_readfirstlane((int)(gj >> 32)) << 32) |
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(gj & 0xffffffff));
-        const double qx = A[4 * gju], qy = A[4 * gju + 1], qz = A[4 * gju + 2];
-        double dx = p0x - qx, dy = p0y - qy, dz = p0z - qz;
-        double v0 = gen_point_entry(gq, fma(dx, dx, fma(dy, dy, dz * dz)));
-        dx = p1x - qx; dy = p1y - qy; dz = p1z - qz;
-        double v1 = gen_point_entry(gq, fma(dx, dx, fma(dy, dy, dz * dz)));
-        v0 += (g_row0 == gju) ? gen.nugget : 0.0;
-        v1 += (g_row0 + 1 == gju) ? gen.nugget : 0.0;
+        const double qx = A[4 * gju], qy = A[4 * gju + 1];
+        double dx = p0x - qx, dy = p0y - qy;
+        double s0 = fma(dx, dx, dy * dy);
+        dx = p1x - qx; dy = p1y - qy;
+        double s1 = fma(dx, dx, dy * dy);
+        const int fl = gen_flags(gq.flags);
+        if (fl & 1) {
+          const double qz = A[4 * gju + 2];
+          const double dz0 = p0z - qz, dz1 = p1z - qz;
+          s0 = fma(dz0, dz0, s0); s1 = fma(dz1, dz1, s1);
+        }
         double2 pr;
-        pr.x = (okk && ok_r0) ? v0 : 0.0;
-        pr.y = (okk && ok_r1) ? v1 : 0.0;
+        gen_point_pair(gq, fl, s0, s1, gtab, pr.x, pr.y);
+        const int rel = (int)(gju - row_first);                               // (point indices are 31-bit)
+        if ((unsigned)rel < (unsigned)BMT) {                                  // uniform: the diagonal crosses this slot
+          pr.x += (a_r == rel) ? gen.nugget : 0.0;
+          pr.y += (a_r + 1 == rel) ? gen.nugget : 0.0;
+        }
         *reinterpret_cast<double2*>(a_s + (a_k + KSTEP_NN * it) * BMP + a_r) = pr;
       }
     } else
@@ -600,7 +562,7 @@ template <int NT, bool TRANS_A, int GEN, int XMODE>
 static void launch_nt(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* A,
                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha,
                       double beta, double* slabs, int64_t kchunk, int nchunks_x, int wide, int tri, const GenA& gen, int64_t nitems) {
-  constexpr size_t shmem = 2 * ((TRANS_A ? BMT * BKP : BK * BMP) + NT * 16 * BKP) * sizeof(double);
+  constexpr size_t shmem = 2 * ((TRANS_A ? BMT * BKP : BK * BMP) + NT * 16 * BKP) * sizeof(double) + (GEN == 2 ? 64 * sizeof(double) : 0);
   static std::atomic<uint64_t> attr_mask{0};
   if (first_use_on_this_device(attr_mask))
     (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<NT, TRANS_A, GEN, XMODE>,
@@ -756,6 +718,13 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   }
 }
 
+void gemm_splitk_reduce(hipStream_t st, int64_t M, int64_t L, int nsplit, const double* slabs, double* C, int64_t ldc) {
+  const int64_t total = M * L;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, M, L, nsplit, slabs, C, ldc, 1.0, 0.0);
+}
+
 // Host launchers. `ws` must hold gemm_workspace_doubles(M, L, K) doubles (or be null if 0).
 void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, double alpha, const double* A,
               int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws) {
@@ -788,20 +757,31 @@ void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const dou
 // C (M x L) = G * B with G(i, k) = sigma2 kfun(|p_i - p_k| / ell) (+ nugget if i == k), i = roff + row, k = koff + reduction
 // index; pts4 = the points as 32-byte records (x, y, z, 0), npts of them, in device memory.  G is generated in the tile
 // loader, never stored (GEN 2 above).
-void gemm_f64_pointcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int kind, double inv_ell,
+void gemm_f64_pointcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int d, int kind,
                        double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
-                       int64_t ldc, double* ws) {
-  GenA g = {pts4, (int32_t)npts, kind, roff, koff, inv_ell * inv_ell, sigma2, nugget};
+                       int64_t ldc, double* ws, double* xpack) {
+  if (gemm_f64_pointcov_wide(st, M, L, K, pts4, npts, d, kind, sigma2, nugget, roff, koff, B, ldb, C, ldc, ws, xpack)) return;
+  GenA g = {pts4, (int32_t)npts, kind, roff, koff, 0.0, sigma2, nugget, (int32_t)d};
   gemm_launch(st, false, &g, M, L, K, 1.0, pts4, 2, B, ldb, 0.0, C, ldc, ws, 0, 2);      // A = the points (16-byte aligned records)
 }
-// pts (d x n, point i = column i) -> 32-byte records (x, y, z, 0)
-__global__ __launch_bounds__(256) void pointcov_pad_kernel(const double* __restrict__ pts, int d, int64_t n, double* __restrict__ out) {
+// the factor the points are scaled by, so that the squared distance of two records is the squared ARGUMENT of the kernel's
+// exponential: c1 / ell (c1 = 1, sqrt 3, sqrt 5 for exponential, Matern 3/2, 5/2), 1 / (ell sqrt 2) for the Gaussian
+double pointcov_point_scale(int kind, double inv_ell) {
+  switch (kind) {
+    case pointcov::GAUSSIAN: return inv_ell * 0.70710678118654752440;
+    case pointcov::MATERN32: return inv_ell * 1.7320508075688772;
+    case pointcov::MATERN52: return inv_ell * 2.23606797749979;
+    default: return inv_ell;
+  }
+}
+// pts (d x n, point i = column i) -> 32-byte records scale * (x, y, z, 0)
+__global__ __launch_bounds__(256) void pointcov_pad_kernel(const double* __restrict__ pts, int d, int64_t n, double scale, double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  for (int a = 0; a < 4; ++a) out[4 * i + a] = (a < d) ? pts[i * d + a] : 0.0;
+  for (int a = 0; a < 4; ++a) out[4 * i + a] = (a < d) ? scale * pts[i * d + a] : 0.0;
 }
-void pointcov_pad_points(hipStream_t st, const double* pts, int d, int64_t n, double* out4) {
-  hipLaunchKernelGGL(pointcov_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pts, d, n, out4);
+void pointcov_pad_points(hipStream_t st, const double* pts, int d, int64_t n, double scale, double* out4) {
+  hipLaunchKernelGGL(pointcov_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pts, d, n, scale, out4);
 }
 
 }}  // namespace gsi::hipk

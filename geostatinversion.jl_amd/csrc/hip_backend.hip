@@ -268,9 +268,10 @@ class HipBackend : public Backend {
     if (!panels) {
       const int64_t npts = std::max(roff + m, koff + k);
       Scratch p4(this, (size_t)4 * npts);                  // the points as 32-byte records (x, y, z, 0): one scalar load each
-      hipk::pointcov_pad_points(st_, pts, d, npts, p4.p);
-      double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, k));
-      hipk::gemm_f64_pointcov(st_, m, l, k, p4.p, npts, kind, 1.0 / ell, sigma2, nugget, roff, koff, B, ldb, C, ldc, ws);
+      hipk::pointcov_pad_points(st_, pts, d, npts, hipk::pointcov_point_scale(kind, 1.0 / ell), p4.p);
+      double* ws = gemm_ws(hipk::gemm_pointcov_workspace_doubles(m, l, k));
+      Scratch xp(this, hipk::gemm_pointcov_pack_doubles(m, l, k));   // the wide kernel streams a tile-ordered copy of the sketch panel
+      hipk::gemm_f64_pointcov(st_, m, l, k, p4.p, npts, d, kind, sigma2, nugget, roff, koff, B, ldb, C, ldc, ws, xp.p);
       check_launch("gemm_nn_pointcov (in-loader generator)");
       return;
     }
@@ -1138,8 +1139,8 @@ class HipBackend : public Backend {
  private:
   struct Scratch {                 // a pooled temporary that goes back to the block cache on every exit path
     HipBackend* be; double* p;
-    Scratch(HipBackend* b, size_t doubles) : be(b), p(b->alloc(doubles)) {}
-    ~Scratch() { be->release(p); }
+    Scratch(HipBackend* b, size_t doubles) : be(b), p(doubles ? b->alloc(doubles) : nullptr) {}
+    ~Scratch() { if (p) be->release(p); }
     Scratch(const Scratch&) = delete;
     Scratch& operator=(const Scratch&) = delete;
   };

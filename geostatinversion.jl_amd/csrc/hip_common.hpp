@@ -40,10 +40,21 @@ void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const dou
 
 // ---- pointcov.hip: row panels of a scattered-point covariance ----
 // the scattered-point covariance generated inside the contraction's tile loader (gemm_f64.hip, GEN 2); pts4: 32-byte records
-void gemm_f64_pointcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int kind, double inv_ell,
+void gemm_f64_pointcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int d, int kind,
                        double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
-                       int64_t ldc, double* ws);
-void pointcov_pad_points(hipStream_t st, const double* pts, int d, int64_t n, double* out4);
+                       int64_t ldc, double* ws, double* xpack);
+double pointcov_point_scale(int kind, double inv_ell);
+// pointcov_gemm.hip: the same product with 64-row x 320-column tiles (every entry generated once for sketches of up to 320
+// columns); false = not applicable (L <= 160, GSI_POINTCOV_WIDE=0, X beyond 32-bit tile offsets)
+bool gemm_f64_pointcov_wide(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int d, int kind,
+                            double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
+                            int64_t ldc, double* ws, double* xpack);
+size_t gemm_pointcov_workspace_doubles(int64_t M, int64_t L, int64_t K);   // covers both tilings
+size_t gemm_pointcov_pack_doubles(int64_t M, int64_t L, int64_t K);        // the wide kernel's packed copy of X (0: not its product)
+int gemm_choose_split(int64_t nwg, int64_t K);
+// C = sum over the nsplit slabs (M x L each, leading dimension M), fixed order
+void gemm_splitk_reduce(hipStream_t st, int64_t M, int64_t L, int nsplit, const double* slabs, double* C, int64_t ldc);
+void pointcov_pad_points(hipStream_t st, const double* pts, int d, int64_t n, double scale, double* out4);
 void pointcov_panel(hipStream_t st, double* P, int64_t ldp, int64_t rows, int64_t cols, const double* pts,
                     const pointcov::Params& prm, int64_t roff, int64_t koff);
 

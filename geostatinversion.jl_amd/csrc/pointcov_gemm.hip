@@ -1,0 +1,342 @@
+// pointcov_gemm.hip -- C (M x L) = G * X for the covariance of SCATTERED points, G(i, j) = sigma2 k(|p_i - p_j| / ell)
+// (+ nugget on the diagonal), with 64-row x 320-column output tiles: every entry of G is generated ONCE per product for
+// sketches of up to 320 columns (SURVEY.md 8b "entries generated in the tile loader"; RandMatFact.jl:55,70 are the products).
+//
+// Why a second kernel beside gemm_f64.hip's GEN 2 path (128 rows x 160 columns per workgroup): on gfx950 an fp64 MFMA holds the
+// vector ALU, so the generator's vector instructions ADD to the matrix time -- measured 2.0-2.6 ns per wave
+// instruction whatever the instruction (tools/valu_f64_rates.hip; v_rsq_f64 7 ns).  At l = 320 the 160-column kernel walks the
+// reduction twice and generates every entry twice.  Here a workgroup owns ALL 320 columns of 64 rows: the same eight waves with
+// the same 32 x 80 wave tile (2 row groups x 4 column quarters instead of 4 x 2), the same 0.7 LDS reads per MFMA, half the
+// generator work per flop.  The price is the X tile: 320 columns x 8 bytes x depth must sit in LDS twice (double buffering), so the
+// reduction depth per tile is 16 instead of 32 (2 x 55 KB), i.e. one barrier per 40 MFMAs of a wave instead of 80.
+//
+// Per tile of 16 reduction indices: wave w generates the two columns k = 2w, 2w + 1 of the 64 x 16 tile of G, lane = row -- the row
+// point stays in registers for the whole kernel, the two column points are wave-uniform scalar loads of 32-byte records, and the
+// two entries are evaluated side by side (pointcov_gen.hpp: pre-scaled points, v_rsq_f64 + one Goldschmidt step + residual,
+// table-driven exponential; 27 vector instructions per entry).  X goes HBM/L2 -> registers two tiles ahead -> LDS, as in
+// gemm_f64.hip.  Rows beyond M are generated from a clamped index and never stored; reduction indices beyond the range meet zero
+// rows of the X tile.  Split-K with per-split slabs and the fixed-order reduction of gemm_f64.hip when the row blocks would not
+// fill the chip (row shards on 8 GPUs).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+#include "hip_common.hpp"
+#include "pointcov_gen.hpp"
+
+namespace gsi { namespace hipk {
+namespace {
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int WBM = 64;            // rows of C per workgroup
+constexpr int WBK = 16;            // reduction depth per LDS tile
+constexpr int WBKP = WBK + 2;      // padded k stride of the X image [column][k] (WBKP / 2 odd: conflict-free ds_read_b64)
+constexpr int WBMP = WBM + 16;     // padded row stride of the G image [k][row]
+constexpr int WTHREADS = 512;
+constexpr int WCSTEP = 2 * WTHREADS / WBK;   // X tile: column advance per pair slot (64)
+
+struct PointGen {
+  int32_t npts, kind, dim, pad;
+  int64_t roff, koff;      // global index of row 0 of the product / of reduction index 0
+  double sigma2, nugget;
+};
+
+template <int NTQ>
+__global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
+    int64_t M, int64_t L, int64_t K, const double* __restrict__ P4, const double2* __restrict__ Xp, int64_t ktiles,
+    double* __restrict__ C, int64_t ldc, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, PointGen gen) {
+  constexpr int NT = 4 * NTQ;                 // 16-column tiles per workgroup
+  constexpr int A_ELEMS = WBK * WBMP;
+  constexpr int B_ELEMS = NT * 16 * WBKP;
+  constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
+  extern __shared__ double smem_raw[];        // [64-entry table] [2][G tile | X tile]
+  double* const gtab = smem_raw;
+  double* const smem = smem_raw + 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave & 1;          // row group: C rows 32 rg .. of the workgroup tile
+  const int cq = wave >> 1;         // column quarter: 16-column tiles cq * NTQ ..
+  const int ch = wave >> 2;         // which of the two waves of a SIMD (w, w + 4): their chores are staggered
+  const int jl = lane & 15;
+  const int kk = lane >> 4;
+  const int64_t tile_lin = blockIdx.x;
+  const int split = (int)blockIdx.y;
+  const int64_t r0 = (tile_lin / nchunks_x) * WBM;
+  const int64_t c0 = (tile_lin % nchunks_x) * (NT * 16);
+  const int64_t kbeg = (int64_t)split * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  const int64_t ntiles = (kend > kbeg) ? (kend - kbeg + WBK - 1) / WBK : 0;
+
+  double4_t acc[2][NTQ];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) acc[h][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  // X tile: pair (k = 2 (tid % 8), column = tid / 8 + 64 it), it < NTQ: one 16-byte load and one ds_write_b128 per pair.  X arrives
+  // PACKED (pointcov_pack_kernel): tile kt of column chunk c is the contiguous block [it][tid] of pairs -- a wave's load
+  // instruction reads 1 KB in a row and a tile touches one 40 KB run instead of 128 bytes in each of 320 columns 8 n bytes apart
+  // (measured: the strided form cost 34 ms of a 480 ms product in misses alone), zero-filled beyond L and K: no predicates here.
+  double2 b_reg[2][NTQ];
+  const int b_c = tid >> 3;
+  const int b_k = 2 * (tid & 7);
+  const double2* const Xbase = Xp + ((tile_lin % nchunks_x) * ktiles * NTQ) * WTHREADS + tid;
+
+  // this thread's row point (fixed for the whole kernel)
+  const int64_t row_first = gen.roff + r0;
+  double px, py, pz;
+  {
+    const int64_t gr = row_first + lane;
+    const int64_t i0 = (gr < gen.npts) ? gr : (int64_t)gen.npts - 1;
+    px = P4[4 * i0]; py = P4[4 * i0 + 1]; pz = P4[4 * i0 + 2];
+  }
+  const GenPointK gq = gen_point_setup(gen.dim, gen.kind);
+  gen_table_init(gtab, tid, gen.sigma2);
+  __syncthreads();
+
+  auto prefetch = [&](int64_t k0, auto SET) __attribute__((always_inline)) {
+    constexpr int set = decltype(SET)::value;
+    const double2* src = Xbase + (k0 / WBK) * (NTQ * WTHREADS);   // (k0 is a multiple of the tile depth)
+#pragma unroll
+    for (int it = 0; it < NTQ; ++it) {                         // (element-wise: the struct copy kept the array in scratch memory)
+      const double2 v = src[it * WTHREADS];
+      b_reg[set][it].x = v.x; b_reg[set][it].y = v.y;
+    }
+  };
+
+  // The two column points of this wave's slots, ONE tile ahead, through the VECTOR memory pipe (every lane the same address:
+  // one line per load).  As scalar loads they shared the counter of the LDS reads -- every wait for a fragment waited for them
+  // too (measured: 22 ms of a 517 ms product).
+  double2 qxy0, qxy1;
+  double qz0 = 0.0, qz1 = 0.0;
+  int64_t qg0 = 0, qg1 = 0;                                   // their indices (uniform)
+  uint32_t vzero = 0;
+  asm volatile("" : "+v"(vzero));                             // an opaque vector zero: keeps the loads out of the scalar unit
+  auto load_points = [&](int64_t k0) __attribute__((always_inline)) {
+    const int kw = 2 * wave;                                                  // this wave's two columns of the G tile
+    const int krem = (kend - k0 < WBK) ? (int)((kend - k0 > 0) ? kend - k0 : 0) : WBK;   // reduction indices of that tile that exist
+    // beyond the range: any valid point (the X rows there are zero)
+    const int64_t g0 = gen.koff + ((kw < krem) ? k0 + kw : kbeg), g1 = gen.koff + ((kw + 1 < krem) ? k0 + kw + 1 : kbeg);
+    qg0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(g0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(g0 & 0xffffffff));
+    qg1 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(g1 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(g1 & 0xffffffff));
+    const char* const pb = reinterpret_cast<const char*>(P4);
+    qxy0 = *reinterpret_cast<const double2*>(pb + 32 * qg0 + vzero);
+    qxy1 = *reinterpret_cast<const double2*>(pb + 32 * qg1 + vzero);
+    if (gq.flags & 1) {
+      qz0 = *reinterpret_cast<const double*>(pb + 32 * qg0 + 16 + vzero);
+      qz1 = *reinterpret_cast<const double*>(pb + 32 * qg1 + 16 + vzero);
+    }
+  };
+
+  auto stage = [&](int buf, auto SET, int64_t k0) __attribute__((always_inline)) {
+    constexpr int set = decltype(SET)::value;
+    double* a_s = smem + buf * BUF_ELEMS;
+    double* b_s = a_s + A_ELEMS;
+    {
+      const int kw = 2 * wave;
+      double dx = px - qxy0.x, dy = py - qxy0.y;
+      double s0 = fma(dx, dx, dy * dy);
+      dx = px - qxy1.x; dy = py - qxy1.y;
+      double s1 = fma(dx, dx, dy * dy);
+      const int fl = gen_flags(gq.flags);
+      if (fl & 1) {
+        const double dz0 = pz - qz0, dz1 = pz - qz1;
+        s0 = fma(dz0, dz0, s0); s1 = fma(dz1, dz1, s1);
+      }
+      double v0, v1;
+      gen_point_pair(gq, fl, s0, s1, gtab, v0, v1);
+      const int rel0 = (int)(qg0 - row_first), rel1 = (int)(qg1 - row_first);  // (point indices are 31-bit)
+      if ((unsigned)rel0 < (unsigned)WBM || (unsigned)rel1 < (unsigned)WBM) {  // uniform: the diagonal crosses this slot
+        v0 += (lane == rel0) ? gen.nugget : 0.0;
+        v1 += (lane == rel1) ? gen.nugget : 0.0;
+      }
+      a_s[kw * WBMP + lane] = v0;
+      a_s[(kw + 1) * WBMP + lane] = v1;
+      load_points(k0 + WBK);                                                    // the next tile's (clamped when there is none)
+    }
+#pragma unroll
+    for (int it = 0; it < NTQ; ++it)
+      *reinterpret_cast<double2*>(b_s + (b_c + WCSTEP * it) * WBKP + b_k) = b_reg[set][it];
+  };
+
+  double fa[2], fan[2];
+  double fb[NTQ];
+  const int t0 = cq * NTQ;
+  auto a_frag = [&](int buf, int s, int h) -> double {
+    return (smem + buf * BUF_ELEMS)[(4 * s + kk) * WBMP + 32 * rg + 16 * h + jl];
+  };
+  auto b_frag = [&](int buf, int s, int t) -> double {
+    return (smem + buf * BUF_ELEMS + A_ELEMS)[(16 * (t0 + t) + jl) * WBKP + 4 * s + kk];
+  };
+
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  auto do_tile = [&](int64_t t, auto PAR) __attribute__((always_inline)) {
+    constexpr int cur = decltype(PAR)::value;
+    using NextSet = std::integral_constant<int, cur ^ 1>;
+    auto chores = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_s_setprio(0);
+      if (t + 1 < ntiles) stage(cur ^ 1, NextSet{}, kbeg + (t + 1) * WBK);       // tile t+1: registers / generator -> other LDS buffer
+      if (t + 3 < ntiles) prefetch(kbeg + (t + 3) * WBK, NextSet{});              // HBM -> the set just drained
+      __builtin_amdgcn_s_setprio(1);
+    };
+#pragma unroll
+    for (int s = 0; s < WBK / 4; ++s) {
+      if (s == 1 && ch == 0) chores();
+      if (s == 2 && ch != 0) chores();
+      const bool last = (s + 1 == WBK / 4);
+      // the one barrier per tile: tile t+1 becomes visible, and after this step's MFMAs nobody reads buffer `cur` any more
+      if (last) __syncthreads();
+      const int nbuf = last ? (cur ^ 1) : cur;
+      const int ns = last ? 0 : s + 1;
+      const bool more = !last || (t + 1 < ntiles);
+      if (more) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) fan[h] = a_frag(nbuf, ns, h);
+      }
+#pragma unroll
+      for (int tt = 0; tt < NTQ; ++tt) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          acc[h][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tt], fa[h], acc[h][tt], 0, 0, 0);
+        if (more) fb[tt] = b_frag(nbuf, ns, tt);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) fa[h] = fan[h];
+    }
+  };
+
+  if (ntiles > 0) {
+    load_points(kbeg);
+    prefetch(kbeg, Set0{});
+    if (ntiles > 1) prefetch(kbeg + WBK, Set1{});
+    stage(0, Set0{}, kbeg);
+    if (ntiles > 2) prefetch(kbeg + 2 * WBK, Set0{});
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) fa[h] = a_frag(0, 0, h);
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) fb[t] = b_frag(0, 0, t);
+    int64_t t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+      do_tile(t, Set0{});
+      do_tile(t + 1, Set1{});
+    }
+    if (t < ntiles) do_tile(t, Set0{});
+  }
+
+  // epilogue: lane holds D[i = kk + 4 reg][j = jl]  ->  C[row = .. + jl][col = c0 + 16 (t0 + t) + kk + 4 reg]
+  double* const W = (slabs != nullptr) ? slabs + (int64_t)split * M * L : nullptr;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t row = r0 + 32 * rg + 16 * h + jl;
+    if (row < M) {
+#pragma unroll
+      for (int t = 0; t < NTQ; ++t) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int64_t col = c0 + 16 * (t0 + t) + kk + 4 * reg;
+          if (col < L) {
+            if (W != nullptr) W[row + col * M] = acc[h][t][reg];
+            else C[row + col * ldc] = acc[h][t][reg];
+          }
+        }
+      }
+    }
+  }
+}
+
+// X (K x L, leading dimension ldb) -> the tile stream of the kernel above: [chunk][k tile][it][tid] pairs (k = 16 kt + 2 (tid % 8)
+// + {0, 1}, column = 64 ntq chunk + tid / 8 + 64 it), zero beyond K and L.  One read and one write of the sketch panel.
+__global__ __launch_bounds__(WTHREADS) void pointcov_pack_kernel(int64_t L, int64_t K, const double* __restrict__ B, int64_t ldb,
+                                                                 int ntq, int64_t ktiles, double2* __restrict__ Xp) {
+  const int tid = threadIdx.x;
+  const int64_t kt = blockIdx.x, chunk = blockIdx.y;
+  const int64_t k = kt * WBK + 2 * (tid & 7);
+  for (int it = 0; it < ntq; ++it) {
+    const int64_t c = chunk * 64 * ntq + (tid >> 3) + WCSTEP * it;
+    double2 v;
+    v.x = (c < L && k < K) ? B[k + c * ldb] : 0.0;
+    v.y = (c < L && k + 1 < K) ? B[k + 1 + c * ldb] : 0.0;
+    Xp[((chunk * ktiles + kt) * ntq + it) * WTHREADS + tid] = v;
+  }
+}
+
+template <int NTQ>
+void launch_wide(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* P4, const double2* Xp, int64_t ktiles,
+                 double* C, int64_t ldc, double* slabs, int64_t kchunk, int nchunks, const PointGen& gen) {
+  constexpr size_t shmem = (64 + 2 * (WBK * WBMP + 4 * NTQ * 16 * WBKP)) * sizeof(double);
+  static std::atomic<uint64_t> attr_mask{0};
+  if (first_use_on_this_device(attr_mask))
+    (void)hipFuncSetAttribute((const void*)pointcov_wide_kernel<NTQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL((pointcov_wide_kernel<NTQ>), grid, dim3(WTHREADS), shmem, st, M, L, K, P4, Xp, ktiles, C, ldc, slabs, kchunk,
+                     nchunks, gen);
+}
+
+// the tiling of a product with L columns: chunks of 64 ntq columns, ntq in 3..5 (L > 160)
+struct WideTiling { int ntq; int64_t nchunks, active; int nsplit; int64_t kchunk; int ns_eff; };
+WideTiling wide_tiling(int64_t M, int64_t L, int64_t K) {
+  WideTiling w;
+  const int64_t tiles = (L + 15) / 16;
+  const int64_t nch = (tiles + 19) / 20;
+  const int64_t nt = (tiles + nch - 1) / nch;                 // balanced: 11 .. 20 tiles per chunk
+  w.ntq = (int)((nt + 3) / 4);
+  if (w.ntq < 3) w.ntq = 3;
+  w.nchunks = (L + 64 * w.ntq - 1) / (64 * w.ntq);
+  w.active = ((M + WBM - 1) / WBM) * w.nchunks;
+  w.nsplit = (K > 0) ? gemm_choose_split(w.active, K) : 1;
+  w.kchunk = (K + w.nsplit - 1) / w.nsplit;
+  w.kchunk = ((w.kchunk + 31) / 32) * 32;
+  if (w.kchunk == 0) w.kchunk = 32;
+  w.ns_eff = (K > 0) ? (int)((K + w.kchunk - 1) / w.kchunk) : 1;
+  return w;
+}
+bool wide_applies(int64_t L) {
+  static const bool on = !(getenv("GSI_POINTCOV_WIDE") != nullptr && getenv("GSI_POINTCOV_WIDE")[0] == '0');   // A/B
+  return on && L > 160;
+}
+}  // namespace
+
+size_t gemm_pointcov_workspace_doubles(int64_t M, int64_t L, int64_t K) {
+  size_t need = gemm_workspace_doubles(M, L, K);
+  if (L > 160) {
+    const WideTiling w = wide_tiling(M, L, K);
+    if (w.ns_eff > 1) need = std::max(need, (size_t)w.ns_eff * (size_t)M * (size_t)L);
+  }
+  return need;
+}
+// doubles of the packed copy of X the wide kernel streams (0: the product is not that kernel's)
+size_t gemm_pointcov_pack_doubles(int64_t M, int64_t L, int64_t K) {
+  if (M <= 0 || L <= 0 || K <= 0 || !wide_applies(L)) return 0;
+  const WideTiling w = wide_tiling(M, L, K);
+  const int64_t ktiles = (K + WBK - 1) / WBK;
+  return (size_t)w.nchunks * (size_t)ktiles * (size_t)(64 * w.ntq) * (size_t)WBK;
+}
+
+// returns false when the product is not this kernel's (narrow sketches: gemm_f64.hip's 160-column kernel generates once anyway).
+// xpack: gemm_pointcov_pack_doubles(M, L, K) doubles, 16-byte aligned.
+bool gemm_f64_pointcov_wide(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int d, int kind,
+                            double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
+                            int64_t ldc, double* ws, double* xpack) {
+  if (M <= 0 || L <= 0 || K <= 0 || xpack == nullptr || !wide_applies(L)) return false;
+  const WideTiling w = wide_tiling(M, L, K);
+  const int64_t ktiles = (K + WBK - 1) / WBK;
+  double2* const Xp = reinterpret_cast<double2*>(xpack);
+  hipLaunchKernelGGL(pointcov_pack_kernel, dim3((unsigned)ktiles, (unsigned)w.nchunks), dim3(WTHREADS), 0, st, L, K, B, ldb, w.ntq,
+                     ktiles, Xp);
+  const PointGen gen = {(int32_t)npts, kind, d, 0, roff, koff, sigma2, nugget};
+  dim3 grid((unsigned)w.active, (unsigned)w.ns_eff, 1);
+  double* slabs = (w.ns_eff > 1) ? ws : nullptr;
+  switch (w.ntq) {
+    case 3: launch_wide<3>(grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
+    case 4: launch_wide<4>(grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
+    default: launch_wide<5>(grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
+  }
+  if (w.ns_eff > 1) gemm_splitk_reduce(st, M, L, w.ns_eff, slabs, C, ldc);
+  return true;
+}
+
+}}  // namespace gsi::hipk

@@ -1326,7 +1326,11 @@ def _dense_pointcov(P, kind, ell, sigma2, nugget):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,d,kind,l", [(300, 2, "exponential", 7), (1000, 3, "gaussian", 48), (777, 1, "matern32", 33),
-                                         (2500, 2, "matern52", 160), (4097, 2, "exponential", 320)])
+                                         (2500, 2, "matern52", 160), (4097, 2, "exponential", 320),
+                                         # the 64-row x 320-column kernel (pointcov_gemm.hip: 160 < l): ragged widths, three
+                                         # dimensions, fewer rows than one tile, two column chunks, an even leading dimension
+                                         (1500, 3, "matern52", 250), (3000, 2, "gaussian", 400), (50, 2, "exponential", 170),
+                                         (5000, 1, "matern32", 192), (2048, 3, "exponential", 320)])
 def test_pointcov_implicit_products(gsi, ctx, n, d, kind, l):
     rng = np.random.default_rng(n + l)
     P = rng.uniform(0.0, 30.0, size=(d, n))
