@@ -112,7 +112,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   // operand tiles are requested BEFORE the result stores are issued (vmcnt retires in order on gfx9: loads queued behind 80
   // stores would wait for all of them; the staging registers are dead at that point, so this costs no register), and the
   // stores drain under the next tile's matrix work.
-  constexpr bool CANP = (GEN == 0 && XMODE == 0);
+  // Not for the transposed form: its launches are split-K or symmetric, never persistent -- and the extra live state of the
+  // work-item loop cost the TN tile loop registers it does not have (measured on one box, same process: S'X 11.8 -> 10.8 ms
+  // with the loop compiled out; 32-bit tile counters on top of that: 13.0 -- the allocator sits on a cliff in this kernel).
+  constexpr bool CANP = (GEN == 0 && XMODE == 0 && !TRANS_A);
   const bool persist = CANP && nitems > 0;
   constexpr bool RAGGED = XMODE != 0;
   constexpr bool BIG = XMODE == 2;
@@ -695,7 +698,7 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   const bool irregular_x = a_ok && (!b_ok || L % ((int64_t)nt * 16) != 0);
   const int wide = a_ok ? 1 : 0;
   const int xmode = big ? 2 : (irregular_x ? 1 : 0);
-  if (persist_on && gen == nullptr && xmode == 0 && tri == 0 && ns_eff == 1 && (ncus & 7) == 0 && active >= 2 * (int64_t)ncus &&
+  if (persist_on && gen == nullptr && !transA && xmode == 0 && tri == 0 && ns_eff == 1 && (ncus & 7) == 0 && active >= 2 * (int64_t)ncus &&
       K <= 128 * BK) {
     nitems = active;
     grid.x = (unsigned)ncus;
