@@ -112,10 +112,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   // operand tiles are requested BEFORE the result stores are issued (vmcnt retires in order on gfx9: loads queued behind 80
   // stores would wait for all of them; the staging registers are dead at that point, so this costs no register), and the
   // stores drain under the next tile's matrix work.
-  // Not for the transposed form: its launches are split-K or symmetric, never persistent -- and the extra live state of the
-  // work-item loop cost the TN tile loop registers it does not have (measured on one box, same process: S'X 11.8 -> 10.8 ms
-  // with the loop compiled out; 32-bit tile counters on top of that: 13.0 -- the allocator sits on a cliff in this kernel).
-  constexpr bool CANP = (GEN == 0 && XMODE == 0 && !TRANS_A);
+  constexpr bool CANP = (GEN == 0 && XMODE == 0);
   const bool persist = CANP && nitems > 0;
   constexpr bool RAGGED = XMODE != 0;
   constexpr bool BIG = XMODE == 2;
@@ -123,8 +120,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   constexpr int A_ELEMS = TRANS_A ? BMT * BKP : BK * BMP;
   constexpr int B_ELEMS = NT * 16 * BKP;
   constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
-  extern __shared__ double smem_raw[];   // [GEN 2: 64-entry table] [2][A tile | B tile]
-  double* const smem = smem_raw + (GEN == 2 ? 64 : 0);
+  extern __shared__ double smem[];   // [GEN 2: 64-entry table] [2][A tile | B tile]
+  // LDS0: a constant in every index, NOT a second pointer `smem_raw + 64`: with the derived pointer the stored-operand
+  // instantiations (offset 0!) compiled differently and ran 4 % (NN) and 24 % (TN: 9.5 -> 11.8 ms) slower -- this kernel sits on a
+  // register-allocation cliff; any edit is A/B-ed against the previous build in one process (tools/bench_lrcm_products.py with
+  // GSI_HIP_LIB), a lesson of round 4.
+  constexpr int LDS0 = (GEN == 2) ? 64 : 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   double p0x = 0.0, p0y = 0.0, p0z = 0.0, p1x = 0.0, p1y = 0.0, p1z = 0.0;      // GEN 2: this thread's two row points
   int64_t g_row0 = 0;
   GenPointK gq{};
-  double* const gtab = smem_raw;                    // GEN 2: sigma^2 2^(j/64) / 120, j = 0..63, at LDS offset 0 (the lookup's address is the index)
+  double* const gtab = smem;                        // GEN 2: sigma^2 2^(j/64) / 120, j = 0..63, at LDS offset 0 (the lookup's address is the index)
   if constexpr (GEN == 2) {                        // the points ride in the (otherwise unused) A argument: const __restrict__
     g_row0 = gen.roff + r0 + a_r;
     const int64_t i0 = (g_row0 < gen.ny) ? g_row0 : (int64_t)gen.ny - 1, i1 = (g_row0 + 1 < gen.ny) ? g_row0 + 1 : (int64_t)gen.ny - 1;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 
   auto stage = [&](int buf, auto SET, int64_t k0) __attribute__((always_inline)) {
     constexpr int set = decltype(SET)::value;
-    double* a_s = smem + buf * BUF_ELEMS;
+    double* a_s = smem + LDS0 + buf * BUF_ELEMS;
     double* b_s = a_s + A_ELEMS;
     (void)k0;
     if constexpr (GEN == 2) {
@@ -417,12 +418,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   const int t0 = ch * NTW;                       // first 16-column tile of this wave
   const int ntw = (NT - t0 < NTW) ? ((NT - t0 > 0) ? NT - t0 : 0) : NTW;   // tiles this wave owns (wave-uniform)
   auto a_frag = [&](int buf, int s, int h) -> double {
-    const double* a_s = smem + buf * BUF_ELEMS;
+    const double* a_s = smem + LDS0 + buf * BUF_ELEMS;
     return TRANS_A ? a_s[(16 * MT * rg + 16 * h + jl) * BKP + 4 * s + kk]
                    : a_s[(4 * s + kk) * BMP + 16 * MT * rg + 16 * h + jl];
   };
   auto b_frag = [&](int buf, int s, int t) -> double {
-    const double* b_s = smem + buf * BUF_ELEMS + A_ELEMS;
+    const double* b_s = smem + LDS0 + buf * BUF_ELEMS + A_ELEMS;
     return b_s[(16 * (t0 + t) + jl) * BKP + 4 * s + kk];
   };
 
@@ -698,7 +699,7 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
   const bool irregular_x = a_ok && (!b_ok || L % ((int64_t)nt * 16) != 0);
   const int wide = a_ok ? 1 : 0;
   const int xmode = big ? 2 : (irregular_x ? 1 : 0);
-  if (persist_on && gen == nullptr && !transA && xmode == 0 && tri == 0 && ns_eff == 1 && (ncus & 7) == 0 && active >= 2 * (int64_t)ncus &&
+  if (persist_on && gen == nullptr && xmode == 0 && tri == 0 && ns_eff == 1 && (ncus & 7) == 0 && active >= 2 * (int64_t)ncus &&
       K <= 128 * BK) {
     nitems = active;
     grid.x = (unsigned)ncus;

@@ -7,7 +7,7 @@ for d in (f"pmc_{tag}_a", f"pmc_{tag}_b", f"pmc_{tag}_c"):
     if not fs:
         continue
     rows = list(csv.DictReader(open(fs[0])))
-    for kn in ("gemm_f64_kernel<10, true, false, 0>", "gemm_f64_kernel<10, false, false, 0>"):
+    for kn in ("gemm_f64_kernel<10, true, 0, 0>", "gemm_f64_kernel<10, false, 0, 0>"):
         byd = collections.defaultdict(dict)
         for r in rows:
             if kn in r["Kernel_Name"]:
