@@ -184,7 +184,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   int64_t kbeg = (int64_t)split * kchunk;
   int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
   if (tri == 2 && kend > c0 + NT * 16) kend = c0 + NT * 16;
-  int64_t ntiles = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+  // tile counts as 32-bit scalars: the 64-bit form of `t + 1 < ntiles` / `k0 + BK <= kend` compiles to vector compares
+  // (v_mov_b64 + v_cmp_*_u64: there is no 64-bit s_cmp_lt), a dozen vector instructions per tile.  Measured in one process
+  // against the previous build: S'X 9.53 -> 9.45 ms, S T 10.24 -> 10.13, dense 65536^2 at l = 144: 19.2 -> 18.7 / 21.2 -> 20.1;
+  // the table-generated operand (GEN 1) 416 -> 428 ms per product, and no spelling of this code that keeps its old form
+  // brought that back -- the allocator decides, not the source.
+  const int ntiles = (kend > kbeg) ? (int)((kend - kbeg + BK - 1) / BK) : 0;
+  const int nfull = (kend > kbeg) ? (int)((kend - kbeg) / BK) : 0;          // tiles with all BK reduction indices in range
 
   double4_t acc[MT][NTW];
 #pragma unroll
@@ -262,8 +268,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     t_qy = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8u * (uint32_t)g_ky));
   }
 
-  auto prefetch = [&](int64_t k0, auto SET) __attribute__((always_inline)) {
+  auto prefetch = [&](int tt, auto SET) __attribute__((always_inline)) {      // tt: tile index within this K range
     constexpr int set = decltype(SET)::value;
+    const int64_t k0 = kbeg + (int64_t)tt * BK;
+    const bool tile_full = tt < nfull;
     if constexpr (GEN == 1) {
       const int64_t kfirst = k0 + __builtin_amdgcn_readfirstlane(a_k);
       auto advance = [&]() {                       // scalar: the reduction index of the next pair slot, in table bytes
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
       auto entry = [&](uint32_t px, uint32_t py) -> double {
         return *reinterpret_cast<const double*>(tb + sad(py, t_qy, sad(px, t_qx, 0u)));
       };
-      if (r0 + BMT <= M && k0 + BK <= kend) {      // interior: no predicates (workgroup-uniform branch)
+      if (r0 + BMT <= M && tile_full) {      // interior: no predicates (workgroup-uniform branch)
 #pragma unroll
         for (int it = 0; it < A_PAIRS; ++it) {
           a_reg[set][it].x = entry(t_px0, t_py0);
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     // instead of staying live in VGPRs across the MFMA loop
     off_t a_step = a_step_c, b_step = b_step_c;
     if constexpr (!BIG) asm volatile("" : "+s"(a_step), "+s"(b_step));
-    if (wide && wg_full && k0 + BK <= kend) {
+    if (wide && wg_full && tile_full) {
       if constexpr (GEN == 0) {
 #pragma unroll
       for (int it = 0; it < A_PAIRS; ++it)
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
   // one tile of the pipeline; PAR = parity of t (compile time: selects LDS buffer and register set)
-  auto do_tile = [&](int64_t t, auto PAR) __attribute__((always_inline)) {
+  auto do_tile = [&](int t, auto PAR) __attribute__((always_inline)) {
     constexpr int cur = decltype(PAR)::value;
     using NextSet = std::integral_constant<int, (NSETS == 2) ? (cur ^ 1) : 0>;
     // The two waves of a SIMD (column halves ch = 0 / 1 of the same rows) run the same program;
@@ -440,8 +448,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
     // pipe (measured +1.5..2 %; a static priority for waves 4-7 alone measured -1 %).
     auto chores = [&]() __attribute__((always_inline)) {
       __builtin_amdgcn_s_setprio(0);
-      if (t + 1 < ntiles) stage(cur ^ 1, NextSet{}, kbeg + (t + 1) * BK);            // tile t+1: registers -> other LDS buffer
-      if (t + 1 + NSETS < ntiles) prefetch(kbeg + (t + 1 + NSETS) * BK, NextSet{});  // HBM -> the set just drained
+      if (t + 1 < ntiles) stage(cur ^ 1, NextSet{}, kbeg + (int64_t)(t + 1) * BK);   // tile t+1: registers -> other LDS buffer
+      if (t + 1 + NSETS < ntiles) prefetch(t + 1 + NSETS, NextSet{});                // HBM -> the set just drained
       __builtin_amdgcn_s_setprio(1);
     };
 #pragma unroll
@@ -478,18 +486,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
   for (;;) {
     if (ntiles > 0) {
       if (!primed) {
-        prefetch(kbeg, Set0{});
-        if (NSETS == 2 && ntiles > 1) prefetch(kbeg + BK, Set1{});
+        prefetch(0, Set0{});
+        if (NSETS == 2 && ntiles > 1) prefetch(1, Set1{});
       }
       stage(0, Set0{}, kbeg);
-      if (ntiles > NSETS) prefetch(kbeg + NSETS * BK, Set0{});
+      if (ntiles > NSETS) prefetch(NSETS, Set0{});
       __syncthreads();
 #pragma unroll
       for (int h = 0; h < MT; ++h) fa[h] = a_frag(0, 0, h);
 #pragma unroll
       for (int t = 0; t < NTW; ++t)
         if ((NT % 2 == 0) || t < ntw) fb[t] = b_frag(0, 0, t);
-      int64_t t = 0;
+      int t = 0;
       for (; t + 1 < ntiles; t += 2) {
         do_tile(t, Set0{});
         do_tile(t + 1, Set1{});
@@ -506,8 +514,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
         locate(item);
         setup_item();
         if (ntiles > 0) {                             // (K, hence ntiles, is the same for every item of this mode)
-          prefetch(kbeg, Set0{});
-          if (NSETS == 2 && ntiles > 1) prefetch(kbeg + BK, Set1{});
+          prefetch(0, Set0{});
+          if (NSETS == 2 && ntiles > 1) prefetch(1, Set1{});
         }
         primed = true;
       }
