@@ -366,8 +366,9 @@ def secondary_pointcov(gsi, ctx, barrier):
     X.close()
     Y.close()
     return {
-        "workload": f"implicit covariance exp(-d/45) of n = {n} SCATTERED points (given as coordinates), l = {l}: one product; row "
-                    "panels of A generated on a second stream, consumed by the stored-operand contraction (DESIGN.md 4.9)",
+        "workload": f"implicit covariance exp(-d/45) of n = {n} SCATTERED points (given as coordinates), l = {l}: one product; every "
+                    "entry generated once, inside the contraction's tile loader (64 x 320 output tiles, DESIGN.md 4.9)",
+        "contraction_frac_of_mfma_peak": 2.0 * n * n * l / out["points"] / 1e12 / PEAK_FP64_MFMA_TFLOPS,
         "ms_per_product": 1e3 * out["points"], "contraction_TFLOP/s": 2.0 * n * n * l / out["points"] / 1e12,
         "table_based_grid_operator_ms_per_product": 1e3 * out["table"],
         "table_based_grid_operator_TFLOP/s": 2.0 * n * n * l / out["table"] / 1e12,
