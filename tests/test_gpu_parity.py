@@ -1463,6 +1463,9 @@ def run_rank(rank, world, ctx, exchange, out):
     X = rng.standard_normal((333, 4))
     out["pointcov_mul"] = float(np.abs(pop.matmul(X) - Ap @ X).max())
     out["pointcov_mul_t"] = float(np.abs(pop.rmatmul_t(X) - Ap @ X).max())
+    Xw = rng.standard_normal((333, 200))                       # 160 < l: the 64 x 320-tile kernel with row / reduction offsets
+    out["pointcov_wide_mul"] = float(np.abs(pop.matmul(Xw) - Ap @ Xw).max())
+    out["pointcov_wide_mul_t"] = float(np.abs(pop.rmatmul_t(Xw) - Ap @ Xw).max())
     Om = rng.standard_normal((333, 24))
     Z, S = gsi.randsvd(pop, 16, 8, 2, Omega=Om, return_S=True)
     Zr, Sr, _ = orc.randsvd_full(Ap, 16, 8, 2, Om)
