@@ -63,6 +63,7 @@ struct FftPass {
   int lb, log2M0;           // lb = 0: natural layout
   int kind;                 // strided passes: 0 natural, 1 blocked / lines along axis 1, 2 blocked / lines along axis 2
   uint32_t BK0, OS, ks;     // block stride of k0 >> lb; stride of the tile's other index; stride between consecutive k of a line
+  int lsync;                // 1: stage boundaries order only the line's own waves (line_barrier); 0: workgroup barriers (A/B)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt -- every global load and store in
@@ -132,7 +133,21 @@ struct FftLine {            // what a thread knows about its line
   const double2* tabB;      // W_Ma^(64 b)
   int jt, tpl, L;           // index within the line, threads per line (Ma / points per thread), log2 Ma
   bool act;                 // writes anything at all (a thread past the tile's lines only keeps the barriers company)
+  int wpl;                  // waves per line (1: a wave holds whole lines)
 };
+
+// Barrier between the stages of ONE line (round 4).  A line belongs to tpl = Ma / 16 threads -- one wave at 1024 points, two at
+// 2048 -- and a stage boundary only orders the LDS traffic of that line's own waves.  With one wave per line (or several lines
+// per wave) there is nothing to wait for: the LDS executes a wave's instructions in order, a later ds_read of any lane sees
+// an earlier ds_write of any lane; only the compiler must not reorder them.  Measured at 512^3 (1024-point lines: 9 of the
+// fused item's 12 workgroup barriers gone): 134.5 -> 131.1 ms per 16 columns -- 2.6 %, which says the barriers were never
+// what the pass waits for.  With two waves per line an arrival counter in LDS (ds_add, poll) was built and measured SLOWER than
+// s_barrier (1000^2: 6.68 -> 6.95 ms) and removed: lines that span waves keep the workgroup barrier.
+// Fills and drains of a strided tile touch every line from every thread and keep the workgroup barrier too.
+__device__ __forceinline__ void line_barrier(const FftLine& f) {
+  if (f.wpl <= 1) { asm volatile("" ::: "memory"); return; }
+  lds_barrier();
+}
 
 // twiddle and NB R-point DFTs over the slots c + r NB.  Ns = 1 << lNs.
 template <int R, int NB, int SGN>
@@ -197,7 +212,8 @@ __device__ __forceinline__ void stage_gather(double2 (&v)[P], const FftLine& f, 
 // result in the slots (else the line ends up in LDS, behind a barrier).
 // `late` runs once, just before the final stage's butterflies (the pass issues the next item's loads there when it
 // cannot afford to hold them through the whole transform).
-template <int SGN, int LR, bool SHORT, bool IN_REGS, bool OUT_REGS, class Late>
+// FULL_END: the barrier behind the final scatter is the workgroup's (a strided tile is drained by every thread).
+template <int SGN, int LR, bool SHORT, bool IN_REGS, bool OUT_REGS, bool FULL_END, class Late>
 __device__ __forceinline__ void fft_line(double2 (&v)[SHORT ? (1 << LR) : 16], const FftLine& f, int n16, bool zpad, int nin,
                                          Late late) {
   constexpr int P = SHORT ? (1 << LR) : 16;
@@ -208,9 +224,9 @@ __device__ __forceinline__ void fft_line(double2 (&v)[SHORT ? (1 << LR) : 16], c
     for (int s = 0; s < nfull; ++s) {
       if (!(IN_REGS && s == 0)) stage_gather<16>(v, f, zpad && s == 0, nin);
       stage_compute<16, 1, SGN>(v, f, lNs);
-      lds_barrier();            // every thread has gathered: the line may be overwritten
+      line_barrier(f);          // every thread of the line has gathered: it may be overwritten
       stage_scatter<16, 1>(v, f, lNs);
-      lds_barrier();
+      line_barrier(f);
       lNs += 4;
     }
   }
@@ -218,9 +234,9 @@ __device__ __forceinline__ void fft_line(double2 (&v)[SHORT ? (1 << LR) : 16], c
   late();
   stage_compute<RF, P / RF, SGN>(v, f, lNs);
   if (!OUT_REGS) {
-    lds_barrier();
+    line_barrier(f);
     stage_scatter<RF, P / RF>(v, f, lNs);
-    lds_barrier();
+    if (FULL_END) lds_barrier(); else line_barrier(f);
   }
 }
 
@@ -261,6 +277,8 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
     if (tid < 64) st2(&fsm[tid], ld2(&twg[(tid < half ? tid : 0) * tstep]));
     for (int b = tid; b < ntabB; b += nth) st2(&fsm[64 + b], ld2(&twg[(b * 64 < half ? b * 64 : 0) * tstep]));
   }
+  f.wpl = (f.tpl >= 64) ? (f.tpl >> 6) : 1;
+  if (ps.lsync == 0) f.wpl = 8;                      // A/B: every stage boundary a workgroup barrier (GSI_FFT_LINE_SYNC=0)
   lds_barrier();
   const int nouter = (int)(ps.R1 * ps.R2);
   // contiguous-axis passes: W position of slot s of this thread = a0_tb + s a0_ss (natural: jt + s tpl; blocked, tpl a multiple of
@@ -393,13 +411,13 @@ __global__ __launch_bounds__(512) void fft_pass_kernel(double2* __restrict__ W, 
     auto nothing = []() {};
     if (!FUSED && !PRE_LATE) prefetch();
     // ---- transforms
-    if (PRE_LATE) fft_line<SGN1, LR, SHORT, AXIS0, AXIS0 || FUSED>(v, f, n16, !INV, ps.nin, prefetch);
-    else fft_line<SGN1, LR, SHORT, AXIS0, AXIS0 || FUSED>(v, f, n16, !INV, ps.nin, nothing);
+    if (PRE_LATE) fft_line<SGN1, LR, SHORT, AXIS0, AXIS0 || FUSED, !AXIS0>(v, f, n16, !INV, ps.nin, prefetch);
+    else fft_line<SGN1, LR, SHORT, AXIS0, AXIS0 || FUSED, !AXIS0>(v, f, n16, !INV, ps.nin, nothing);
     if (FUSED) {
 #pragma unroll
       for (int s = 0; s < P; ++s) { v[s].x *= lamv[s]; v[s].y *= lamv[s]; }
       prefetch();
-      fft_line<1, LR, SHORT, true, AXIS0>(v, f, n16, false, 0, nothing);
+      fft_line<1, LR, SHORT, true, AXIS0, !AXIS0>(v, f, n16, false, 0, nothing);
     }
     // ---- results
     if (AXIS0) {
@@ -663,6 +681,8 @@ static void fft_pass(hipStream_t st, double2* W, int nb, const int64_t N[3], con
     ps.lstride = ps.Ma + (T >= 2 ? 16 / T : 0);      // line-fastest fills and drains: T lines x 16/T neighbours = 16 banks rows apart
   }
   ps.T = T;
+  static const int lsync_env = getenv("GSI_FFT_LINE_SYNC") ? atoi(getenv("GSI_FFT_LINE_SYNC")) : 1;
+  ps.lsync = lsync_env;
   const int tpl = ps.Ma >= 16 ? ps.Ma / 16 : 1;
   const int threads = (T * tpl + 63) / 64 * 64;
   if (threads > 512) throw std::runtime_error("fft_pass: tile exceeds 16 points per thread");
