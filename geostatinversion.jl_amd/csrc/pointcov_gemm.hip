@@ -29,10 +29,9 @@ namespace gsi { namespace hipk {
 namespace {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int WBM = 64;            // rows of C per workgroup
+constexpr int WBM = 64;            // rows of C per workgroup (MT = 2: two 16-row tiles per wave); MT = 3: 96
 constexpr int WBK = 16;            // reduction depth per LDS tile
 constexpr int WBKP = WBK + 2;      // padded k stride of the X image [column][k] (WBKP / 2 odd: conflict-free ds_read_b64)
-constexpr int WBMP = WBM + 16;     // padded row stride of the G image [k][row]
 constexpr int WTHREADS = 512;
 constexpr int WCSTEP = 2 * WTHREADS / WBK;   // X tile: column advance per pair slot (64)
 
@@ -42,11 +41,16 @@ struct PointGen {
   double sigma2, nugget;
 };
 
-template <int NTQ>
+// MT = 3 (96 rows per workgroup, wave tile 48 x 80, 120 accumulator registers): per flop 2/3 of the X traffic and 2/3 of the
+// barriers of the 64-row tile (60 MFMAs per wave between barriers instead of 40).  A wave generates 96 x 2 entries per tile, three
+// per lane: (k0, row l), (k1, row 32 + l) and -- lanes 0..31: (k0, row 64 + l), lanes 32..63: (k1, row l - 32).
+template <int NTQ, int MT>
 __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
     int64_t M, int64_t L, int64_t K, const double* __restrict__ P4, const double2* __restrict__ Xp, int64_t ktiles,
     double* __restrict__ C, int64_t ldc, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, PointGen gen) {
   constexpr int NT = 4 * NTQ;                 // 16-column tiles per workgroup
+  constexpr int BM = 32 * MT;                 // rows of C per workgroup
+  constexpr int WBMP = BM + 16;               // padded row stride of the G image [k][row]
   constexpr int A_ELEMS = WBK * WBMP;
   constexpr int B_ELEMS = NT * 16 * WBKP;
   constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
@@ -57,22 +61,22 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = wave & 1;          // row group: C rows 32 rg .. of the workgroup tile
+  const int rg = wave & 1;          // row group: C rows 16 MT rg .. of the workgroup tile
   const int cq = wave >> 1;         // column quarter: 16-column tiles cq * NTQ ..
   const int ch = wave >> 2;         // which of the two waves of a SIMD (w, w + 4): their chores are staggered
   const int jl = lane & 15;
   const int kk = lane >> 4;
   const int64_t tile_lin = blockIdx.x;
   const int split = (int)blockIdx.y;
-  const int64_t r0 = (tile_lin / nchunks_x) * WBM;
+  const int64_t r0 = (tile_lin / nchunks_x) * BM;
   const int64_t c0 = (tile_lin % nchunks_x) * (NT * 16);
   const int64_t kbeg = (int64_t)split * kchunk;
   const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
   const int64_t ntiles = (kend > kbeg) ? (kend - kbeg + WBK - 1) / WBK : 0;
 
-  double4_t acc[2][NTQ];
+  double4_t acc[MT][NTQ];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < MT; ++h)
 #pragma unroll
     for (int t = 0; t < NTQ; ++t) acc[h][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
@@ -80,18 +84,27 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
   // PACKED (pointcov_pack_kernel): tile kt of column chunk c is the contiguous block [it][tid] of pairs -- a wave's load
   // instruction reads 1 KB in a row and a tile touches one 40 KB run instead of 128 bytes in each of 320 columns 8 n bytes apart
   // (measured: the strided form cost 34 ms of a 480 ms product in misses alone), zero-filled beyond L and K: no predicates here.
-  double2 b_reg[2][NTQ];
+  // register sets of the X prefetch: two (tiles t+3, t+2 in flight) at 64 rows; ONE at 96 rows -- 120 accumulator registers
+  // leave no room for the second, and the packed stream comes out of L2 within the one tile (60 MFMAs per wave) it then has
+  constexpr int NS = (MT == 3) ? 1 : 2;
+  double2 b_reg[NS][NTQ];
   const int b_c = tid >> 3;
   const int b_k = 2 * (tid & 7);
   const double2* const Xbase = Xp + ((tile_lin % nchunks_x) * ktiles * NTQ) * WTHREADS + tid;
 
-  // this thread's row point (fixed for the whole kernel)
+  // this thread's row point(s) (fixed for the whole kernel)
   const int64_t row_first = gen.roff + r0;
   double px, py, pz;
+  double pbx = 0.0, pby = 0.0, pbz = 0.0, pcx = 0.0, pcy = 0.0, pcz = 0.0;       // MT = 3: rows 32 + lane and (64 + lane | lane - 32)
+  const int rowC = (lane < 32) ? 64 + lane : lane - 32;
   {
-    const int64_t gr = row_first + lane;
-    const int64_t i0 = (gr < gen.npts) ? gr : (int64_t)gen.npts - 1;
-    px = P4[4 * i0]; py = P4[4 * i0 + 1]; pz = P4[4 * i0 + 2];
+    auto rowpt = [&](int r, double& x, double& y, double& z) {
+      const int64_t gr = row_first + r;
+      const int64_t i0 = (gr < gen.npts) ? gr : (int64_t)gen.npts - 1;
+      x = P4[4 * i0]; y = P4[4 * i0 + 1]; z = P4[4 * i0 + 2];
+    };
+    rowpt(lane, px, py, pz);
+    if constexpr (MT == 3) { rowpt(32 + lane, pbx, pby, pbz); rowpt(rowC, pcx, pcy, pcz); }
   }
   const GenPointK gq = gen_point_setup(gen.dim, gen.kind);
   gen_table_init(gtab, tid, gen.sigma2);
@@ -137,24 +150,49 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
     double* b_s = a_s + A_ELEMS;
     {
       const int kw = 2 * wave;
-      double dx = px - qxy0.x, dy = py - qxy0.y;
-      double s0 = fma(dx, dx, dy * dy);
-      dx = px - qxy1.x; dy = py - qxy1.y;
-      double s1 = fma(dx, dx, dy * dy);
       const int fl = gen_flags(gq.flags);
-      if (fl & 1) {
-        const double dz0 = pz - qz0, dz1 = pz - qz1;
-        s0 = fma(dz0, dz0, s0); s1 = fma(dz1, dz1, s1);
-      }
-      double v0, v1;
-      gen_point_pair(gq, fl, s0, s1, gtab, v0, v1);
       const int rel0 = (int)(qg0 - row_first), rel1 = (int)(qg1 - row_first);  // (point indices are 31-bit)
-      if ((unsigned)rel0 < (unsigned)WBM || (unsigned)rel1 < (unsigned)WBM) {  // uniform: the diagonal crosses this slot
-        v0 += (lane == rel0) ? gen.nugget : 0.0;
-        v1 += (lane == rel1) ? gen.nugget : 0.0;
+      if constexpr (MT == 2) {
+        double dx = px - qxy0.x, dy = py - qxy0.y;
+        double s0 = fma(dx, dx, dy * dy);
+        dx = px - qxy1.x; dy = py - qxy1.y;
+        double s1 = fma(dx, dx, dy * dy);
+        if (fl & 1) {
+          const double dz0 = pz - qz0, dz1 = pz - qz1;
+          s0 = fma(dz0, dz0, s0); s1 = fma(dz1, dz1, s1);
+        }
+        double v0, v1;
+        gen_point_pair(gq, fl, s0, s1, gtab, v0, v1);
+        if ((unsigned)rel0 < (unsigned)BM || (unsigned)rel1 < (unsigned)BM) {  // uniform: the diagonal crosses this slot
+          v0 += (lane == rel0) ? gen.nugget : 0.0;
+          v1 += (lane == rel1) ? gen.nugget : 0.0;
+        }
+        a_s[kw * WBMP + lane] = v0;
+        a_s[(kw + 1) * WBMP + lane] = v1;
+      } else {
+        const bool lo = lane < 32;                                             // the middle entry: column k0 (lanes 0..31) or k1
+        const double qcx = lo ? qxy0.x : qxy1.x, qcy = lo ? qxy0.y : qxy1.y;
+        double dx = px - qxy0.x, dy = py - qxy0.y;
+        double s0 = fma(dx, dx, dy * dy);
+        dx = pcx - qcx; dy = pcy - qcy;
+        double s1 = fma(dx, dx, dy * dy);
+        dx = pbx - qxy1.x; dy = pby - qxy1.y;
+        double s2 = fma(dx, dx, dy * dy);
+        if (fl & 1) {
+          const double dz0 = pz - qz0, dz1 = pcz - (lo ? qz0 : qz1), dz2 = pbz - qz1;
+          s0 = fma(dz0, dz0, s0); s1 = fma(dz1, dz1, s1); s2 = fma(dz2, dz2, s2);
+        }
+        double v0, v1, v2;
+        gen_point_triple(gq, fl, s0, s1, s2, gtab, v0, v1, v2);
+        if ((unsigned)rel0 < (unsigned)BM || (unsigned)rel1 < (unsigned)BM) {  // uniform: the diagonal crosses this slot
+          v0 += (lane == rel0) ? gen.nugget : 0.0;
+          v1 += (rowC == (lo ? rel0 : rel1)) ? gen.nugget : 0.0;
+          v2 += (32 + lane == rel1) ? gen.nugget : 0.0;
+        }
+        a_s[kw * WBMP + lane] = v0;
+        a_s[(lo ? kw : kw + 1) * WBMP + rowC] = v1;
+        a_s[(kw + 1) * WBMP + 32 + lane] = v2;
       }
-      a_s[kw * WBMP + lane] = v0;
-      a_s[(kw + 1) * WBMP + lane] = v1;
       load_points(k0 + WBK);                                                    // the next tile's (clamped when there is none)
     }
 #pragma unroll
@@ -162,11 +200,11 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
       *reinterpret_cast<double2*>(b_s + (b_c + WCSTEP * it) * WBKP + b_k) = b_reg[set][it];
   };
 
-  double fa[2], fan[2];
+  double fa[MT], fan[MT];
   double fb[NTQ];
   const int t0 = cq * NTQ;
   auto a_frag = [&](int buf, int s, int h) -> double {
-    return (smem + buf * BUF_ELEMS)[(4 * s + kk) * WBMP + 32 * rg + 16 * h + jl];
+    return (smem + buf * BUF_ELEMS)[(4 * s + kk) * WBMP + 16 * MT * rg + 16 * h + jl];
   };
   auto b_frag = [&](int buf, int s, int t) -> double {
     return (smem + buf * BUF_ELEMS + A_ELEMS)[(16 * (t0 + t) + jl) * WBKP + 4 * s + kk];
@@ -176,11 +214,11 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
   using Set1 = std::integral_constant<int, 1>;
   auto do_tile = [&](int64_t t, auto PAR) __attribute__((always_inline)) {
     constexpr int cur = decltype(PAR)::value;
-    using NextSet = std::integral_constant<int, cur ^ 1>;
+    using NextSet = std::integral_constant<int, (NS == 2) ? (cur ^ 1) : 0>;
     auto chores = [&]() __attribute__((always_inline)) {
       __builtin_amdgcn_s_setprio(0);
       if (t + 1 < ntiles) stage(cur ^ 1, NextSet{}, kbeg + (t + 1) * WBK);       // tile t+1: registers / generator -> other LDS buffer
-      if (t + 3 < ntiles) prefetch(kbeg + (t + 3) * WBK, NextSet{});              // HBM -> the set just drained
+      if (t + 1 + NS < ntiles) prefetch(kbeg + (t + 1 + NS) * WBK, NextSet{});    // HBM -> the set just drained
       __builtin_amdgcn_s_setprio(1);
     };
 #pragma unroll
@@ -195,29 +233,29 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
       const bool more = !last || (t + 1 < ntiles);
       if (more) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) fan[h] = a_frag(nbuf, ns, h);
+        for (int h = 0; h < MT; ++h) fan[h] = a_frag(nbuf, ns, h);
       }
 #pragma unroll
       for (int tt = 0; tt < NTQ; ++tt) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < MT; ++h)
           acc[h][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tt], fa[h], acc[h][tt], 0, 0, 0);
         if (more) fb[tt] = b_frag(nbuf, ns, tt);
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) fa[h] = fan[h];
+      for (int h = 0; h < MT; ++h) fa[h] = fan[h];
     }
   };
 
   if (ntiles > 0) {
     load_points(kbeg);
     prefetch(kbeg, Set0{});
-    if (ntiles > 1) prefetch(kbeg + WBK, Set1{});
+    if (NS == 2 && ntiles > 1) prefetch(kbeg + WBK, std::integral_constant<int, NS - 1>{});
     stage(0, Set0{}, kbeg);
-    if (ntiles > 2) prefetch(kbeg + 2 * WBK, Set0{});
+    if (ntiles > NS) prefetch(kbeg + NS * WBK, Set0{});
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) fa[h] = a_frag(0, 0, h);
+    for (int h = 0; h < MT; ++h) fa[h] = a_frag(0, 0, h);
 #pragma unroll
     for (int t = 0; t < NTQ; ++t) fb[t] = b_frag(0, 0, t);
     int64_t t = 0;
@@ -231,8 +269,8 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
   // epilogue: lane holds D[i = kk + 4 reg][j = jl]  ->  C[row = .. + jl][col = c0 + 16 (t0 + t) + kk + 4 reg]
   double* const W = (slabs != nullptr) ? slabs + (int64_t)split * M * L : nullptr;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int64_t row = r0 + 32 * rg + 16 * h + jl;
+  for (int h = 0; h < MT; ++h) {
+    const int64_t row = r0 + 16 * MT * rg + 16 * h + jl;
     if (row < M) {
 #pragma unroll
       for (int t = 0; t < NTQ; ++t) {
@@ -265,29 +303,53 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_pack_kernel(int64_t L, int6
   }
 }
 
-template <int NTQ>
-void launch_wide(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* P4, const double2* Xp, int64_t ktiles,
-                 double* C, int64_t ldc, double* slabs, int64_t kchunk, int nchunks, const PointGen& gen) {
-  constexpr size_t shmem = (64 + 2 * (WBK * WBMP + 4 * NTQ * 16 * WBKP)) * sizeof(double);
+template <int NTQ, int MT>
+void launch_wide2(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* P4, const double2* Xp, int64_t ktiles,
+                  double* C, int64_t ldc, double* slabs, int64_t kchunk, int nchunks, const PointGen& gen) {
+  constexpr size_t shmem = (64 + 2 * (WBK * (32 * MT + 16) + 4 * NTQ * 16 * WBKP)) * sizeof(double);
   static std::atomic<uint64_t> attr_mask{0};
   if (first_use_on_this_device(attr_mask))
-    (void)hipFuncSetAttribute((const void*)pointcov_wide_kernel<NTQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  hipLaunchKernelGGL((pointcov_wide_kernel<NTQ>), grid, dim3(WTHREADS), shmem, st, M, L, K, P4, Xp, ktiles, C, ldc, slabs, kchunk,
-                     nchunks, gen);
+    (void)hipFuncSetAttribute((const void*)pointcov_wide_kernel<NTQ, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL((pointcov_wide_kernel<NTQ, MT>), grid, dim3(WTHREADS), shmem, st, M, L, K, P4, Xp, ktiles, C, ldc, slabs,
+                     kchunk, nchunks, gen);
+}
+template <int NTQ>
+void launch_wide(int mt, dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* P4, const double2* Xp,
+                 int64_t ktiles, double* C, int64_t ldc, double* slabs, int64_t kchunk, int nchunks, const PointGen& gen) {
+  if (mt == 3) launch_wide2<NTQ, 3>(grid, st, M, L, K, P4, Xp, ktiles, C, ldc, slabs, kchunk, nchunks, gen);
+  else launch_wide2<NTQ, 2>(grid, st, M, L, K, P4, Xp, ktiles, C, ldc, slabs, kchunk, nchunks, gen);
 }
 
+int forced_split() {
+  static const int f = getenv("GSI_GEMM_FORCE_SPLIT") ? atoi(getenv("GSI_GEMM_FORCE_SPLIT")) : 0;   // experiments
+  return f;
+}
 // the tiling of a product with L columns: chunks of 64 ntq columns, ntq in 3..5 (L > 160)
-struct WideTiling { int ntq; int64_t nchunks, active; int nsplit; int64_t kchunk; int ns_eff; };
+struct WideTiling { int ntq, mt; int64_t nchunks, active; int nsplit; int64_t kchunk; int ns_eff; };
 WideTiling wide_tiling(int64_t M, int64_t L, int64_t K) {
   WideTiling w;
+  static const int rows = getenv("GSI_POINTCOV_ROWS") ? atoi(getenv("GSI_POINTCOV_ROWS")) : 96;   // 64 | 96 rows per workgroup (A/B)
+  w.mt = (rows == 64) ? 2 : 3;
   const int64_t tiles = (L + 15) / 16;
   const int64_t nch = (tiles + 19) / 20;
   const int64_t nt = (tiles + nch - 1) / nch;                 // balanced: 11 .. 20 tiles per chunk
   w.ntq = (int)((nt + 3) / 4);
   if (w.ntq < 3) w.ntq = 3;
   w.nchunks = (L + 64 * w.ntq - 1) / (64 * w.ntq);
-  w.active = ((M + WBM - 1) / WBM) * w.nchunks;
-  w.nsplit = (K > 0) ? gemm_choose_split(w.active, K) : 1;
+  w.active = ((M + 32 * w.mt - 1) / (32 * w.mt)) * w.nchunks;
+  // K splits: the grid takes ceil(g s / 256) / s rounds of workgroups, and with 2110 row blocks (n = 202 500, 96 rows) the
+  // partial last round is the whole difference between 8.24 and 9 -- measured 478 (s = 1), 453 (2), 439 (4), 440 ms (8), exactly
+  // the model.  So the best s is taken outright (the contraction kernel's chooser asks for a 3 % gain per step and stops at 2).
+  w.nsplit = 1;
+  if (K > 0 && forced_split() > 0) w.nsplit = forced_split();
+  else if (K > 0) {
+    static const int ncus = [] { int dev = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    double best = 0.0;
+    for (int sp = 1; sp <= 16 && (sp == 1 || K / sp >= 4096); ++sp) {
+      const double cost = (double)((w.active * sp + ncus - 1) / ncus) / (double)sp * (1.0 + 0.002 * (double)sp);
+      if (sp == 1 || cost < best) { best = cost; w.nsplit = sp; }
+    }
+  }
   w.kchunk = (K + w.nsplit - 1) / w.nsplit;
   w.kchunk = ((w.kchunk + 31) / 32) * 32;
   if (w.kchunk == 0) w.kchunk = 32;
@@ -331,9 +393,9 @@ bool gemm_f64_pointcov_wide(hipStream_t st, int64_t M, int64_t L, int64_t K, con
   dim3 grid((unsigned)w.active, (unsigned)w.ns_eff, 1);
   double* slabs = (w.ns_eff > 1) ? ws : nullptr;
   switch (w.ntq) {
-    case 3: launch_wide<3>(grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
-    case 4: launch_wide<4>(grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
-    default: launch_wide<5>(grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
+    case 3: launch_wide<3>(w.mt, grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
+    case 4: launch_wide<4>(w.mt, grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
+    default: launch_wide<5>(w.mt, grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
   }
   if (w.ns_eff > 1) gemm_splitk_reduce(st, M, L, w.ns_eff, slabs, C, ldc);
   return true;

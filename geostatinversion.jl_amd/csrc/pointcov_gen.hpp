@@ -72,6 +72,22 @@ __device__ __forceinline__ void gen_point_pair(const GenPointK& q, int fl, doubl
     v1 *= (1.0 + a1) + (a1 * a1) * q.p2;
   }
 }
+// three entries side by side (the 96-row tile of pointcov_gemm.hip: three independent chains per lane)
+__device__ __forceinline__ void gen_point_triple(const GenPointK& q, int fl, double s0, double s1, double s2, const double* tab,
+                                                 double& v0, double& v1, double& v2) {
+  double a0 = s0 + 1e-280, a1 = s1 + 1e-280, a2 = s2 + 1e-280;
+  if (!(fl & 2)) {                                 // uniform
+    a0 = gen_sqrt(a0); a1 = gen_sqrt(a1); a2 = gen_sqrt(a2);
+    asm volatile("" ::: "memory");
+  }
+  v0 = gen_exp_neg(a0, tab); v1 = gen_exp_neg(a1, tab); v2 = gen_exp_neg(a2, tab);
+  if (fl & 4) {                                    // uniform
+    asm volatile("" ::: "memory");
+    v0 *= (1.0 + a0) + (a0 * a0) * q.p2;
+    v1 *= (1.0 + a1) + (a1 * a1) * q.p2;
+    v2 *= (1.0 + a2) + (a2 * a2) * q.p2;
+  }
+}
 // the table of gen_exp_neg, filled by the first wave of a workgroup (a barrier must follow)
 __device__ __forceinline__ void gen_table_init(double* tab, int tid, double sigma2) {
   if (tid < 64) tab[tid] = (sigma2 / 60.0) * pointcov::exp_nonpos((double)(tid - 64) * 1.0830424696249145e-02);   // 2 sigma^2 / 120 x exp((j - 64) ln 2 / 64)
