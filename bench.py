@@ -367,7 +367,7 @@ def secondary_pointcov(gsi, ctx, barrier):
     Y.close()
     return {
         "workload": f"implicit covariance exp(-d/45) of n = {n} SCATTERED points (given as coordinates), l = {l}: one product; every "
-                    "entry generated once, inside the contraction's tile loader (64 x 320 output tiles, DESIGN.md 4.9)",
+                    "entry generated once, inside the contraction's tile loader (96 x 320 output tiles, DESIGN.md 4.9)",
         "contraction_frac_of_mfma_peak": 2.0 * n * n * l / out["points"] / 1e12 / PEAK_FP64_MFMA_TFLOPS,
         "ms_per_product": 1e3 * out["points"], "contraction_TFLOP/s": 2.0 * n * n * l / out["points"] / 1e12,
         "table_based_grid_operator_ms_per_product": 1e3 * out["table"],

@@ -44,7 +44,7 @@ void gemm_f64_pointcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const do
                        double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
                        int64_t ldc, double* ws, double* xpack);
 double pointcov_point_scale(int kind, double inv_ell);
-// pointcov_gemm.hip: the same product with 64-row x 320-column tiles (every entry generated once for sketches of up to 320
+// pointcov_gemm.hip: the same product with 96-row x 320-column tiles (every entry generated once for sketches of up to 320
 // columns); false = not applicable (L <= 160, GSI_POINTCOV_WIDE=0, X beyond 32-bit tile offsets)
 bool gemm_f64_pointcov_wide(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int d, int kind,
                             double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,

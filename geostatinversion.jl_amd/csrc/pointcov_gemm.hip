@@ -1,22 +1,22 @@
 // pointcov_gemm.hip -- C (M x L) = G * X for the covariance of SCATTERED points, G(i, j) = sigma2 k(|p_i - p_j| / ell)
-// (+ nugget on the diagonal), with 64-row x 320-column output tiles: every entry of G is generated ONCE per product for
-// sketches of up to 320 columns (SURVEY.md 8b "entries generated in the tile loader"; RandMatFact.jl:55,70 are the products).
+// (+ nugget on the diagonal), with 96-row (or 64-row) x 320-column output tiles: every entry of G is generated ONCE per product
+// for sketches of up to 320 columns (SURVEY.md 8b "entries generated in the tile loader"; RandMatFact.jl:55,70 are the products).
 //
 // Why a second kernel beside gemm_f64.hip's GEN 2 path (128 rows x 160 columns per workgroup): on gfx950 an fp64 MFMA holds the
 // vector ALU, so the generator's vector instructions ADD to the matrix time -- measured 2.0-2.6 ns per wave
 // instruction whatever the instruction (tools/valu_f64_rates.hip; v_rsq_f64 7 ns).  At l = 320 the 160-column kernel walks the
-// reduction twice and generates every entry twice.  Here a workgroup owns ALL 320 columns of 64 rows: the same eight waves with
-// the same 32 x 80 wave tile (2 row groups x 4 column quarters instead of 4 x 2), the same 0.7 LDS reads per MFMA, half the
-// generator work per flop.  The price is the X tile: 320 columns x 8 bytes x depth must sit in LDS twice (double buffering), so the
-// reduction depth per tile is 16 instead of 32 (2 x 55 KB), i.e. one barrier per 40 MFMAs of a wave instead of 80.
+// reduction twice and generates every entry twice.  Here a workgroup owns ALL 320 columns of its rows: eight waves, 2 row groups x
+// 4 column quarters, wave tile 48 x 80 (MT = 3; 32 x 80 at MT = 2), half the generator work per flop.  The price is the X tile:
+// 320 columns x 8 bytes x depth must sit in LDS twice (double buffering), so the reduction depth per tile is 16 instead of 32
+// (2 x 60 KB) -- one barrier per 60 (40) MFMAs of a wave instead of 80 -- and X is re-read once per 96 (64) rows instead of 128.
 //
-// Per tile of 16 reduction indices: wave w generates the two columns k = 2w, 2w + 1 of the 64 x 16 tile of G, lane = row -- the row
-// point stays in registers for the whole kernel, the two column points are wave-uniform scalar loads of 32-byte records, and the
-// two entries are evaluated side by side (pointcov_gen.hpp: pre-scaled points, v_rsq_f64 + one Goldschmidt step + residual,
-// table-driven exponential; 27 vector instructions per entry).  X goes HBM/L2 -> registers two tiles ahead -> LDS, as in
-// gemm_f64.hip.  Rows beyond M are generated from a clamped index and never stored; reduction indices beyond the range meet zero
-// rows of the X tile.  Split-K with per-split slabs and the fixed-order reduction of gemm_f64.hip when the row blocks would not
-// fill the chip (row shards on 8 GPUs).
+// Per tile of 16 reduction indices: wave w generates the two columns k = 2w, 2w + 1 of the tile of G -- the row points stay in
+// registers for the whole kernel, the two column points are loaded one tile ahead through the VECTOR pipe (every lane the same
+// address; as scalar loads they shared lgkmcnt with the LDS reads), and a lane's two or three entries are evaluated side by side
+// (pointcov_gen.hpp: pre-scaled points, v_rsq_f64 + one Goldschmidt step + residual, table-driven exponential; 27 vector
+// instructions per entry).  X arrives PACKED in tile order (pointcov_pack_kernel), HBM/L2 -> registers -> LDS.  Rows beyond M are
+// generated from a clamped index and never stored; reduction indices beyond the range meet zero rows of the X tile.  Split-K with
+// per-split slabs and the fixed-order reduction of gemm_f64.hip, the split chosen so that the last round of workgroups is full.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>

@@ -1,5 +1,5 @@
 // pointcov_gen.hpp -- one matrix entry of the scattered-point covariance, as the contraction kernels' tile loaders evaluate it
-// (gemm_f64.hip GEN 2: 128 x 160 output tiles; pointcov_gemm.hip: 64 x 320).  Device code only.
+// (gemm_f64.hip GEN 2: 128 x 160 output tiles; pointcov_gemm.hip: 96 x 320).  Device code only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pointcov.hpp"
