@@ -13,6 +13,19 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fft512_r04 -- python3 $R/tools/fft_cov_bench.py --Ns 512 512 512 --l 16 --fftrf --no-svd > $R/gpurun_out/prof_fft512_r04.log 2>&1
 find $R/gpurun_out/prof_fft512_r04 -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/r04_fft_kernel_stats_512cube.csv \;
 cd $R
+# the scattered-point operator: default (96 x 320 tiles), the A/B knobs, the kernel trace
+(echo "# tools/pointcov_bench.py (default: 96 x 320 tiles over the packed sketch panel, K splits chosen outright)"; timeout -k 10 200 python tools/pointcov_bench.py
+ echo "# GSI_POINTCOV_ROWS=64 (64 x 320 tiles)"; GSI_POINTCOV_ROWS=64 timeout -k 10 200 python tools/pointcov_bench.py
+ echo "# GSI_GEMM_FORCE_SPLIT=1 / 2 (96 rows: the partial last round of workgroups)"
+ GSI_GEMM_FORCE_SPLIT=1 timeout -k 10 200 python tools/pointcov_bench.py | grep exponential; GSI_GEMM_FORCE_SPLIT=2 timeout -k 10 200 python tools/pointcov_bench.py | grep exponential
+ echo "# GSI_POINTCOV_WIDE=0 (128 x 160 tiles, every entry generated twice at l = 320)"; GSI_POINTCOV_WIDE=0 timeout -k 10 200 python tools/pointcov_bench.py
+ echo "# l = 160 (one column chunk: the 128 x 160 kernel)"; timeout -k 10 200 python tools/pointcov_bench.py 450 160
+ echo "# GSI_POINTCOV_PANELS=1 (round 3: row panels in HBM)"; GSI_POINTCOV_PANELS=1 timeout -k 10 200 python tools/pointcov_bench.py) > gpurun_out/r04_pointcov_bench.log 2>&1
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_pc -- python3 $R/tools/pointcov_bench.py > $R/gpurun_out/prof_pc.log 2>&1
+find $R/gpurun_out/prof_pc -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/r04_pointcov_kernel_stats.csv \;
+cd $R
+rm -rf gpurun_out/prof_pc
 rm -rf gpurun_out/prof_fft_r04 gpurun_out/prof_fft3_r04 gpurun_out/prof_fft512_r04 gpurun_out/pmc_fft_r04_*_[1-4]
 python - <<'PY'
 import json
