@@ -29,7 +29,7 @@ namespace gsi { namespace hipk {
 namespace {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int WBM = 64;            // rows of C per workgroup (MT = 2: two 16-row tiles per wave); MT = 3: 96
+// rows of C per workgroup: 32 MT (MT 16-row tiles per wave, two row groups): 96 at MT = 3, 64 at MT = 2
 constexpr int WBK = 16;            // reduction depth per LDS tile
 constexpr int WBKP = WBK + 2;      // padded k stride of the X image [column][k] (WBKP / 2 odd: conflict-free ds_read_b64)
 constexpr int WTHREADS = 512;
