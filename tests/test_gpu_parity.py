@@ -1345,6 +1345,29 @@ def test_pointcov_implicit_products(gsi, ctx, n, d, kind, l):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("l", [32, 200])           # the 128 x 160 kernel (GEN 2) and the 96 x 320 one
+@pytest.mark.parametrize("kind", ["exponential", "gaussian", "matern52"])
+def test_pointcov_entry_extremes(gsi, ctx, kind, l):
+    """The in-loader entry at the ends of its range (pointcov_gen.hpp: no clamp in front of the exponential, r^2 + 1e-280 in
+    front of the square root): coincident points off the diagonal, arguments far beyond exp's underflow (the exponent must
+    saturate to 0, not wrap), arguments ~ 1e-9 (everything ~ sigma^2), sigma^2 at both ends of the double range."""
+    rng = np.random.default_rng(7)
+    n = 700
+    P = rng.uniform(0.0, 1.0, size=(2, n))
+    P[:, 100:120] = P[:, 300:320]                       # twenty coincident pairs
+    X = rng.standard_normal((n, l))
+    for scale, ell, sigma2 in ((1.0e6, 1.0e-3, 3.0), (1.0, 1.0e9, 1.0e-30), (50.0, 1.0, 1.0e30), (1.0e12, 1.0, 1.0)):
+        Ps = P * scale
+        A = _dense_pointcov(Ps, kind, ell, sigma2, 0.0)
+        op = gsi.pointcov_implicit_operator(ctx, Ps, kind, ell=ell, sigma2=sigma2)
+        Y = op.matmul(X)
+        op.close()
+        ref = A @ X
+        assert np.isfinite(Y).all()
+        assert np.abs(Y - ref).max() <= 1e-11 * np.abs(ref).max(), (kind, l, scale, ell, sigma2)
+
+
+@pytest.mark.gpu
 def test_pointcov_implicit_randsvd_and_panels(gsi):
     import os
     import subprocess
