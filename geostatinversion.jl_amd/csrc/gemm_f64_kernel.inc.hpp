@@ -440,13 +440,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f64_kernel(
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
       if (s == 1 && ch == 0) chores();
-#if GSI_GEMM_TILE_COUNTERS_32
-      // (160-column passes: one step later than half a tile -- S T 10.14 -> 9.99 ms, dense 65536^2 at l = 320 39.7 -> 39.0 / 39.1
-      //  -> 38.5; at l = 144, NT = 9, the same shift measured 2.5 % SLOWER, so it is NT = 10's alone; same process)
-      if (s == ((NT == 10) ? 2 : 1) + BK / 8 && ch != 0) chores();
-#else
       if (s == 1 + BK / 8 && ch != 0) chores();
-#endif
       const bool last = (s + 1 == BK / 4);
       // the one barrier per tile: tile t+1 becomes visible, and after this step's MFMAs nobody
       // reads buffer `cur` any more (its last fragments are already in registers)
