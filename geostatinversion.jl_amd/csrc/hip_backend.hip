@@ -270,8 +270,13 @@ class HipBackend : public Backend {
       Scratch p4(this, (size_t)4 * npts);                  // the points as 32-byte records (x, y, z, 0): one scalar load each
       hipk::pointcov_pad_points(st_, pts, d, npts, hipk::pointcov_point_scale(kind, 1.0 / ell), p4.p);
       double* ws = gemm_ws(hipk::gemm_pointcov_workspace_doubles(m, l, k));
-      Scratch xp(this, hipk::gemm_pointcov_pack_doubles(m, l, k));   // the wide kernel streams a tile-ordered copy of the sketch panel
-      hipk::gemm_f64_pointcov(st_, m, l, k, p4.p, npts, d, kind, sigma2, nugget, roff, koff, B, ldb, C, ldc, ws, xp.p);
+      // the wide kernel streams a tile-ordered copy of the sketch panel (k x l doubles); memory is never a reason to fail: without
+      // the copy the product runs on the 128 x 160 kernel, which reads X where it lies
+      double* xpack = nullptr;
+      const size_t xdoubles = hipk::gemm_pointcov_pack_doubles(m, l, k);          // 0: not the wide kernel's product
+      if (xdoubles > 0) { try { xpack = alloc(xdoubles); } catch (const Error&) { xpack = nullptr; } }
+      struct Free { HipBackend* be; double* p; ~Free() { if (p) be->release(p); } } xfree{this, xpack};
+      hipk::gemm_f64_pointcov(st_, m, l, k, p4.p, npts, d, kind, sigma2, nugget, roff, koff, B, ldb, C, ldc, ws, xpack);
       check_launch("gemm_nn_pointcov (in-loader generator)");
       return;
     }
