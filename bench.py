@@ -149,6 +149,23 @@ def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234, keep=
 run_steps.last_path_info = None
 
 
+def toolchain_info():
+    """What compiled the kernels (the resource usage of the hot kernels is pinned per compiler version,
+    profiles/isa_resources.json) and what runs them."""
+    info = {}
+    try:
+        r = subprocess.run(["hipcc", "--version"], capture_output=True, text=True, timeout=60)
+        lines = [ln.strip() for ln in r.stdout.splitlines() if ln.strip()]
+        info["hipcc_version"] = "; ".join(lines[:2])
+    except Exception as exc:                                # noqa: BLE001
+        info["hipcc_version"] = f"unavailable ({type(exc).__name__})"
+    try:
+        info["isa_resources"] = json.load(open(os.path.join(ROOT, "profiles", "isa_resources.json"))).get("hipcc_version")
+    except Exception:                                       # noqa: BLE001
+        info["isa_resources"] = None
+    return info
+
+
 def host_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -457,6 +474,148 @@ def secondary_fft_512cube(gsi, ctx, barrier):
         "phases_ms_per_step": {k: v[0] for k, v in ph5.items()}}
 
 
+def _timed(fn, reps=1):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms, c2_step_ms):
+    """"upload and Omega generation timed and reported separately".  Every figure of the line above is
+    device-resident; what the reference's callers invoke hands over HOST memory -- getxis(Q::Matrix, numxis, p, q, seed)
+    (GeostatInversion.jl:63-70), LowRankCovMatrix(samples) (lowrank.jl:14-30), randn(n, l) on the host (RandMatFact.jl:54).
+    Timed here, around the host-pointer entry points the Julia shim binds, at C1, C2 and the headline: seconds, GB/s against
+    this box's own pinned-copy rate (gsi_ctx_pinned_copy_rate, measured first) and against the 63 GB/s of PCIe Gen5 x16, and
+    each as a multiple of its device-resident step.  Host arrays are fresh pageable numpy memory (what a Julia array is)."""
+    import ctypes as C
+    import numpy as np
+    from helpers import gaussian_cov, rel_sv_err
+    L = gsi._lib
+    lib = ctx.lib
+    out = {}
+    h2d, d2h = C.c_double(), C.c_double()
+    L.check(lib.gsi_ctx_pinned_copy_rate(ctx.h, 1 << 30, C.byref(h2d), C.byref(d2h)), lib)
+    out["pinned_copy_GB/s"] = {"h2d": h2d.value, "d2h": d2h.value, "bytes": 1 << 30, "pcie_gen5_x16_GB/s": 63.0}
+    pin = max(h2d.value, 1e-9)
+
+    def rate(nbytes, secs, ceiling=pin):
+        return {"seconds": secs, "GB/s": nbytes / secs / 1e9, "frac_of_pinned_copy_rate": nbytes / secs / 1e9 / ceiling,
+                "frac_of_pcie_gen5_x16": nbytes / secs / 1e9 / 63.0, "bytes": float(nbytes)}
+
+    outs = {}
+
+    def out_arrays(n_, l_):
+        # result arrays that exist already (written once): a first write into fresh pages costs the HOST ~0.25 us per 4 KB page
+        # -- 0.15 s for the headline's 2.56 GB Z -- whoever fills them; reported separately below ("fresh_output_array")
+        if (n_, l_) not in outs:
+            outs[(n_, l_)] = (np.zeros((n_, l_), order="F"), np.zeros(l_))
+        return outs[(n_, l_)]
+
+    def host_randsvd(op, Om, K_, p_, q_, fresh=False):
+        n_, l_ = Om.shape
+        Z, S = (np.empty((n_, l_), order="F"), np.empty(l_)) if fresh else out_arrays(n_, l_)
+        L.check(lib.gsi_randsvd(ctx.h, op.h, L.dptr(Om), K_, p_, q_, L.dptr(Z), S.ctypes.data_as(L.c_dp)), lib)
+        return Z, S
+
+    def dense_host(A, Om, K_, p_, q_):
+        m_, n_ = A.shape
+        l_ = K_ + p_
+        Z, S = out_arrays(n_, l_)
+        L.check(lib.gsi_randsvd_dense_host(ctx.h, L.dptr(A), m_, n_, m_, L.dptr(Om), K_, p_, q_, L.dptr(Z),
+                                           S.ctypes.data_as(L.c_dp), None), lib)
+        return Z, S
+
+    # ---- C1: 2000 x 2000 (32 MB), K = 32, p = 16, q = 1 ------------------------------------------------------------
+    A1 = np.asfortranarray(gaussian_cov(50, 40, 5.0))
+    Om1 = np.asfortranarray(np.random.default_rng(1).standard_normal((2000, 48)))
+    ops = []
+    t_up = _timed(lambda: ops.append(gsi.dense_operator(ctx, A1)), reps=9)
+    t_rs = _timed(lambda: host_randsvd(ops[0], Om1, 32, 16, 1), reps=21)
+    t_all = _timed(lambda: dense_host(A1, Om1, 32, 16, 1), reps=21)
+    for o in ops:
+        o.close()
+    out["c1_dense_2000"] = {
+        "gsi_op_dense_upload": rate(A1.nbytes, t_up),
+        "gsi_randsvd_host_Omega_in_Z_out_ms": 1e3 * t_rs,
+        "gsi_randsvd_dense_host_ms": 1e3 * t_all,
+        "what": "gsi_randsvd_dense_host = what getxis(Q::Matrix, ...) costs per call: matrix up, Omega up, randsvd, Z and S down",
+        "device_resident_step_ms": c1_step_ms,
+        "host_api_over_device_resident": (1e3 * t_all / c1_step_ms) if c1_step_ms else None}
+
+    # ---- C2: 65536 x 65536 (34.4 GB), K = 128, p = 32, q = 2 ---------------------------------------------------------
+    # the Gaussian covariance of the 256 x 256 grid is a Kronecker product: built on the host in seconds
+    g, K2, p2, q2 = 256, 128, 32, 2
+    n2, l2 = g * g, K2 + p2
+    d = np.arange(g, dtype=np.float64)
+    k1 = np.exp(-((d[:, None] - d[None, :]) ** 2) / (2.0 * 16.0 ** 2))
+    t0 = time.perf_counter()
+    A2 = np.kron(k1, k1).T                               # symmetric: the transposed view is the column-major matrix, no copy
+    t_build = time.perf_counter() - t0
+    Om2 = np.asfortranarray(np.random.default_rng(2).standard_normal((n2, l2)))
+    ctx.release_cache()
+    ops = []
+    t_up2 = _timed(lambda: ops.append(gsi.dense_operator(ctx, A2)))
+    Z2r, S2r = host_randsvd(ops[0], Om2, K2, p2, q2)     # warm (workspaces exist afterwards)
+    Z2r, S2r = Z2r.copy(), S2r.copy()
+    t_rs2 = _timed(lambda: host_randsvd(ops[0], Om2, K2, p2, q2), reps=3)
+    ops[0].close()
+    t_all2 = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        Z2, S2 = dense_host(A2, Om2, K2, p2, q2)
+        t_all2.append(time.perf_counter() - t0)
+    t_all2 = min(t_all2)
+    out["c2_dense_65536"] = {
+        "host_matrix_build_seconds": t_build,
+        "gsi_op_dense_upload": rate(A2.nbytes, t_up2),
+        "gsi_randsvd_host_Omega_in_Z_out_ms": 1e3 * t_rs2,
+        "gsi_randsvd_dense_host": dict(rate(A2.nbytes + 2 * Om2.nbytes, t_all2), what="matrix and Omega up in row blocks, the "
+                                       "sketch A*Omega under the upload (RandMatFact.jl:55), power iterations, Z and S down"),
+        "upload_then_randsvd_seconds": t_up2 + t_rs2,
+        "overlap_gain_ms": 1e3 * (t_up2 + t_rs2 - t_all2),
+        "overlapped_equals_resident_bitwise": bool(np.array_equal(Z2, Z2r) and np.array_equal(S2, S2r)),
+        "device_resident_step_ms": c2_step_ms,
+        "host_api_over_device_resident": (1e3 * t_all2 / c2_step_ms) if c2_step_ms else None}
+    del A2, Z2, Z2r
+    ctx.release_cache()
+
+    # ---- headline: LowRankCovMatrix(samples) with 8.2 GB of samples, Omega 2.56 GB in, Z 2.56 GB out -------------------
+    if host is not None and "samples" in host:
+        Sh = host["samples"]                               # N_s x n, one sample per row = n x N_s column-major
+        n = Sh.shape[1]
+        l = K + p
+        hs = []
+
+        def up():
+            h = C.c_void_p()
+            L.check(lib.gsi_op_lowrank(ctx.h, C.byref(h), Sh.ctypes.data_as(L.c_dp), n, Ns, n, 1, 0, n), lib)
+            hs.append(gsi.Operator(ctx, h))
+        t_ups = _timed(up)
+        Om = host["Omega"]
+        Zh, Svh = host_randsvd(hs[0], Om, K, p, q)         # warm
+        Svh = Svh.copy()
+        t_rsh = _timed(lambda: host_randsvd(hs[0], Om, K, p, q), reps=3)
+        t_fresh = _timed(lambda: host_randsvd(hs[0], Om, K, p, q, fresh=True))
+        back = np.zeros_like(Sh)
+        t_dn = _timed(lambda: L.check(lib.gsi_op_lowrank_samples(ctx.h, hs[0].h, back.ctypes.data_as(L.c_dp), n), lib))
+        hs[0].close()
+        out["headline_lowrank_1e6"] = {
+            "gsi_op_lowrank_upload_and_centre": rate(Sh.nbytes, t_ups),
+            "gsi_op_lowrank_samples_download": rate(Sh.nbytes, t_dn, max(d2h.value, 1e-9)),
+            "gsi_randsvd_host_Omega_in_Z_out_ms": 1e3 * t_rsh,
+            "gsi_randsvd_host_fresh_output_array_ms": 1e3 * t_fresh,
+            "host_transfer_bytes_per_call": float(2 * Om.nbytes),
+            "device_resident_step_ms": headline_ms,
+            "host_api_over_device_resident": 1e3 * t_rsh / headline_ms,
+            "transfers_ms": 1e3 * t_rsh - headline_ms,
+            "transfers_GB/s": 2 * Om.nbytes / max(t_rsh - headline_ms * 1e-3, 1e-9) / 1e9,
+            "sv_rel_err_vs_device_resident_step": rel_sv_err(Svh, host["S"], K) if "S" in host else None}
+    return out
+
+
 def full_size_parity(host, Ns, K, p, q, Sv):
     """The metric's rel-err AT the metric's size: the oracle (RandMatFact.jl:83-90 over lowrank.jl's operator, dgetrf /
     dgeqp3 / dgesdd panels) on the very operator, Omega and step the HIP path was timed on -- the centred samples, Omega
@@ -619,6 +778,8 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=16384)
     ap.add_argument("--no-full-parity", action="store_true",
                     help="skip the oracle run at the headline size (about 1-2 min of host LAPACK, ~40 GB of host memory)")
+    ap.add_argument("--no-boundary", action="store_true",
+                    help="skip the host-boundary block (host-pointer entry points at C1, C2 -- a 34 GB host matrix -- and the headline)")
     ap.add_argument("--no-implicit", action="store_true",
                     help="N > 1: skip the one row-sharded step of the implicit 10^6 x 10^6 covariance")
     args = ap.parse_args()
@@ -688,7 +849,8 @@ def main():
     # N > 1 (same problem row-sharded): rank 0 afterwards re-runs the step on one GPU and reports how far the N-rank numbers
     # are from it -- when the whole problem fits one GPU comfortably (n <= 2e6: 16 GB of samples, 5 GB panels)
     vs_one_gpu = world > 1 and rank == 0 and n <= 2000000 and not args.no_full_parity
-    keep = {} if (full_parity or vs_one_gpu) else None
+    want_host = full_parity or (world == 1 and not use_dist and not args.no_boundary)     # the boundary block re-uploads the samples
+    keep = {} if (want_host or vs_one_gpu) else None
     elapsed, phases, Sv = run_steps(gsi, ctx, op, n, K, p, q, args.steps, args.warmup, barrier, keep=keep, rows=use_dist)
     elapsed = max_over_ranks(elapsed)
     counters = ctx.counters()
@@ -708,7 +870,7 @@ def main():
         Z0_rows = keep["Z"].to_host()
         keep["Omega"].close()
         keep["Z"].close()
-    if full_parity:                      # after the timed region: what the oracle needs, off the device
+    if want_host:                        # after the timed region: what the oracle / the boundary block need, off the device
         try:
             host = {"samples": gsi.device_samples(op, Ns), "Omega": keep["Omega"].to_host(), "Z": keep["Z"].to_host()}
         except Exception:                # noqa: BLE001 -- not enough host memory: the n = 16384 sample is what remains
@@ -839,14 +1001,26 @@ def main():
             guarded("fft_powerlaw_512cube", lambda: secondary_fft_512cube(gsi, ctx, barrier))
         out["secondary"] = sec
 
+    if rank == 0 and world == 1 and not args.no_boundary:
+        try:
+            sec_ = out.get("secondary", {})
+            hb = dict(host, S=Sv) if host is not None else None
+            out["boundary"] = boundary_block(gsi, ctx, barrier, ms_per_step, hb, Ns, K, p, q,
+                                             sec_.get("c1_dense_2000", {}).get("ms_per_step"),
+                                             sec_.get("c2_dense_65536", {}).get("ms_per_step"))
+        except Exception as exc:                            # noqa: BLE001 -- must not cost the line
+            out["boundary"] = {"error": f"{type(exc).__name__}: {exc}"}
+            for ch in list(ctx._children):
+                ch.close()
     if rank == 0:
+        out["toolchain"] = toolchain_info()
         if world == 1 and not args.no_cpu_baseline:
             cb, err, xerr = cpu_baseline_and_parity(gsi, ctx, Ns, K, p, q, args.cpu_sample_n, args.decay)
             out["cpu_baseline"] = cb
             small = {"n": args.cpu_sample_n, "sv_rel_err": err, "xis_err_up_to_sign": xerr,
                      "oracle_products": "the reference's ger!/gemv loop (lowrank.jl:115-121)"}
             full = None
-            if host is not None:
+            if host is not None and full_parity:
                 # the metric's rel-err on the metric's configuration: HIP vs oracle on the timed operator itself
                 try:
                     full = full_size_parity(host, Ns, K, p, q, Sv)

@@ -52,6 +52,8 @@ SIGNATURES = {
     "gsi_op_mul": (C.c_int, [c_vp, c_vp, C.c_int, c_dp, c_i64, c_i64, c_dp, c_i64]),
     "gsi_rangefinder": (C.c_int, [c_vp, c_vp, c_dp, c_i64, c_i64, c_dp]),
     "gsi_randsvd": (C.c_int, [c_vp, c_vp, c_dp, c_i64, c_i64, c_i64, c_dp, c_dp]),
+    "gsi_randsvd_dense_host": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_i64, c_dp, c_i64, c_i64, c_i64, c_dp, c_dp, C.POINTER(c_vp)]),
+    "gsi_rangefinder_dense_host": (C.c_int, [c_vp, c_dp, c_i64, c_i64, c_i64, c_dp, c_i64, c_i64, c_dp, C.POINTER(c_vp)]),
     "gsi_eig_nystrom": (C.c_int, [c_vp, c_vp, c_dp, c_i64, c_dp, c_dp]),
     "gsi_rangefinder_adaptive": (C.c_int, [c_vp, c_vp, RANDN_FN, c_vp, C.c_double, c_i64, c_dp, C.POINTER(c_i64)]),
     "gsi_mat_create": (C.c_int, [c_vp, C.POINTER(c_vp), c_i64, c_i64]),
@@ -90,6 +92,7 @@ SIGNATURES = {
     "gsi_ctx_phase_times": (C.c_int, [c_vp, c_dp, C.POINTER(c_i64)]),
     "gsi_ctx_counters": (C.c_int, [c_vp, C.POINTER(c_i64)]),
     "gsi_ctx_path_info": (C.c_int, [c_vp, C.POINTER(c_i64), c_i64]),
+    "gsi_ctx_pinned_copy_rate": (C.c_int, [c_vp, c_i64, c_dp, c_dp]),
     "gsi_ctx_release_cache": (C.c_int, [c_vp]),
     "gsi_ctx_device_bytes": (C.c_int, [c_vp, C.POINTER(c_i64)]),
 }

@@ -200,6 +200,14 @@ int gsi_ctx_path_info(gsi_ctx* ctx, int64_t* out, int64_t n_out) {
   });
 }
 
+int gsi_ctx_pinned_copy_rate(gsi_ctx* ctx, int64_t bytes, double* h2d_gbs, double* d2h_gbs) {
+  return guarded([&] {
+    REQUIRE(ctx && h2d_gbs && d2h_gbs, "NULL argument");
+    REQUIRE(bytes >= 0 && bytes <= ((int64_t)64 << 30), "bad size");
+    ctx->c.be->pinned_copy_rate(bytes, h2d_gbs, d2h_gbs);
+  });
+}
+
 int gsi_ctx_rank(gsi_ctx* ctx, int* rank, int* nranks) {
   return guarded([&] {
     REQUIRE(ctx, "ctx is NULL");
@@ -467,6 +475,83 @@ int gsi_randsvd(gsi_ctx* ctx, const gsi_op* op, const double* Omega, int64_t K, 
     });
     be->download2d(Z_out, A.n, Z.p, A.n, A.n, l);
     if (S_out) be->download2d(S_out, l, S.p, l, l, 1);
+  });
+}
+
+// ---- the dense operator still in HOST memory: what getxis(Q::Matrix, ...) is called with ----------------------------
+namespace {
+// A dense operator whose rows are on their way: allocated, the upload started in row blocks (single rank, large matrices;
+// otherwise uploaded synchronously), `pending_upload` set for the first product.  The guard ends the transfer on every path.
+struct UploadGuard {
+  Backend* be = nullptr;
+  void* h = nullptr;
+  ~UploadGuard() {
+    if (!h) return;
+    try { be->upload2d_end(h); } catch (...) {}
+  }
+};
+std::unique_ptr<gsi_op> dense_op_streaming(gsi_ctx* ctx, const double* A_host, int64_t m, int64_t n, int64_t lda, UploadGuard& g) {
+  REQUIRE(m >= 1 && n >= 1 && lda >= m, "bad matrix shape");
+  REQUIRE(ctx->c.nranks() == 1, "the host-matrix entry points are single-rank: with a communicator upload this rank's rows with gsi_op_dense");
+  std::unique_ptr<gsi_op> o(new gsi_op());
+  Operator& A = o->op;
+  Backend* be = ctx->c.be.get();
+  A.ctx = &ctx->c; A.kind = OP_DENSE; A.m = m; A.n = n; A.row0 = 0; A.mloc = m;
+  A.ld = ((m + 15) / 16) * 16;
+  A.data = Buf(be, (size_t)A.ld * n);
+  const int64_t mb = be->upload_block_rows(m, n);
+  g.be = be;
+  g.h = be->upload2d_begin(A.data.p, A.ld, A_host, lda, m, n, mb);
+  if (g.h != nullptr) { A.pending_upload = g.h; A.pending_block_rows = mb; }
+  return o;
+}
+}  // namespace
+
+int gsi_randsvd_dense_host(gsi_ctx* ctx, const double* A_host, int64_t m, int64_t n, int64_t lda, const double* Omega,
+                           int64_t K, int64_t p, int64_t q, double* Z_out, double* S_out, gsi_op** op_out) {
+  return guarded([&] {
+    REQUIRE(ctx && A_host && Omega && Z_out, "NULL argument");
+    if (op_out) *op_out = nullptr;
+    REQUIRE(K >= 0 && p >= 0 && K + p >= 1, "need K >= 0, p >= 0, K + p >= 1");
+    Backend* be = ctx->c.be.get();
+    const int64_t l = K + p;
+    REQUIRE(m >= 1 && n >= 1 && lda >= m, "bad matrix shape");
+    Buf Om(be, (size_t)n * l), Z(be, (size_t)n * l), S(be, (size_t)l);
+    be->upload2d(Om.p, n, Omega, n, n, l);                  // Omega first: the first block's product needs all of it
+    std::unique_ptr<gsi_op> o;                              // (declared before the guard: the transfer ends before the buffer goes)
+    UploadGuard g;
+    o = dense_op_streaming(ctx, A_host, m, n, lda, g);
+    const Operator& A = o->op;
+    with_retry(ctx->c, [&] {
+      randsvd(A, Om.p, K, p, q, Z.p, S.p);
+      check_async_errors(ctx->c);
+    });
+    be->download2d(Z_out, n, Z.p, n, n, l);
+    if (S_out) be->download2d(S_out, l, S.p, l, l, 1);
+    if (op_out) *op_out = o.release();
+  });
+}
+
+int gsi_rangefinder_dense_host(gsi_ctx* ctx, const double* A_host, int64_t m, int64_t n, int64_t lda, const double* Omega,
+                               int64_t l, int64_t numiterations, double* Q_out, gsi_op** op_out) {
+  return guarded([&] {
+    REQUIRE(ctx && A_host && Omega && Q_out, "NULL argument");
+    if (op_out) *op_out = nullptr;
+    REQUIRE(l >= 1, "l must be positive");
+    REQUIRE(m >= 1 && n >= 1 && lda >= m, "bad matrix shape");
+    Backend* be = ctx->c.be.get();
+    Buf Om(be, (size_t)n * l);
+    be->upload2d(Om.p, n, Omega, n, n, l);
+    std::unique_ptr<gsi_op> o;                              // (declared before the guard: the transfer ends before the buffer goes)
+    UploadGuard g;
+    o = dense_op_streaming(ctx, A_host, m, n, lda, g);
+    const Operator& A = o->op;
+    with_retry(ctx->c, [&] {
+      Buf Q = rangefinder(A, Om.p, l, numiterations);
+      check_async_errors(ctx->c);
+      be->download2d(Q_out, m, Q.p, m, m, l);
+    });
+    if (op_out) *op_out = o.release();
   });
 }
 

@@ -39,11 +39,36 @@ class Backend {
   virtual void copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) = 0;
   virtual void fill_zero(double* p, size_t count) = 0;
   virtual void sync() = 0;
+  // The same upload in ROW BLOCKS of upload_block_rows(rows, cols) rows, in the background: upload2d_begin returns at once
+  // (a handle, or null when the backend uploaded synchronously), upload2d_wait_block makes the context's stream wait for
+  // block b (rows [b * mb, (b + 1) * mb)), upload2d_end returns when the host buffer is no longer read.  What lets the
+  // first pass over a dense host matrix run under its own upload (gsi_randsvd_dense_host; getxis(Q::Matrix, ...),
+  // GeostatInversion.jl:63-70).  The default implementation is the synchronous upload.
+  virtual int64_t upload_block_rows(int64_t rows, int64_t cols) { (void)cols; return rows; }
+  virtual void* upload2d_begin(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols,
+                               int64_t block_rows) {
+    (void)block_rows;
+    upload2d(dst, ldd, host, ldh, rows, cols);
+    return nullptr;
+  }
+  // GB/s of one plain copy of `bytes` from / to pinned host memory on this context's device: the ceiling the staged
+  // transfers are measured against (gsi_ctx_pinned_copy_rate).  0: not measurable on this backend.
+  virtual void pinned_copy_rate(int64_t bytes, double* h2d_gbs, double* d2h_gbs) { (void)bytes; *h2d_gbs = 0.0; *d2h_gbs = 0.0; }
+  virtual void upload2d_wait_block(void* handle, int64_t b) { (void)handle; (void)b; }
+  virtual void upload2d_end(void* handle) { (void)handle; }
 
   // ---- products ----
   // C(m x l) = alpha * A(m x k) * B(k x l) + beta * C      beta in {0, 1}
   virtual void gemm_nn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc) = 0;
+  // rows [r0, r0 + mb) of the product C(m_full x l) = A(m_full x k) * B that gemm_nn would compute -- the same reduction
+  // order per element (the K split is the one the FULL shape gets), so the blocks put together are bit-identical to the one
+  // launch.  A, C: the full matrices (element (0, 0)); r0 a multiple of 128.
+  virtual void gemm_nn_rowblock(int64_t m_full, int64_t r0, int64_t mb, int64_t l, int64_t k, const double* A, int64_t lda,
+                                const double* B, int64_t ldb, double* C, int64_t ldc) {
+    (void)m_full;
+    gemm_nn(mb, l, k, 1.0, A + r0, lda, B, ldb, 0.0, C + r0, ldc);
+  }
   // C(m x l) = alpha * A'(m x k) * B(k x l) + beta * C,  A stored k x m
   virtual void gemm_tn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc) = 0;

@@ -129,7 +129,7 @@ static int gemm_chunk_tiles(int) { return NTMAX; }
 
 static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M, int64_t L, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
-                        int64_t ldc, double* ws, int tri = 0, int gen_mode = 1) {
+                        int64_t ldc, double* ws, int tri = 0, int gen_mode = 1, int force_nsplit = 0) {
   if (M <= 0 || L <= 0) return;
   // The kernel addresses a tile with one uniform 64-bit base per operand plus per-thread byte offsets spanning up to
   // 160 columns of B, 128 rows of a transposed A or 32 columns of a plain A: 32 bits reach panels of ~3.3 million
@@ -151,7 +151,7 @@ static void gemm_launch(hipStream_t st, bool transA, const GenA* gen, int64_t M,
       for (int64_t cb = 0; cb < nchunks; ++cb)
         if (cb >= (rb * BMT) / ((int64_t)nt * 16)) ++active;
   }
-  const int nsplit = (K > 0) ? gemm_choose_split(active, K) : 1;
+  const int nsplit = (force_nsplit > 0) ? force_nsplit : ((K > 0) ? gemm_choose_split(active, K) : 1);
   int64_t kchunk = (K + nsplit - 1) / nsplit;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   if (kchunk == 0) kchunk = BK;
@@ -204,6 +204,24 @@ void gemm_splitk_reduce(hipStream_t st, int64_t M, int64_t L, int nsplit, const 
 void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, double alpha, const double* A,
               int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws) {
   gemm_launch(st, transA, nullptr, M, L, K, alpha, A, lda, B, ldb, beta, C, ldc, ws);
+}
+
+// The K split gemm_f64 (NN or TN, plain operands) uses for an M x L x K product, and rows [r0, r0 + mb) of that product
+// with the SAME split (per-element reduction order unchanged: the row blocks put together are bit-identical to the one
+// launch).  What the streamed upload of a dense operator needs: Y = A * Omega block by block as the rows land.
+int gemm_split_for(int64_t M, int64_t L, int64_t K) {
+  if (M <= 0 || L <= 0 || K <= 0) return 1;
+  const int64_t tiles = (L + 15) / 16, nchunks = (tiles + NTMAX - 1) / NTMAX;
+  const int64_t active = ((M + BMT - 1) / BMT) * nchunks;
+  return gemm_choose_split(active, K);          // the chooser's split, before the rounding of the K chunk to whole tiles
+}
+size_t gemm_rowblock_workspace_doubles(int64_t M_full, int64_t mb, int64_t L, int64_t K) {
+  const int ns = gemm_split_for(M_full, L, K);    // (the launcher may end up with fewer, never more, slabs)
+  return ns > 1 ? (size_t)ns * (size_t)mb * (size_t)L : 0;
+}
+void gemm_f64_nn_rowblock(hipStream_t st, int64_t M_full, int64_t r0, int64_t mb, int64_t L, int64_t K, const double* A,
+                          int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws) {
+  gemm_launch(st, false, nullptr, mb, L, K, 1.0, A + r0, lda, B, ldb, 0.0, C + r0, ldc, ws, 0, 1, gemm_split_for(M_full, L, K));
 }
 
 // C (l x l, ld ldc) = A'A for A m x l: only tiles that touch the upper triangle are computed, the rest of C is

@@ -25,6 +25,7 @@
 #include "../../include/gsi_hip.h"
 #include "backend.hpp"
 #include "hip_common.hpp"
+#include "host_staging.hpp"
 
 namespace gsi {
 
@@ -87,6 +88,8 @@ class HipBackend : public Backend {
   ~HipBackend() override {
     hipSetDevice(device_);
     hipStreamSynchronize(st_);
+    stager_.reset();
+    if (ev_stage_) hipEventDestroy(ev_stage_);
     for (auto& b : {&ws_gemm_, &ws_lu_, &ws_qr_, &ws_svd_, &ws_blas2_, &ws_lus_, &ws_svdf_, &ws_qr_hh_}) free_ws(*b);
     collect_garbage();
     for (auto& b : pool_) hipFree(b.p);
@@ -203,9 +206,50 @@ class HipBackend : public Backend {
       if (!b->pooled) ws += (int64_t)b->bytes;          // pooled workspaces are counted by alloc()
     return in_use_ + pooled_ + ws + (int64_t)garbage_bytes_;
   }
+  // ---- the host boundary (host_staging.hpp): caller memory is pageable; transfers of GSI_STAGE_MIN_MB (default 16) MiB and
+  // more go through the pinned staging ring (GSI_STAGE_THREADS workers, default 4, GSI_STAGE_CHUNK_MB MiB chunks, default
+  // 16: 0.98 of this box's pinned-copy rate in both directions, profiles/r05_h2d_rates.log); smaller ones straight from the
+  // caller's pages (54 us for C1's 768 KB Omega).  If the ring cannot be allocated the direct path serves everything.
+  HostStager* stager() {
+    if (stager_ || stager_failed_) return stager_.get();
+    static const int threads = getenv("GSI_STAGE_THREADS") ? std::max(1, std::min(32, atoi(getenv("GSI_STAGE_THREADS")))) : 4;
+    static const size_t chunk = (size_t)(getenv("GSI_STAGE_CHUNK_MB") ? std::max(1, std::min(1024, atoi(getenv("GSI_STAGE_CHUNK_MB")))) : 16) << 20;
+    try {
+      stager_.reset(new HostStager(device_, threads, chunk));
+      HIP_CHECK(hipEventCreateWithFlags(&ev_stage_, hipEventDisableTiming));
+    } catch (const std::exception&) {
+      (void)hipGetLastError();
+      stager_.reset();
+      stager_failed_ = true;
+    }
+    return stager_.get();
+  }
+  static size_t stage_min_bytes() {
+    const char* e = getenv("GSI_STAGE_MIN_MB");            // read per call (a getenv against a transfer of MiBs; tests switch it)
+    return (size_t)(e ? std::max(0ll, atoll(e)) : 16) << 20;
+  }
+  bool staged(bool h2d, double* dev, int64_t ldd, double* host, int64_t ldh, int64_t rows, int64_t cols) {
+    if (sizeof(double) * (size_t)rows * (size_t)cols < std::max<size_t>(stage_min_bytes(), 1)) return false;
+    HostStager* s = stager();
+    if (!s) return false;
+    HIP_CHECK(hipEventRecord(ev_stage_, st_));       // copies start after everything queued so far (pooled destination / source in the making)
+    try {
+      // mid-size transfers (C1's 32 MB matrix): smaller rectangles, so that every worker has several in flight
+      const size_t bytes = sizeof(double) * (size_t)rows * (size_t)cols;
+      size_t chunk = std::min(s->chunk_bytes(), std::max<size_t>((size_t)1 << 20, (bytes / (4 * (size_t)s->threads())) & ~(((size_t)1 << 18) - 1)));
+      s->begin(h2d, dev, ldd, host, ldh, stage_plan_whole(rows, cols, chunk), 1, ev_stage_);
+      s->end();
+    } catch (const Error&) {
+      throw;
+    } catch (const std::exception& e) {
+      throw Error(GSI_ERR_HIP, e.what());
+    }
+    return true;
+  }
   void upload2d(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols) override {
     if (rows <= 0 || cols <= 0) return;
     bind();
+    if (staged(true, dst, ldd, const_cast<double*>(host), ldh, rows, cols)) return;
     HIP_CHECK(hipMemcpy2DAsync(dst, ldd * sizeof(double), host, ldh * sizeof(double), rows * sizeof(double),
                                cols, hipMemcpyHostToDevice, st_));
     HIP_CHECK(hipStreamSynchronize(st_));  // the caller may reuse / free the host buffer on return
@@ -213,9 +257,79 @@ class HipBackend : public Backend {
   void download2d(double* host, int64_t ldh, const double* src, int64_t lds, int64_t rows, int64_t cols) override {
     if (rows <= 0 || cols <= 0) return;
     bind();
+    if (staged(false, const_cast<double*>(src), lds, host, ldh, rows, cols)) return;
     HIP_CHECK(hipMemcpy2DAsync(host, ldh * sizeof(double), src, lds * sizeof(double), rows * sizeof(double),
                                cols, hipMemcpyDeviceToHost, st_));
     HIP_CHECK(hipStreamSynchronize(st_));
+  }
+  // Row-block upload in the background (Backend::upload2d_begin): matrices of 256 MiB and more, in blocks of 4096 rows
+  // (32 KB per column segment on the host side; a block of a 65536-column matrix is 2 GiB = 37 ms of PCIe against ~10 ms
+  // of contraction: the product of block b runs while block b + 1 crosses).  GSI_STAGE_BLOCK_ROWS overrides (tests).
+  int64_t upload_block_rows(int64_t rows, int64_t cols) override {
+    const int64_t forced = getenv("GSI_STAGE_BLOCK_ROWS") ? atoll(getenv("GSI_STAGE_BLOCK_ROWS")) : 0;
+    if (forced >= 128) return std::min(rows, (forced / 128) * 128);
+    if (sizeof(double) * (size_t)rows * (size_t)cols < ((size_t)256 << 20) || rows < 2 * 4096) return rows;
+    return 4096;
+  }
+  void* upload2d_begin(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols,
+                       int64_t block_rows) override {
+    if (rows <= 0 || cols <= 0) return nullptr;
+    bind();
+    HostStager* s = (block_rows < rows) ? stager() : nullptr;
+    if (!s) { upload2d(dst, ldd, host, ldh, rows, cols); return nullptr; }
+    HIP_CHECK(hipEventRecord(ev_stage_, st_));
+    int nblocks = 0;
+    std::vector<StageRect> plan = stage_plan_rowblocks(rows, cols, block_rows, s->chunk_bytes(), &nblocks);
+    try {
+      s->begin(true, dst, ldd, const_cast<double*>(host), ldh, std::move(plan), nblocks, ev_stage_);
+    } catch (const std::exception& e) {
+      throw Error(GSI_ERR_HIP, e.what());
+    }
+    return s;
+  }
+  void upload2d_wait_block(void* handle, int64_t b) override {
+    if (!handle) return;
+    bind();
+    try {
+      static_cast<HostStager*>(handle)->wait_block((int)b, st_);
+    } catch (const std::exception& e) {
+      throw Error(GSI_ERR_HIP, e.what());
+    }
+  }
+  void pinned_copy_rate(int64_t bytes, double* h2d_gbs, double* d2h_gbs) override {
+    bind();
+    if (bytes < (1 << 20)) bytes = 1 << 20;
+    void* pin = nullptr;
+    HIP_CHECK(hipHostMalloc(&pin, (size_t)bytes, hipHostMallocDefault));
+    struct FreePin { void* p; ~FreePin() { hipHostFree(p); } } fp{pin};
+    memset(pin, 1, (size_t)bytes);
+    Scratch dev(this, (size_t)bytes / sizeof(double) + 1);
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    struct FreeEv { hipEvent_t a, b; ~FreeEv() { hipEventDestroy(a); hipEventDestroy(b); } } fe{e0, e1};
+    double best[2] = {0.0, 0.0};
+    for (int dir = 0; dir < 2; ++dir)
+      for (int rep = 0; rep < 3; ++rep) {
+        HIP_CHECK(hipEventRecord(e0, st_));
+        if (dir == 0) HIP_CHECK(hipMemcpyAsync(dev.p, pin, (size_t)bytes, hipMemcpyHostToDevice, st_));
+        else HIP_CHECK(hipMemcpyAsync(pin, dev.p, (size_t)bytes, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipEventRecord(e1, st_));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms > 0.f) best[dir] = std::max(best[dir], (double)bytes / (ms * 1e-3) / 1e9);
+      }
+    *h2d_gbs = best[0];
+    *d2h_gbs = best[1];
+  }
+  void upload2d_end(void* handle) override {
+    if (!handle) return;
+    try {
+      static_cast<HostStager*>(handle)->end();
+    } catch (const std::exception& e) {
+      throw Error(GSI_ERR_HIP, e.what());
+    }
   }
   void copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) override {
     if (rows <= 0 || cols <= 0) return;
@@ -239,6 +353,13 @@ class HipBackend : public Backend {
     double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, k));
     hipk::gemm_f64(st_, false, m, l, k, alpha, A, lda, B, ldb, beta, C, ldc, ws);
     check_launch("gemm_nn");
+  }
+  void gemm_nn_rowblock(int64_t m_full, int64_t r0, int64_t mb, int64_t l, int64_t k, const double* A, int64_t lda,
+                        const double* B, int64_t ldb, double* C, int64_t ldc) override {
+    bind();
+    double* ws = gemm_ws(hipk::gemm_rowblock_workspace_doubles(m_full, mb, l, k));
+    hipk::gemm_f64_nn_rowblock(st_, m_full, r0, mb, l, k, A, lda, B, ldb, C, ldc, ws);
+    check_launch("gemm_nn_rowblock");
   }
   void gemm_tn(int64_t m, int64_t l, int64_t k, double alpha, const double* A, int64_t lda, const double* B,
                int64_t ldb, double beta, double* C, int64_t ldc) override {
@@ -1221,6 +1342,9 @@ class HipBackend : public Backend {
   std::string arch_;
   hipStream_t st_ = nullptr;
   hipStream_t st2_ = nullptr;                 // the panel generator of the scattered-point operator
+  std::unique_ptr<HostStager> stager_;        // the pinned staging ring of the host boundary (created at the first large transfer)
+  bool stager_failed_ = false;
+  hipEvent_t ev_stage_ = nullptr;
   hipEvent_t ev_gen_[2] = {nullptr, nullptr}, ev_used_[2] = {nullptr, nullptr};
   int32_t* flags_ = nullptr;  // [0] lu info, [1] chol info, [8] jacobi rotation counter
   double* scal_ = nullptr;

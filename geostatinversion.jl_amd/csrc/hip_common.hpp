@@ -22,6 +22,10 @@ inline bool first_use_on_this_device(std::atomic<uint64_t>& mask) {
 size_t gemm_workspace_doubles(int64_t M, int64_t L, int64_t K);
 void gemm_f64(hipStream_t st, bool transA, int64_t M, int64_t L, int64_t K, double alpha, const double* A,
               int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws);
+// rows [r0, r0 + mb) of the NN product of an M_full-row launch, with that launch's K split (bit-identical blocks)
+size_t gemm_rowblock_workspace_doubles(int64_t M_full, int64_t mb, int64_t L, int64_t K);
+void gemm_f64_nn_rowblock(hipStream_t st, int64_t M_full, int64_t r0, int64_t mb, int64_t L, int64_t K, const double* A,
+                          int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws);
 // C (l x l) = A'A, upper-triangle tiles only; C = A * B with B upper triangular (CholeskyQR: half the flops each)
 size_t gemm_syrk_workspace_doubles(int64_t l, int64_t m);
 // syrk_f64.hip: G = A'A (both triangles) for l <= 320 by the register-resident kernel; false = shape not covered

@@ -69,6 +69,22 @@ void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* 
     cols_to_rows(c, A.n, l, YC.p, Yloc, ldy);
     return;
   }
+  if (A.kind == OP_DENSE && A.pending_upload != nullptr) {
+    // the matrix is still being uploaded in row blocks: Y = A*Omega (RandMatFact.jl:55) block by block as the rows land, each
+    // block with the K split of the whole product (bit-identical to the product of the resident matrix)
+    void* h = A.pending_upload;
+    const int64_t mb = A.pending_block_rows;
+    A.pending_upload = nullptr;                              // (the guard of the entry point still ends the transfer if we throw)
+    {
+      ScopedPhase ph(be, PH_GEMM_N);
+      for (int64_t r0 = 0, b = 0; r0 < A.mloc; r0 += mb, ++b) {
+        be->upload2d_wait_block(h, b);
+        be->gemm_nn_rowblock(A.mloc, r0, std::min(mb, A.mloc - r0), l, A.n, A.data.p, A.ld, X, ldx, Yloc, ldy);
+      }
+    }
+    be->upload2d_end(h);
+    return;
+  }
   if (A.kind == OP_DENSE) {
     ScopedPhase ph(be, PH_GEMM_N);
     be->gemm_nn(A.mloc, l, A.n, 1.0, A.data.p, A.ld, X, ldx, 0.0, Yloc, ldy);   // RandMatFact.jl:55,70

@@ -63,6 +63,12 @@ struct Operator {
   int pc_d = 0, pc_kind = 0;
   double pc_ell = 1.0, pc_sigma2 = 1.0, pc_nugget = 0.0;
   void* plan = nullptr;     // OP_FFT_COV: the backend's circulant-embedding plan (owned; single rank)
+  // OP_DENSE whose rows are still crossing PCIe (gsi_randsvd_dense_host / gsi_rangefinder_dense_host): the handle of
+  // Backend::upload2d_begin and its row-block height.  The FIRST product A*X consumes it -- block by block as the rows land,
+  // bit-identical to the product of the resident matrix -- and clears it; the entry point's guard ends the upload on every
+  // other exit path.  Null everywhere else.
+  mutable void* pending_upload = nullptr;
+  mutable int64_t pending_block_rows = 0;
   Operator() = default;
   Operator(const Operator&) = delete;
   Operator& operator=(const Operator&) = delete;

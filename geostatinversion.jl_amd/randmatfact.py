@@ -40,6 +40,14 @@ def _as_operator(A, ctx=None):
     return dense_operator(ctx, A), True
 
 
+def _is_host_matrix(A, ctx=None):
+    """A plain host matrix on a single-rank context: the host-matrix entry points take it (with a communicator every rank
+    uploads its own block of rows through `dense_operator`)."""
+    if isinstance(A, Operator) or hasattr(A, "_device_operator"):
+        return False
+    return (ctx or default_context()).rank()[1] == 1
+
+
 def colnorms(Y):
     """`colnorms(Y)`  (RandMatFact.jl:7-13)."""
     Y = np.asarray(Y, dtype=np.float64)
@@ -53,6 +61,19 @@ def rangefinder(A, l=None, numiterations=None, *, Omega=None, epsilon=1e-8, r=10
     `rangefinder(A; epsilon=1e-8, r=10)`              (RandMatFact.jl:15-48) when `l` is omitted.
     Returns Q (m x l, orthonormal columns).
     """
+    if l is not None and _is_host_matrix(A, ctx):
+        # rangefinder(A::Matrix, l, numiterations): the matrix goes up in row blocks and the sketch runs under the upload
+        cx = ctx or default_context()
+        Af = L.fmat(A, "A")
+        m, n = Af.shape
+        l, q = int(l), int(numiterations)
+        Om = L.fmat(randn(n, l) if Omega is None else Omega, "Omega")           # RandMatFact.jl:54
+        if Om.shape != (n, l):
+            raise ValueError(f"Omega must be {(n, l)}, got {Om.shape}")
+        Q = np.empty((m, l), order="F")
+        L.check(cx.lib.gsi_rangefinder_dense_host(cx.h, L.dptr(Af), m, n, Af.shape[0], L.dptr(Om), l, q, L.dptr(Q), None),
+                cx.lib)
+        return Q
     op, owned = _as_operator(A, ctx)
     try:
         m, n = op.shape
@@ -91,7 +112,24 @@ def _rangefinder_adaptive(op, epsilon, r):
 
 def randsvd(A, K, p, q, *, Omega=None, return_S=False, ctx=None):
     """`randsvd(A, K::Int, p::Int, q::Int)`  (RandMatFact.jl:83-90): Z (n x (K+p)) with the last p
-    columns zero and Z Z' ~ A.  `return_S` also returns svd(Q'A).S (RandMatFact.jl:86)."""
+    columns zero and Z Z' ~ A.  `return_S` also returns svd(Q'A).S (RandMatFact.jl:86).
+
+    A host matrix (what `getxis(Q::Matrix, ...)` hands over, GeostatInversion.jl:63-70) goes through
+    `gsi_randsvd_dense_host`: uploaded in row blocks, the first pass under the upload."""
+    if _is_host_matrix(A, ctx):
+        cx = ctx or default_context()
+        Af = L.fmat(A, "A")
+        m, n = Af.shape
+        K, p, q = int(K), int(p), int(q)
+        l = K + p
+        Om = L.fmat(randn(n, l) if Omega is None else Omega, "Omega")
+        if Om.shape != (n, l):
+            raise ValueError(f"Omega must be {(n, l)}, got {Om.shape}")
+        Z = np.empty((n, l), order="F")
+        S = np.empty(l)
+        L.check(cx.lib.gsi_randsvd_dense_host(cx.h, L.dptr(Af), m, n, Af.shape[0], L.dptr(Om), K, p, q, L.dptr(Z),
+                                              S.ctypes.data_as(L.c_dp), None), cx.lib)
+        return (Z, S) if return_S else Z
     op, owned = _as_operator(A, ctx)
     try:
         m, n = op.shape

@@ -404,7 +404,16 @@ function rangefinder(A::DeviceOperator, l::Int64, numiterations::Int64)
 		A.c.h, A.h, Omega, l, numiterations, Q))
 	return Q
 end
-rangefinder(A::Matrix{Float64}, l::Int64, numiterations::Int64) = rangefinder(DeviceOperator(A), l, numiterations)
+"The same for a host `Matrix{Float64}`: uploaded in row blocks, the sketch `A * Omega` (RandMatFact.jl:55) runs under the upload."
+function rangefinder(A::Matrix{Float64}, l::Int64, numiterations::Int64; c=ctx())
+	m, n = size(A)
+	Omega = randn(n, l)                                                              # RandMatFact.jl:54
+	Q = Matrix{Float64}(undef, m, l)
+	check(ccall((:gsi_rangefinder_dense_host, libgsi), Cint,
+		(Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Cvoid}),
+		c.h, A, m, n, stride(A, 2), Omega, l, numiterations, Q, C_NULL))
+	return Q
+end
 
 "`rangefinder(A; epsilon=1e-8, r=10)`  (RandMatFact.jl:15-48): the library pulls Julia's randn stream through a callback."
 function rangefinder(A::Matrix{Float64}; epsilon=1e-8, r=10)
@@ -428,7 +437,17 @@ function randsvd(A::DeviceOperator, K::Int, p::Int, q::Int)
 		A.c.h, A.h, Omega, K, p, q, Z, C_NULL))
 	return Z
 end
-randsvd(A::Matrix{Float64}, K::Int, p::Int, q::Int) = randsvd(DeviceOperator(A), K, p, q)
+"`randsvd(Q::Matrix, numxis, p, q)` as `getxis(Q::Matrix, ...)` calls it (GeostatInversion.jl:63-70 -> :20-27): the matrix is
+still on the host; it is uploaded in row blocks through the library's pinned staging ring and the first pass runs under the upload."
+function randsvd(A::Matrix{Float64}, K::Int, p::Int, q::Int; c=ctx())
+	m, n = size(A)
+	Omega = randn(n, K + p)
+	Z = Matrix{Float64}(undef, n, K + p)
+	check(ccall((:gsi_randsvd_dense_host, libgsi), Cint,
+		(Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+		c.h, A, m, n, stride(A, 2), Omega, K, p, q, Z, C_NULL, C_NULL))
+	return Z
+end
 
 "`eig_nystrom(A, Q)`  (RandMatFact.jl:92-102)"
 function eig_nystrom(A::Matrix{Float64}, Q::Matrix{Float64})
