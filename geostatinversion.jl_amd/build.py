@@ -18,6 +18,52 @@ SOURCES = ["gemm_f64.hip", "gemm_f64_gen1.hip", "syrk_f64.hip", "panel_lu.hip", 
 HEADERS = ["backend.hpp", "hip_common.hpp", "pipeline.hpp", "lsqr_state.hpp", "pointcov.hpp", "pointcov_gen.hpp", "host_staging.hpp", "gemm_f64_kernel.inc.hpp", "../../include/gsi_hip.h"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
             "-Wno-unused-result", "-Wno-unused-value"]
+# Every kernel file is compiled with the backend's resource-usage remarks on; what hipcc made of each kernel (VGPRs, AGPRs,
+# SGPRs, scratch, spills, occupancy, LDS) is kept beside the object as build/<source>.resources.json.  The contraction and
+# panel kernels sit on register-allocation cliffs (a zero-offset pointer cost 24 %): tests/test_isa_resources.py
+# compares the hot instantiations with the committed profiles/isa_resources.json and fails when one moves.
+RESOURCE_FLAG = "-Rpass-analysis=kernel-resource-usage"
+_RES_KEYS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+             "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "SGPRs Spill": "sgpr_spills", "VGPRs Spill": "vgpr_spills",
+             "LDS Size [bytes/block]": "lds_bytes_per_block", "Dynamic Stack": "dynamic_stack"}
+
+
+def parse_resource_remarks(text):
+    """{mangled kernel name: {vgprs, agprs, sgprs, scratch_bytes_per_lane, ...}} from hipcc's kernel-resource-usage remarks."""
+    out, cur = {}, None
+    for line in text.splitlines():
+        if "remark:" not in line or "[-Rpass-analysis=kernel-resource-usage]" not in line:
+            continue
+        body = line.split("remark:", 1)[1].replace("[-Rpass-analysis=kernel-resource-usage]", "").strip()
+        if ":" not in body:
+            continue
+        key, val = [x.strip() for x in body.rsplit(":", 1)]
+        if key == "Function Name":
+            cur = out.setdefault(val, {})
+        elif cur is not None and key in _RES_KEYS:
+            cur[_RES_KEYS[key]] = (val == "True") if key == "Dynamic Stack" else int(val)
+    return out
+
+
+def hipcc_version():
+    r = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True)
+    lines = [ln.strip() for ln in r.stdout.splitlines() if ln.strip()]
+    return "; ".join(lines[:2])
+
+
+def kernel_resources():
+    """Resource usage of every kernel of the library as the LAST compile of each source reported it (build() first)."""
+    import json
+    res = {}
+    for src in SOURCES:
+        if not src.endswith(".hip"):
+            continue
+        path = os.path.join(OBJ, src.replace(".", "_") + ".resources.json")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run build() (it recompiles sources whose resource record is absent)")
+        for name, r in json.load(open(path)).items():
+            res[name] = dict(r, source=src)
+    return res
 
 
 def _hipcc():
@@ -44,16 +90,25 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".", "_") + ".o")
         objs.append(o)
-        if force or _newer(o, [s] + hdrs):
-            cmd = [hipcc] + CXXFLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
+        is_hip = src.endswith(".hip")
+        resj = os.path.join(OBJ, src.replace(".", "_") + ".resources.json")
+        if force or _newer(o, [s] + hdrs) or (is_hip and not os.path.exists(resj)):
+            cmd = [hipcc] + CXXFLAGS + (["-x", "hip", RESOURCE_FLAG] if is_hip else []) + ["-c", s, "-o", o]
             jobs.append(cmd)
 
     def run(cmd):
+        import json
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("compile failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+        if RESOURCE_FLAG in cmd:
+            obj = cmd[cmd.index("-o") + 1]
+            with open(obj[:-2] + ".resources.json", "w") as f:
+                json.dump(parse_resource_remarks(r.stderr), f, indent=0, sort_keys=True)
+            # the remarks are not warnings: keep only what is left for the verbose log
+            return "\n".join(ln for ln in r.stderr.splitlines() if "kernel-resource-usage" not in ln and not ln.startswith(" ") and "remark" not in ln)
         return r.stderr
 
     if jobs:
