@@ -101,8 +101,17 @@ def fft_pair_bytes(Ns, Ms):
     return 16.0 * units + 8.0 * M
 
 
-def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234, keep=None, rows=False):
-    """warmup + timed randsvd steps on device-resident inputs; returns (elapsed_s, phases, counters)."""
+def phases_over_ranks(ctx, phases, steps):
+    """max / min over the ranks of every phase's ms per step (collective: every rank calls it)."""
+    import numpy as np
+    names = sorted(phases)
+    allp = ctx.host_allgather([phases[k][0] / max(steps, 1) for k in names])
+    return {k: {"max": float(allp[:, i].max()), "min": float(allp[:, i].min())} for i, k in enumerate(names)}
+
+
+def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234, keep=None, rows=False, profile=1):
+    """warmup + timed randsvd steps on device-resident inputs; returns (elapsed_s, phases, counters).  profile = 2 (several
+    ranks): skew barriers in front of every collective / panel LU, so that waiting for peers is `comm_wait`, not LU time."""
     l = K + p
     lib = ctx.lib
     rank, world = ctx.rank()
@@ -125,7 +134,7 @@ def run_steps(gsi, ctx, op, n, K, p, q, steps, warmup, barrier, seed=1234, keep=
 
     for _ in range(warmup):
         step()
-    ctx.profile(True)
+    ctx.profile(profile)
     ctx.phase_reset()
     barrier()
     t0 = time.perf_counter()
@@ -282,7 +291,8 @@ def one_gpu_implicit_reference():
             if d.get("n_gpus", 1) != 1:
                 continue
             ms = d["secondary"]["implicit_dense_1e6"]["ms_per_step"]
-            return {"ms_per_step": float(ms), "source": os.path.relpath(path, ROOT) + " (recorded 1-GPU line, not re-measured in this run)"}
+            return {"ms_per_step": float(ms), "kernel_source_hash": d.get("kernel_source_hash"),
+                    "source": os.path.relpath(path, ROOT) + " (recorded 1-GPU line, not re-measured in this run)"}
         except Exception:                                   # noqa: BLE001
             continue
     return None
@@ -297,7 +307,9 @@ def secondary_implicit(gsi, ctx, barrier, rows=False, max_over_ranks=None):
     n3, l3 = gi * gi, K3 + p3
     op3 = gsi.gridcov_implicit_operator(ctx, gi, gi, 100.0, kind=1)      # exponential kernel, ell = 100
     keep = {} if rows else None
-    e3, ph3, S3 = run_steps(gsi, ctx, op3, n3, K3, p3, q3, 1, 0, barrier, keep=keep, rows=rows)
+    # N > 1: profile level 2 -- ~20 one-double all-reduces in a step of seconds, and the phases say what was work and what was
+    # waiting for the slowest rank
+    e3, ph3, S3 = run_steps(gsi, ctx, op3, n3, K3, p3, q3, 1, 0, barrier, keep=keep, rows=rows, profile=2 if rows else 1)
     pinfo = run_steps.last_path_info
     op3.close()
     extra = {}
@@ -317,10 +329,18 @@ def secondary_implicit(gsi, ctx, barrier, rows=False, max_over_ranks=None):
                  "trailing_p_columns_max_abs": float(tot[:, K3].max()),
                  "sv_descending_positive": bool(all(S3[i] >= S3[i + 1] for i in range(l3 - 1)) and S3[K3 - 1] > 0),
                  "lu_form": pinfo["lu_form"], "collectives_per_step": pinfo["collectives"],
+                 "phases_ms_max_min_over_ranks": phases_over_ranks(ctx, ph3, 1),
+                 "phases_note": "profile level 2: comm_wait = arrival skew in front of collectives / panel LUs (one-double all-reduces)",
                  "one_gpu_reference": one_gpu_implicit_reference()}
         ref = extra["one_gpu_reference"]
-        if ref:
+        # a ratio only between runs of the SAME kernels: the recorded line must carry this build's source hash
+        if ref and ref.get("kernel_source_hash") == kernel_source_hash():
             extra["speedup_vs_recorded_one_gpu"] = ref["ms_per_step"] / (1e3 * e3)
+        else:
+            extra["speedup_vs_recorded_one_gpu"] = None
+            extra["speedup_note"] = ("no recorded 1-GPU line" if not ref else
+                                     "the recorded 1-GPU line is from another build (kernel_source_hash %s, this build %s): "
+                                     "divide by a 1-GPU run of THIS build" % (ref.get("kernel_source_hash"), kernel_source_hash()))
     gm = ph3["gemm_n"][0] + ph3["gemm_t"][0]
     gc = ph3["gemm_n"][1] + ph3["gemm_t"][1]
     nloc3 = ctx.shard(n3)[1]
@@ -733,8 +753,11 @@ class Rendezvous:
         self.own = False
         if not self.dir:
             base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-            self.dir = os.path.join(base, "gsi-bench-%s-%s-%d" % (os.environ.get("MASTER_PORT", "0"),
-                                                                  os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
+            # one directory per incarnation of the job: a restarted worker group (max_restarts > 0) must not read the id file of
+            # the group before it
+            self.dir = os.path.join(base, "gsi-bench-%s-%s-%d-r%s" % (os.environ.get("MASTER_PORT", "0"),
+                                                                      os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(),
+                                                                      os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")))
             os.makedirs(self.dir, exist_ok=True)
             self.own = True
 
@@ -754,6 +777,14 @@ class Rendezvous:
             time.sleep(0.01)
         with open(path, "rb") as f:
             return f.read()
+
+    def fail(self, why):
+        """Tell the other ranks (they look at every rendezvous wait; the launcher ends them after its grace period)."""
+        try:
+            with open(os.path.join(self.dir, "failed"), "w") as f:
+                f.write("rank %d: %s\n" % (self.rank, why))
+        except OSError:
+            pass
 
     def close(self):
         if self.own and self.rank == 0:
@@ -853,8 +884,15 @@ def main():
     keep = {} if (want_host or vs_one_gpu) else None
     elapsed, phases, Sv = run_steps(gsi, ctx, op, n, K, p, q, args.steps, args.warmup, barrier, keep=keep, rows=use_dist)
     elapsed = max_over_ranks(elapsed)
+    pinfo = run_steps.last_path_info                     # of exactly the timed steps
+    ranks_phases = skew_split = None
+    if use_dist:
+        # the same phases per rank (max / min), and ONE more step with skew barriers (profile level 2): what is waiting for the
+        # slowest rank and what is work -- outside the timed region, the barriers are extra collectives
+        ranks_phases = phases_over_ranks(ctx, phases, args.steps)
+        _, ph2, _ = run_steps(gsi, ctx, op, n, K, p, q, 1, 0, barrier, rows=True, profile=2)
+        skew_split = phases_over_ranks(ctx, ph2, 1)
     counters = ctx.counters()
-    pinfo = run_steps.last_path_info
     counters.update({"lu_form": pinfo["lu_form"], "lu_forms_run_in_timed_steps": pinfo["lu_forms_run"],
                      "lu_selftest_mask": pinfo["lu_selftest_mask"],
                      "collectives_per_step": pinfo["collectives"] / max(args.steps, 1), "n_ranks_seen": pinfo["n_ranks_seen"],
@@ -955,8 +993,11 @@ def main():
             "phases_hbm": phases_hbm,
             "phases_ms_per_step": {k: v[0] / args.steps for k, v in phases.items()},
             "phase_launch_groups_per_step": {k: v[1] / args.steps for k, v in phases.items()},
+            "phases_ms_max_min_over_ranks": ranks_phases,
+            "phases_ms_skew_split_one_step": skew_split,
             "path_counters": counters,
             "algorithmic_bytes_per_step": lrcm_bytes(n, Ns, l, q),
+            "kernel_source_hash": kernel_source_hash(),
         }
         # size-independent property at the full size: the trailing p singular values exist, descending, positive
         out["sv_descending_positive"] = bool(all(Sv[i] >= Sv[i + 1] for i in range(l - 1)) and Sv[K - 1] > 0)
@@ -971,8 +1012,13 @@ def main():
     if world > 1 and not args.no_implicit and not args.no_secondary:
         try:
             imp = secondary_implicit(gsi, ctx, barrier, rows=True, max_over_ranks=max_over_ranks)
-        except gsi.GsiError as exc:                     # a library error on this rank: the other ranks see theirs or time out
-            imp = {"error": f"{type(exc).__name__}: {exc}"}
+        except gsi.GsiError as exc:
+            # a library error inside a collective section: the peers may be in a different collective, so meeting them at the
+            # final barrier could hang until the driver's time-out -- mark the job failed and leave non-zero
+            sys.stderr.write(f"bench.py: rank {rank}: {type(exc).__name__}: {exc}\n")
+            if rdv is not None:
+                rdv.fail(f"{type(exc).__name__} in the row-sharded implicit step")
+            os._exit(4)
         if rank == 0:
             out["secondary"] = {"implicit_dense_1e6": imp}
 

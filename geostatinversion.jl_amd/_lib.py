@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libgsi_hip.so")
 GSI_OK = 0
 ERR_NAMES = {1: "GSI_ERR_ARG", 2: "GSI_ERR_NEG_ITERS", 3: "GSI_ERR_SINGULAR", 4: "GSI_ERR_HIP",
              5: "GSI_ERR_RCCL", 6: "GSI_ERR_OOM", 7: "GSI_ERR_NOT_POSDEF", 8: "GSI_ERR_INTERNAL"}
-PHASES = ["gemm_n", "gemm_t", "lu", "qr", "svd", "small_gemm", "comm", "other"]
+PHASES = ["gemm_n", "gemm_t", "lu", "qr", "svd", "small_gemm", "comm", "other", "comm_wait"]
 UNIQUE_ID_BYTES = 128
 
 c_i64 = C.c_int64

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgsi_hip.so")
-SOURCES = ["gemm_f64.hip", "gemm_f64_gen1.hip", "syrk_f64.hip", "panel_lu.hip", "panel_lu_leaf.hip", "panel_qr.hip", "cholqr.hip", "jacobi_svd.hip", "misc.hip", "lsqr_dev.hip", "pointcov.hip", "pointcov_gemm.hip", "fft_cov.hip",
+SOURCES = ["gemm_f64.hip", "gemm_f64_gen1.hip", "syrk_f64.hip", "panel_lu_leaf.hip", "panel_qr.hip", "cholqr.hip", "jacobi_svd.hip", "misc.hip", "lsqr_dev.hip", "pointcov_gemm.hip", "fft_cov.hip",
            "hip_backend.hip", "pipeline.cpp", "api.cpp"]
 HEADERS = ["backend.hpp", "hip_common.hpp", "pipeline.hpp", "lsqr_state.hpp", "pointcov.hpp", "pointcov_gen.hpp", "host_staging.hpp", "gemm_f64_kernel.inc.hpp", "../../include/gsi_hip.h"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",

@@ -69,7 +69,9 @@ class Context:
 
     # ---- measurement ----
     def profile(self, on=True):
-        L.check(self.lib.gsi_ctx_profile(self.h, int(bool(on))), self.lib)
+        """0 / False: off; 1 / True: phase events; 2: additionally skew barriers in front of collectives and panel LUs
+        (`comm_wait` phase; several ranks, diagnostic steps only)."""
+        L.check(self.lib.gsi_ctx_profile(self.h, int(on)), self.lib)
 
     def phase_reset(self):
         L.check(self.lib.gsi_ctx_phase_reset(self.h), self.lib)

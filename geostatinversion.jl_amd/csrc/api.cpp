@@ -359,6 +359,17 @@ int gsi_op_pointcov_implicit(gsi_ctx* ctx, gsi_op** op, const double* points, in
     REQUIRE(n >= 1 && d >= 1 && d <= 3, "point covariance: need n >= 1 points in 1, 2 or 3 dimensions");
     REQUIRE(kind >= 0 && kind < pointcov::NUM_KINDS, "point covariance: kind 0 Gaussian, 1 exponential, 2 Matern 3/2, 3 Matern 5/2");
     REQUIRE(ell > 0.0 && sigma2 > 0.0 && nugget >= 0.0, "point covariance: need ell > 0, sigma2 > 0, nugget >= 0");
+    REQUIRE(std::isfinite(ell) && std::isfinite(sigma2) && std::isfinite(nugget), "point covariance: parameters must be finite");
+    // The in-loader generator has no clamp in front of its exponential (every vector instruction there is matrix time lost):
+    // it saturates to 0 by itself for arguments up to ~1e77 and would return inf / NaN beyond.  The accepted range
+    // is checked here instead, once, on the host: finite coordinates within 1e29 correlation lengths of the first point
+    // (squared scaled distances <= 3e58 x c1^2: 19 orders of magnitude inside what the generator handles).
+    for (int64_t i = 0; i < n; ++i)
+      for (int a = 0; a < d; ++a) {
+        const double x = points[i * d + a], dx = (x - points[a]) / ell;
+        REQUIRE(std::isfinite(x) && std::fabs(dx) <= 1e29,
+                "point covariance: coordinates must be finite and within 1e29 correlation lengths of the first point");
+      }
     check_shard(ctx->c, n, row0, m_local);
     std::unique_ptr<gsi_op> o(new gsi_op());
     Operator& A = o->op;
@@ -1079,6 +1090,7 @@ int gsi_ctx_profile(gsi_ctx* ctx, int enable) {
   return guarded([&] {
     REQUIRE(ctx, "ctx is NULL");
     ctx->c.be->profile(enable != 0);
+    ctx->c.profile_level = enable;
   });
 }
 int gsi_ctx_phase_reset(gsi_ctx* ctx) {

@@ -20,7 +20,7 @@ struct Error : std::runtime_error {
 
 enum Phase : int {
   PH_GEMM_N = 0, PH_GEMM_T = 1, PH_LU = 2, PH_QR = 3, PH_SVD = 4, PH_SMALL_GEMM = 5,
-  PH_COMM = 6, PH_OTHER = 7, PH_COUNT = 8
+  PH_COMM = 6, PH_OTHER = 7, PH_COMM_WAIT = 8, PH_COUNT = 9
 };
 
 // All pointers below are "backend memory" (HBM for the HIP backend), column-major fp64.

@@ -267,11 +267,15 @@ double pointcov_point_scale(int kind, double inv_ell) {
     default: return inv_ell;
   }
 }
-// pts (d x n, point i = column i) -> 32-byte records scale * (x, y, z, 0)
+// pts (d x n, point i = column i) -> 32-byte records scale * (x - x_0, y - y_0, z - z_0, 0).  The translation by the first
+// point makes the scaling translation-invariant: the kernels subtract SCALED coordinates, and scaling raw
+// coordinates rounds at the size of their common offset -- UTM-like points (x ~ 5e5, y ~ 4.6e6, ell = 20) lost 5 digits of
+// every entry (1.5e-11 against 1e-16 for subtract-then-scale).  After the translation the rounding is relative to the EXTENT
+// of the point set, as in pointcov::kernel's subtract-then-scale; it costs the loader nothing.
 __global__ __launch_bounds__(256) void pointcov_pad_kernel(const double* __restrict__ pts, int d, int64_t n, double scale, double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  for (int a = 0; a < 4; ++a) out[4 * i + a] = (a < d) ? scale * pts[i * d + a] : 0.0;
+  for (int a = 0; a < 4; ++a) out[4 * i + a] = (a < d) ? scale * (pts[i * d + a] - pts[a]) : 0.0;
 }
 void pointcov_pad_points(hipStream_t st, const double* pts, int d, int64_t n, double scale, double* out4) {
   hipLaunchKernelGGL(pointcov_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pts, d, n, scale, out4);

@@ -61,7 +61,7 @@ struct RoctxApi {
 };
 static RoctxApi& roctx() { static RoctxApi api; return api; }
 static const char* const kPhaseNames[PH_COUNT] = {"gsi:A*X", "gsi:A'*X", "gsi:lu(Y).L", "gsi:thin QR", "gsi:svd(l x l)",
-                                                 "gsi:panel x (l x l)", "gsi:collective", "gsi:other"};
+                                                 "gsi:panel x (l x l)", "gsi:collective", "gsi:other", "gsi:waiting for peers"};
 
 class HipBackend : public Backend {
  public:
@@ -98,11 +98,6 @@ class HipBackend : public Backend {
     hipFree(flags_);
     hipFree(scal_);
     if (mr_recs_) hipFree(mr_recs_);
-    if (st2_) {
-      hipStreamSynchronize(st2_);
-      for (int i = 0; i < 2; ++i) { hipEventDestroy(ev_gen_[i]); hipEventDestroy(ev_used_[i]); }
-      hipStreamDestroy(st2_);
-    }
     hipStreamDestroy(st_);
   }
   const char* name() const override { return "hip-gfx950"; }
@@ -376,74 +371,27 @@ class HipBackend : public Backend {
     check_launch("gemm_nn_gridcov");
   }
 
-  // Scattered-point covariance, row-streamed: panels of `pr` rows of G are generated on a second stream (pointcov.hip)
-  // while the stored-operand contraction consumes the previous one; two panels ping-pong, events order them.
+  // Scattered-point covariance, row-streamed: the entries are generated inside the contraction's tile loader (gemm_f64.hip
+  // GEN 2: 128 x 160 tiles; pointcov_gemm.hip: 96 x 320) -- nothing of A ever exists in HBM.  (Round 3's form, row panels of A
+  // generated into HBM on a second stream, is kept as tools/rejected_kernels/pointcov_round3_panels.hip.txt: 39 TFLOP/s
+  // against 59.)
   void gemm_nn_pointcov(int64_t m, int64_t l, int64_t k, const double* pts, int d, int kind, double ell, double sigma2,
                         double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
                         int64_t ldc) override {
     bind();
     if (m <= 0 || l <= 0 || k <= 0) return;
-    // Default (round 4): the entries are generated inside the contraction's tile loader (gemm_f64.hip, GEN 2) -- nothing of A
-    // ever exists in HBM.  GSI_POINTCOV_PANELS=1 keeps round 3's row panels generated on a second stream (A/B).
-    static const bool panels = (getenv("GSI_POINTCOV_PANELS") != nullptr && getenv("GSI_POINTCOV_PANELS")[0] == '1');
-    if (!panels) {
-      const int64_t npts = std::max(roff + m, koff + k);
-      Scratch p4(this, (size_t)4 * npts);                  // the points as 32-byte records (x, y, z, 0): one scalar load each
-      hipk::pointcov_pad_points(st_, pts, d, npts, hipk::pointcov_point_scale(kind, 1.0 / ell), p4.p);
-      double* ws = gemm_ws(hipk::gemm_pointcov_workspace_doubles(m, l, k));
-      // the wide kernel streams a tile-ordered copy of the sketch panel (k x l doubles); memory is never a reason to fail: without
-      // the copy the product runs on the 128 x 160 kernel, which reads X where it lies
-      double* xpack = nullptr;
-      const size_t xdoubles = hipk::gemm_pointcov_pack_doubles(m, l, k);          // 0: not the wide kernel's product
-      if (xdoubles > 0) { try { xpack = alloc(xdoubles); } catch (const Error&) { xpack = nullptr; } }
-      struct Free { HipBackend* be; double* p; ~Free() { if (p) be->release(p); } } xfree{this, xpack};
-      hipk::gemm_f64_pointcov(st_, m, l, k, p4.p, npts, d, kind, sigma2, nugget, roff, koff, B, ldb, C, ldc, ws, xpack);
-      check_launch("gemm_nn_pointcov (in-loader generator)");
-      return;
-    }
-    pointcov::Params prm{d, kind, 1.0 / ell, sigma2, nugget};
-    // panel height: a multiple of 128 rows (the contraction's row block), <= m.  Tall panels keep the contraction efficient
-    // (its output tile count grows with the panel height: measured 35 TFLOP/s with 4 GB panels, 39 with 16 GB at n = 2e5):
-    // 32 GB per panel by default (two of them, of 288 GB), GSI_POINTCOV_PANEL_MB overrides.
-    static const int64_t panel_mb = getenv("GSI_POINTCOV_PANEL_MB") ? atoll(getenv("GSI_POINTCOV_PANEL_MB")) : 32768;
-    int64_t pr = (panel_mb << 20) / (8 * k);
-    pr = std::max<int64_t>(128, (pr / 128) * 128);
-    if (pr > m) pr = ((m + 1) / 2) * 2;                      // even leading dimension: 16-byte loads in the contraction
-    if (!st2_) {
-      HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
-      for (int i = 0; i < 2; ++i) { HIP_CHECK(hipEventCreateWithFlags(&ev_gen_[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_used_[i], hipEventDisableTiming)); }
-    }
-    double* P[2] = {nullptr, nullptr};
-    for (;;) {                                               // memory is the operator's to use, but never a reason to fail
-      try {
-        P[0] = alloc((size_t)pr * k);
-        P[1] = (m > pr) ? alloc((size_t)pr * k) : nullptr;
-        break;
-      } catch (const Error&) {
-        if (P[0]) { release(P[0]); P[0] = nullptr; }
-        trim_pool(0);
-        if (pr <= 128) throw;
-        pr = std::max<int64_t>(128, ((pr / 2) / 128) * 128);
-      }
-    }
-    // the panels go back to the block cache on every exit path (a HIP_CHECK or an allocation below may throw)
-    struct PanelGuard { HipBackend* be; double** P; ~PanelGuard() { for (int i = 0; i < 2; ++i) if (P[i]) { be->release(P[i]); P[i] = nullptr; } } } guard{this, P};
-    double* ws = gemm_ws(hipk::gemm_workspace_doubles(std::min(pr, m), l, k));
-    // the generator must not overwrite a panel buffer that earlier work on st_ may still read (pooled memory)
-    HIP_CHECK(hipEventRecord(ev_used_[0], st_));
-    HIP_CHECK(hipEventRecord(ev_used_[1], st_));
-    const int64_t npan = (m + pr - 1) / pr;
-    for (int64_t p = 0; p < npan; ++p) {
-      const int b = (int)(p & 1);
-      const int64_t r0 = p * pr, rows = std::min(pr, m - r0);
-      HIP_CHECK(hipStreamWaitEvent(st2_, ev_used_[b], 0));   // the contraction that read this buffer two panels ago is done
-      hipk::pointcov_panel(st2_, P[b], pr, rows, k, pts, prm, roff + r0, koff);
-      HIP_CHECK(hipEventRecord(ev_gen_[b], st2_));
-      HIP_CHECK(hipStreamWaitEvent(st_, ev_gen_[b], 0));
-      hipk::gemm_f64(st_, false, rows, l, k, 1.0, P[b], pr, B, ldb, 0.0, C + r0, ldc, ws);
-      HIP_CHECK(hipEventRecord(ev_used_[b], st_));
-    }
-    check_launch("gemm_nn_pointcov");     // (the guard releases the panels: stream-ordered pool, the next user is ordered after st_'s work)
+    const int64_t npts = std::max(roff + m, koff + k);
+    Scratch p4(this, (size_t)4 * npts);                  // the points as 32-byte records (x, y, z, 0): one scalar load each
+    hipk::pointcov_pad_points(st_, pts, d, npts, hipk::pointcov_point_scale(kind, 1.0 / ell), p4.p);
+    double* ws = gemm_ws(hipk::gemm_pointcov_workspace_doubles(m, l, k));
+    // the wide kernel streams a tile-ordered copy of the sketch panel (k x l doubles); memory is never a reason to fail: without
+    // the copy the product runs on the 128 x 160 kernel, which reads X where it lies
+    double* xpack = nullptr;
+    const size_t xdoubles = hipk::gemm_pointcov_pack_doubles(m, l, k);          // 0: not the wide kernel's product
+    if (xdoubles > 0) { try { xpack = alloc(xdoubles); } catch (const Error&) { xpack = nullptr; } }
+    struct Free { HipBackend* be; double* p; ~Free() { if (p) be->release(p); } } xfree{this, xpack};
+    hipk::gemm_f64_pointcov(st_, m, l, k, p4.p, npts, d, kind, sigma2, nugget, roff, koff, B, ldb, C, ldc, ws, xpack);
+    check_launch("gemm_nn_pointcov (in-loader generator)");
   }
 
   // ---- matrix-free FFT covariance ----
@@ -464,6 +412,10 @@ class HipBackend : public Backend {
       Mtot *= p->M[d];
       ++d;
     }
+    // element offsets inside one column pair's array are 32-bit in the pass kernels (fft_cov.hip): refuse such grids HERE, before
+    // the spectrum and the work array (tens of GB) are allocated, not at the first product
+    if (Mtot >= ((int64_t)1 << 31))
+      throw Error(GSI_ERR_ARG, "fft covariance: the embedding grid must have fewer than 2^31 points (e.g. 1024 x 512 x 512 embeds to 2^31)");
     // work array: as many column pairs at once as fit ~2 GB, at most 64
     int64_t nb = ((int64_t)2 << 30) / (16 * Mtot);
     p->nb_max = (int)std::max<int64_t>(1, std::min<int64_t>(nb, 64));
@@ -544,7 +496,6 @@ class HipBackend : public Backend {
     bind();
     // Panels of up to 4096 rows per CU: leaves held in registers, left-looking blocks, streaming rank-64 updates
     // (panel_lu_leaf.hip).  Everything else takes the streamed leaves below.
-    static const bool force_sweeps = (getenv("GSI_LU_SWEEPS") != nullptr);
     hipk::Lu2Work w2;
     static const bool tall_first = (getenv("GSI_LU_TALL") != nullptr && getenv("GSI_LU_TALL")[0] == '1');
     // Panels taller than the register file holds (up to GSI_LU_OV_MAX rows, default 5 x 2^20): the resident kernel on all
@@ -555,7 +506,7 @@ class HipBackend : public Backend {
     // Ranks that SHARE this device (the RCCL-free communicators, one-GPU rehearsals of a multi-GPU job) each factor their
     // replicated panel with a whole-chip grid of their own: the grids cannot all be resident, so the persistent kernel is
     // not a candidate at all (seen: 2 rank processes on one GPU, gathered 10^6 x 320 panel: a poll time-out on some runs).
-    const bool resident_ok = !force_sweeps && !tall_first && !lu2_lost_ && ranks_sharing_device_ <= 1;
+    const bool resident_ok = !tall_first && !lu2_lost_ && ranks_sharing_device_ <= 1;
     bool fits = resident_ok && hipk::lu2_config(m, ncus_, &w2.bs, &w2.rpt, &w2.grid) && lu2_fits(w2.bs, w2.rpt, w2.grid);
     if (!fits && resident_ok && !ov_off && m <= ov_max && ncus_ >= 1) {
       const int g = std::min(ncus_, 256);
@@ -591,43 +542,15 @@ class HipBackend : public Backend {
     // Everything the resident kernel does not take -- panels the register file cannot hold (more than 4096 rows per CU), a
     // context that lost co-residency once, a leaf grid that does not fit the chip: streamed leaves with lazily evaluated
     // candidates (same blocks, pivots and arithmetic; no spin-waits between workgroups).  GSI_LU_TALL=1 forces it for any
-    // height (tests: bit-identical to the resident kernel), GSI_LU_TALL=0 / GSI_LU_SWEEPS=1 take the per-column sweeps of
-    // round 1 instead (A/B).
-    static const char* tall_env = getenv("GSI_LU_TALL");
-    const bool tall_off = tall_env != nullptr && tall_env[0] == '0';
-    if (!force_sweeps && !tall_off && m < ((int64_t)1 << 31)) {
-      grow(ws_lu_, hipk::lu3_work_bytes(l));
-      int32_t* ipiv_dev = nullptr;
-      hipk::lu3_L(st_, Y, m, l, ld, ws_lu_.p, flags_ + 0, &ipiv_dev);
-      check_launch("lu3_L");
-      if (ipiv_host) {
-        HIP_CHECK(hipMemcpyAsync(ipiv_host, ipiv_dev, sizeof(int32_t) * l, hipMemcpyDeviceToHost, st_));
-        HIP_CHECK(hipStreamSynchronize(st_));
-      }
-      return;
-    }
-    const int64_t nb = hipk::lu_max_blocks(m);
-    const size_t per_set = sizeof(double) * (size_t)nb + sizeof(int64_t) * (size_t)nb +
-                           sizeof(double) * (size_t)nb * (hipk::LU_LEAF + 1) + sizeof(double) * 16;
-    const size_t need = 2 * per_set + sizeof(int32_t) * (l + 4) + 256;
-    grow(ws_lu_, need);
-    char* base = (char*)ws_lu_.p;
-    hipk::LuWork w;
-    for (int s = 0; s < 2; ++s) {
-      w.pval[s] = (double*)base; base += sizeof(double) * nb;
-      w.pidx[s] = (int64_t*)base; base += sizeof(int64_t) * nb;
-      w.cand[s] = (double*)base; base += sizeof(double) * nb * (hipk::LU_LEAF + 1);
-      w.rowsave[s] = (double*)base; base += sizeof(double) * 16;
-    }
-    w.ipiv = (int32_t*)base;
-    w.info = flags_ + 0;
-    w.maxblocks = nb;
-    // trailing updates: M <= m, L <= l, K = LU_NB  (never split) -> no slab workspace needed
-    double* ws = gemm_ws(hipk::gemm_workspace_doubles(m, l, hipk::LU_NB));
-    hipk::lu_L(st_, Y, m, l, ld, w, ws);
-    check_launch("lu_L");
+    // height (tests: bit-identical to the resident kernel).  (Round 1's per-column sweeps, the fall-back behind these through
+    // round 4, are kept as tools/rejected_kernels/panel_lu_round1_sweeps.hip.txt.)
+    if (m >= ((int64_t)1 << 31)) throw Error(GSI_ERR_ARG, "lu: panels of 2^31 rows and more are not supported");
+    grow(ws_lu_, hipk::lu3_work_bytes(l));
+    int32_t* ipiv_dev = nullptr;
+    hipk::lu3_L(st_, Y, m, l, ld, ws_lu_.p, flags_ + 0, &ipiv_dev);
+    check_launch("lu3_L");
     if (ipiv_host) {
-      HIP_CHECK(hipMemcpyAsync(ipiv_host, w.ipiv, sizeof(int32_t) * l, hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipMemcpyAsync(ipiv_host, ipiv_dev, sizeof(int32_t) * l, hipMemcpyDeviceToHost, st_));
       HIP_CHECK(hipStreamSynchronize(st_));
     }
   }
@@ -1341,11 +1264,9 @@ class HipBackend : public Backend {
   int ncus_ = 0;
   std::string arch_;
   hipStream_t st_ = nullptr;
-  hipStream_t st2_ = nullptr;                 // the panel generator of the scattered-point operator
   std::unique_ptr<HostStager> stager_;        // the pinned staging ring of the host boundary (created at the first large transfer)
   bool stager_failed_ = false;
   hipEvent_t ev_stage_ = nullptr;
-  hipEvent_t ev_gen_[2] = {nullptr, nullptr}, ev_used_[2] = {nullptr, nullptr};
   int32_t* flags_ = nullptr;  // [0] lu info, [1] chol info, [8] jacobi rotation counter
   double* scal_ = nullptr;
   DevBuf ws_gemm_, ws_lu_, ws_qr_, ws_svd_, ws_blas2_, ws_lus_, ws_svdf_, ws_qr_hh_;

@@ -42,7 +42,7 @@ void gemm_f64_trmm_upper(hipStream_t st, int64_t M, int64_t L, int64_t K, const 
 void gemm_f64_gridcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* tab, int64_t nx, int64_t ny,
                       int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C, int64_t ldc, double* ws);
 
-// ---- pointcov.hip: row panels of a scattered-point covariance ----
+// ---- the scattered-point covariance (gemm_f64.hip GEN 2, pointcov_gemm.hip) ----
 // the scattered-point covariance generated inside the contraction's tile loader (gemm_f64.hip, GEN 2); pts4: 32-byte records
 void gemm_f64_pointcov(hipStream_t st, int64_t M, int64_t L, int64_t K, const double* pts4, int64_t npts, int d, int kind,
                        double sigma2, double nugget, int64_t roff, int64_t koff, const double* B, int64_t ldb, double* C,
@@ -59,9 +59,6 @@ int gemm_choose_split(int64_t nwg, int64_t K);
 // C = sum over the nsplit slabs (M x L each, leading dimension M), fixed order
 void gemm_splitk_reduce(hipStream_t st, int64_t M, int64_t L, int nsplit, const double* slabs, double* C, int64_t ldc);
 void pointcov_pad_points(hipStream_t st, const double* pts, int d, int64_t n, double scale, double* out4);
-void pointcov_panel(hipStream_t st, double* P, int64_t ldp, int64_t rows, int64_t cols, const double* pts,
-                    const pointcov::Params& prm, int64_t roff, int64_t koff);
-
 // ---- fft_cov.hip ----
 int64_t fft_embed_size(int64_t N);   // next power of two >= 2 N (1 for a singleton axis)
 size_t fft_plan_doubles(const int64_t M[3]);   // spectrum + scratch + twiddle table
@@ -74,22 +71,6 @@ void fft_spectrum_natural(hipStream_t st, double* lam, const int64_t M[3], doubl
 void fft_finish_plan(hipStream_t st, double* lam, double* part64, const int64_t M[3]);
 void fft_cov_apply(hipStream_t st, const int64_t N[3], const int64_t M[3], const double* lam, double2* W, int nb_max,
                    int64_t l, const double* X, int64_t ldx, double* Y, int64_t ldy);
-
-// ---- panel_lu.hip ----
-struct LuWork {
-  // ping-pong sets (column parity): what the sweep of column j leaves for the sweep of column j+1
-  double* pval[2];     // [maxblocks] per-workgroup arg-max values of column j
-  int64_t* pidx[2];    // [maxblocks] per-workgroup arg-max rows
-  double* cand[2];     // [maxblocks * LU_LEAF] live-column values of each workgroup's candidate row
-  double* rowsave[2];  // [LU_LEAF] live-column values of row j (the row the pivot will be swapped with)
-  int32_t* ipiv;       // [l] pivot rows (0-based)
-  int32_t* info;       // [1] first exactly-zero pivot (1-based), 0 if none
-  int64_t maxblocks;
-};
-constexpr int LU_NB = 64;     // widest outer block (trailing update through the MFMA GEMM): very tall panels; 32 otherwise
-constexpr int LU_LEAF = 8;    // columns factored by per-column sweeps; blocks in between are split recursively
-int64_t lu_max_blocks(int64_t m);
-void lu_L(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld, const LuWork& w, double* gemm_ws);
 
 // ---- panel_lu_leaf.hip: register-resident leaves + streaming rank-K updates (panels of <= 4096 rows per CU) ----
 constexpr int LU2_LEAF = 8;           // leaf width: columns a thread keeps in registers

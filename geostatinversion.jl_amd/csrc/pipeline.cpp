@@ -44,6 +44,22 @@ static void implicit_mul(Backend* be, const Operator& A, int64_t m, int64_t l, i
   if (A.kind == OP_GRIDCOV_IMPLICIT) be->gemm_nn_gridcov(m, l, k, A.data.p, A.gx, A.gy, roff, koff, B, ldb, C, ldc);
   else be->gemm_nn_pointcov(m, l, k, A.data.p, A.pc_d, A.pc_kind, A.pc_ell, A.pc_sigma2, A.pc_nugget, roff, koff, B, ldb, C, ldc);
 }
+// With profile level 2 the ranks meet in a one-double all-reduce before every collective and every row-sharded LU: what a
+// rank then waits for its peers (load skew, a slower GPU) is timed as PH_COMM_WAIT instead of inflating the phase that follows
+// (profiles/r04_rehearsal_2ranks_one_gpu.json: "lu" 2445 ms where one rank takes 31 -- nobody could tell waiting from work).
+static void skew_barrier(Context& c) {
+  if (!c.comm || c.profile_level < 2) return;
+  Backend* be = c.be.get();
+  Buf one(be, 1);
+  be->fill_zero(one.p, 1);
+  ScopedPhase ph(be, PH_COMM_WAIT);
+  c.comm->allreduce_sum(one.p, 1);
+}
+struct CommPhase {
+  Backend* be;
+  explicit CommPhase(Context& c) : be(c.be.get()) { skew_barrier(c); be->phase_begin(PH_COMM); }
+  ~CommPhase() { be->phase_end(PH_COMM); }
+};
 static bool is_implicit(const Operator& A) { return A.kind == OP_GRIDCOV_IMPLICIT || A.kind == OP_POINTCOV; }
 
 void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* Yloc, int64_t ldy) {
@@ -103,7 +119,7 @@ void op_mul(const Operator& A, const double* X, int64_t ldx, int64_t l, double* 
     else be->fill_zero(T.p, (size_t)A.N * l);
   }
   if (c.comm) {
-    ScopedPhase ph(be, PH_COMM);
+    CommPhase ph(c);
     c.comm->allreduce_sum(T.p, (size_t)A.N * l);
   }
   if (A.mloc > 0) {
@@ -124,7 +140,7 @@ void gather_rows(Context& c, const Operator& A, const double* Yloc, int64_t ldy,
   if (A.mloc < pad) be->fill_zero(send.p, (size_t)pad * l);
   be->copy2d(send.p, pad, Yloc, ldy, A.mloc, l);
   {
-    ScopedPhase ph(be, PH_COMM);
+    CommPhase ph(c);
     c.comm->allgather(send.p, recv.p, (size_t)pad * l);
   }
   for (int g = 0; g < G; ++g) {
@@ -164,7 +180,7 @@ void rows_to_cols(Context& c, int64_t n, int64_t l, const double* Rloc, int64_t 
       if (valid > 0 && nloc > 0) be->copy2d(send.p + (size_t)d * blk, pad_n, Rloc + (c0d + j) * ldr, ldr, nloc, valid);
     }
     {
-      ScopedPhase ph(be, PH_COMM);
+      CommPhase ph(c);
       c.comm->alltoall(send.p, recv.p, (size_t)blk);
     }
     const int64_t mine = std::max<int64_t>(0, std::min(w, lloc - j));
@@ -195,7 +211,7 @@ void cols_to_rows(Context& c, int64_t n, int64_t l, const double* Cloc, double* 
       if (nd > 0) be->copy2d(send.p + (size_t)d * blk, pad_n, Cloc + r0d + j * n, n, nd, mine);
     }
     {
-      ScopedPhase ph(be, PH_COMM);
+      CommPhase ph(c);
       c.comm->alltoall(send.p, recv.p, (size_t)blk);
     }
     for (int s2 = 0; s2 < G; ++s2) {                      // from rank s2: my rows of its columns
@@ -248,7 +264,7 @@ void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, dou
       be->fftcov_apply(A.plan, lloc, XC.p, A.n, YC.p, A.n);
     }
     {
-      ScopedPhase ph(be, PH_COMM);
+      CommPhase ph(c);
       c.comm->allgather(YC.p, all.p, (size_t)A.n * pad_l);
     }
     for (int g = 0; g < G; ++g) {
@@ -267,7 +283,7 @@ void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, dou
         for (int64_t cidx = 0; cidx < l; ++cidx) be->fill_zero(Z + cidx * ldz, (size_t)A.n);
     }
     if (c.comm) {
-      ScopedPhase ph(be, PH_COMM);
+      CommPhase ph(c);
       if (ldz == A.n) c.comm->allreduce_sum(Z, (size_t)A.n * l);
       else throw Error(GSI_ERR_INTERNAL, "op_mul_t: strided output with a communicator");
     }
@@ -284,7 +300,7 @@ void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, dou
         for (int64_t cidx = 0; cidx < l; ++cidx) be->fill_zero(Z + cidx * ldz, (size_t)A.n);
     }
     if (c.comm) {
-      ScopedPhase ph(be, PH_COMM);
+      CommPhase ph(c);
       if (ldz == A.n) c.comm->allreduce_sum(Z, (size_t)A.n * l);
       else throw Error(GSI_ERR_INTERNAL, "op_mul_t: strided output with a communicator");
     }
@@ -297,7 +313,7 @@ void op_mul_t(const Operator& A, const double* Xloc, int64_t ldx, int64_t l, dou
     be->gemm_tn(A.N, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, T.p, A.N);
   }
   if (c.comm) {
-    ScopedPhase ph(be, PH_COMM);
+    CommPhase ph(c);
     c.comm->allreduce_sum(T.p, (size_t)A.N * l);
   }
   if (!c.comm && ldz == A.m) {
@@ -330,7 +346,7 @@ static Buf op_mul_t_sharded(const Operator& A, const double* Xloc, int64_t ldx, 
       be->gemm_tn(A.N, l, A.mloc, 1.0, A.data.p, A.ld, Xloc, ldx, 0.0, T.p, A.N);
     }
     {
-      ScopedPhase ph(be, PH_COMM);
+      CommPhase ph(c);
       c.comm->allreduce_sum(T.p, (size_t)A.N * l);
     }
     Buf Wloc(be, (size_t)std::max<int64_t>(A.mloc, 1) * l);
@@ -362,7 +378,7 @@ static Buf op_mul_t_sharded(const Operator& A, const double* Xloc, int64_t ldx, 
   }
   P.reset();
   {
-    ScopedPhase ph(be, PH_COMM);
+    CommPhase ph(c);
     c.comm->reduce_scatter_sum(send.p, recv.p, (size_t)pad * l);
   }
   if (nloc == pad) return recv;
@@ -377,6 +393,7 @@ static void note_lu_form(Context& c, Context::LuForm f) {
 }
 
 static void lu_panel(Context& c, double* Y, int64_t rows, int64_t l) {
+  skew_barrier(c);                         // profile level 2: the replicated factorizations start together on every rank
   ScopedPhase ph(c.be.get(), PH_LU);
   if (c.comm) note_lu_form(c, Context::LU_REPLICATED);
   c.be->lu_L(Y, rows, l, rows, nullptr);   // F = lu(Y); Q = F.L   RandMatFact.jl:60-61,68-69,72-73
@@ -449,6 +466,7 @@ static int lus_mr_selftest(Context& c) {
 void lu_panel_sharded(Context& c, double* Yloc, int64_t m, int64_t row0, int64_t mloc, int64_t l) {
   Backend* be = c.be.get();
   const int G = c.nranks();
+  skew_barrier(c);                           // profile level 2: arrival skew is PH_COMM_WAIT, not LU time
   if (G > 1 && l > (m + G - 1) / G)
     throw Error(GSI_ERR_INTERNAL, "lu_panel_sharded: the first rank must hold the first l rows");
   // One persistent launch per leaf and rank, pivot exchange inside the kernels (peer-written records), when the backend
@@ -639,7 +657,7 @@ static void tsqr(Context& c, int64_t m, int64_t row0, int64_t mloc, Buf& Yloc, i
     be->qr_thinQ(Yloc.p, mloc, l, mloc, R.p);
   }
   {
-    ScopedPhase ph(be, PH_COMM);
+    CommPhase ph(c);
     c.comm->allgather(R.p, Rall.p, (size_t)l * l);
   }
   const int64_t sl = (int64_t)G * l;
@@ -799,6 +817,7 @@ static void svd_rows(const Operator& A, Buf& Q, int64_t K, int64_t l, double* Zl
   Q.reset();
   Buf R(be, (size_t)l * l), U(be, (size_t)l * l);
   tsqr(c, A.n, r0n, nloc, Wloc, l, R.p);
+  skew_barrier(c);
   {
     ScopedPhase ph(be, PH_SVD);
     be->svd_small(R.p, l, U.p, S);                         // (), S, V = svd(B)                    :86

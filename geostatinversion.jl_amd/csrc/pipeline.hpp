@@ -43,6 +43,7 @@ struct Context {
   int64_t lu_form_last = LU_NONE;
   int64_t lu_form_count[LU_FORMS] = {0, 0, 0, 0, 0, 0};
   int64_t ranks_seen = 1;              // sum over the communicator of one per rank, taken when it was created
+  int profile_level = 0;               // gsi_ctx_profile: 2 = skew barriers in front of collectives / sharded LUs (PH_COMM_WAIT)
   int64_t lu_timeouts_recovered = 0;   // entry points re-run transparently after a lost co-residency (api.cpp:with_retry)
   int rank() const { return comm ? comm->rank : 0; }
   int nranks() const { return comm ? comm->nranks : 1; }

@@ -1,5 +1,5 @@
 // pointcov.hpp -- the stationary covariance kernels of the scattered-point implicit operator (SURVEY.md 8b "kernel-function
-// covariance: coords + kernel id + params"), one definition for the device generator (pointcov.hip) and the CPU reference
+// covariance: coords + kernel id + params"), one definition for the device code (the generator table, tests of the in-loader entry) and the CPU reference
 // backend of the tests.  r = |x_i - x_j| / ell.
 #pragma once
 #include <cmath>

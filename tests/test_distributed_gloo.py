@@ -72,6 +72,21 @@ def _worker(rank, world, port, q):
             s1 = np.linalg.svd(Q.T @ A, compute_uv=False)
             s2 = np.linalg.svd(Qr.T @ A, compute_uv=False)
             results[f"dense_q{qq}_range"] = rel_sv_err(s1, s2, K)
+        # profile level 2 (gsi_ctx_profile): every collective and every panel LU is preceded by a one-double all-reduce counted
+        # as the phase `comm_wait`; the numbers are the same, the extra collectives show in gsi_ctx_path_info
+        Om = rng.standard_normal((143, 16))
+        ctx.profile(1)
+        ctx.phase_reset()
+        Z1, S1 = gsi.randsvd(A, 10, 6, 2, Omega=Om, return_S=True, ctx=ctx)
+        ph1, col1 = ctx.phase_times(), ctx.path_info()["collectives"]
+        ctx.profile(2)
+        ctx.phase_reset()
+        Z2, S2 = gsi.randsvd(A, 10, 6, 2, Omega=Om, return_S=True, ctx=ctx)
+        ph2, col2 = ctx.phase_times(), ctx.path_info()["collectives"]
+        ctx.profile(0)
+        results["skew_profile_same_numbers"] = 0.0 if (np.array_equal(Z1, Z2) and np.array_equal(S1, S2)) else 1.0
+        results["skew_profile_counts"] = 0.0 if (ph1["comm_wait"][1] == 0 and ph2["comm_wait"][1] > 0
+                                                 and col2 - col1 == ph2["comm_wait"][1] and ph2["lu"][1] == ph1["lu"][1]) else 1.0
         # non-symmetric operator (Jacobian-like), shards shorter than... still >= l
         B = rng.standard_normal((90, 60)) @ np.diag(np.logspace(0, -4, 60)) @ rng.standard_normal((60, 60))
         Om = rng.standard_normal((60, 12))

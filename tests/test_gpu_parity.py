@@ -670,6 +670,16 @@ def test_fft_powerlaw_operator(gsi, ctx, Ns, beta, l):
 
 
 @pytest.mark.gpu
+def test_fft_grid_limit_is_refused_at_creation(gsi, ctx):
+    """An embedding of 2^31 points (32-bit offsets inside a column pair's array): GSI_ERR_ARG when the operator is created,
+    before spectrum and work array are allocated -- not at the first product."""
+    before = ctx.device_bytes()
+    with pytest.raises(gsi.GsiError, match="fewer than 2\^31"):
+        gsi.fft_powerlaw_operator(ctx, [1024, 512, 512], -3.5)
+    assert ctx.device_bytes() == before
+
+
+@pytest.mark.gpu
 def test_fft_powerlaw_randsvd(gsi, ctx):
     """randsvd through the matrix-free FFT operator = randsvd of the same covariance stored densely (oracle)."""
     Ns, beta, K, p, q = (20, 16), -3.5, 12, 6, 2
@@ -1112,12 +1122,13 @@ print("headline-ok")
 
 
 # ---- the metric's rel-err at the metric's size (BASELINE.json "top-k singular-value rel-err, n=1e6 rank=256"): the oracle
-#      on the operator the HIP path ran on (samples, Omega downloaded), products in GEMM form.  Opt-in: ~2-5 min of host
-#      LAPACK and ~40 GB of host memory (GSI_TEST_HEADLINE_PARITY=1); bench.py runs the same comparison in every default
-#      run and records it in the driver's line. ----------------------------------------------------------------------
+#      on the operator the HIP path ran on (samples, Omega downloaded), products in GEMM form.  Runs by default (VERDICT r4
+#      item 3: the metric's own parity belongs in the driver-run suite; ~130 s of host LAPACK and ~40 GB of host memory on the
+#      GPU box, the suite stays under its 900 s limit); GSI_SKIP_HEADLINE_PARITY=1 opts out, as for the C2 test.  bench.py runs
+#      the same comparison in every default run and records it in the driver's line. -----------------------------------
 @pytest.mark.gpu
-@pytest.mark.skipif(not __import__("os").environ.get("GSI_TEST_HEADLINE_PARITY"),
-                    reason="opt-in (GSI_TEST_HEADLINE_PARITY=1): minutes of host LAPACK at n = 1e6")
+@pytest.mark.skipif(bool(__import__("os").environ.get("GSI_SKIP_HEADLINE_PARITY")),
+                    reason="opted out (GSI_SKIP_HEADLINE_PARITY=1): ~2 minutes of host LAPACK at n = 1e6")
 def test_headline_parity_vs_oracle(gsi):
     ctx = gsi.default_context()
     n, Ns, K, p, q = 1000000, 1024, 256, 64, 2
@@ -1309,7 +1320,7 @@ print("two-contexts-ok")
 
 # ---- scattered-point covariance as an implicit, row-streamed operator (SURVEY 8b "coords + kernel id + params"): products
 #      and randsvd against the dense kernel matrix built by numpy from the same coordinates; every kernel kind, 1-3
-#      dimensions, a nugget; several row panels (GSI_POINTCOV_PANEL_MB, separate process: read once) -----------------------
+#      dimensions, a nugget -----------------------------------------------------------------------------------------------
 def _dense_pointcov(P, kind, ell, sigma2, nugget):
     d2 = ((P[:, :, None] - P[:, None, :]) ** 2).sum(axis=0)
     r = np.sqrt(d2) / ell
@@ -1368,38 +1379,64 @@ def test_pointcov_entry_extremes(gsi, ctx, kind, l):
 
 
 @pytest.mark.gpu
-def test_pointcov_implicit_randsvd_and_panels(gsi):
-    import os
-    import subprocess
-    import sys
-    code = r"""
-import os, sys, numpy as np
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-import gsi_amd as gsi
-from oracle import oracle as orc
-from helpers import rel_sv_err
-from test_gpu_parity import _dense_pointcov
-ctx = gsi.Context(0)
-rng = np.random.default_rng(5)
-n, K, p, q = 3000, 40, 10, 2
-P = rng.uniform(0.0, 50.0, size=(2, n))
-A = _dense_pointcov(P, "exponential", 12.0, 1.0, 0.0)
-op = gsi.pointcov_implicit_operator(ctx, P, "exponential", ell=12.0)
-X = rng.standard_normal((n, 24))
-assert np.abs(op.matmul(X) - A @ X).max() < 1e-11 * np.abs(A @ X).max()       # 1 MB panels: 3000 rows in 23 panels of 128
-Om = rng.standard_normal((n, K + p))
-Z, S = gsi.randsvd(op, K, p, q, Omega=Om, return_S=True)
-Zr, Sr, _ = orc.randsvd_full(A, K, p, q, Om)
-assert rel_sv_err(S, Sr, K) < 1e-9
-assert orc.xis_error_up_to_sign(Z, Zr, K) < 1e-6
-print("pointcov-ok")
-"""
-    env = dict(os.environ)
-    env["GSI_POINTCOV_PANEL_MB"] = "1"
-    env["GSI_POINTCOV_PANELS"] = "1"     # round 3's row panels (the default since round 4 generates in the tile loader): kept under test
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and "pointcov-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+def test_pointcov_implicit_randsvd(gsi, ctx):
+    rng = np.random.default_rng(5)
+    n, K, p, q = 3000, 40, 10, 2
+    P = rng.uniform(0.0, 50.0, size=(2, n))
+    A = _dense_pointcov(P, "exponential", 12.0, 1.0, 0.0)
+    op = gsi.pointcov_implicit_operator(ctx, P, "exponential", ell=12.0)
+    X = rng.standard_normal((n, 24))
+    assert np.abs(op.matmul(X) - A @ X).max() < 1e-11 * np.abs(A @ X).max()
+    Om = rng.standard_normal((n, K + p))
+    Z, S = gsi.randsvd(op, K, p, q, Omega=Om, return_S=True)
+    op.close()
+    Zr, Sr, _ = orc.randsvd_full(A, K, p, q, Om)
+    assert rel_sv_err(S, Sr, K) < 1e-9
+    assert orc.xis_error_up_to_sign(Z, Zr, K) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,l", [("exponential", 48), ("gaussian", 320), ("matern52", 200)])
+def test_pointcov_translation_invariance(gsi, ctx, kind, l):
+    """Entries depend on coordinate differences only: UTM-like coordinates -- a common offset of 5e5 / 4.6e6 on points
+    that are tens of correlation lengths apart, and an ell whose reciprocal is not a power of two -- must cost no accuracy:
+    the same 1e-12 against the dense matrix as the points centred at the origin, and the two operators agree to rounding."""
+    rng = np.random.default_rng(17)
+    n, ell = 1800, 20.0
+    P0 = rng.uniform(0.0, 600.0, size=(2, n))
+    P1 = P0 + np.array([[5.0e5], [4.6e6]])
+    X = rng.standard_normal((n, l))
+    A = _dense_pointcov(P0, kind, ell, 1.0, 0.0)
+    ref = A @ X
+    Y = []
+    for P in (P0, P1):
+        op = gsi.pointcov_implicit_operator(ctx, P, kind, ell=ell)
+        Y.append(op.matmul(X))
+        op.close()
+    # (P1 - offset is P0 only to rounding of the offset addition itself: ~1e-10 absolute on a coordinate = 5e-12 of ell)
+    A1 = _dense_pointcov(P1, kind, ell, 1.0, 0.0)
+    assert np.abs(Y[0] - ref).max() < 1e-12 * np.abs(ref).max()
+    assert np.abs(Y[1] - A1 @ X).max() < 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_pointcov_rejects_unbounded_coordinates(gsi, ctx):
+    """The generator has no clamp in front of its exponential; the accepted range is checked on the host (gsi_hip.h)."""
+    P = np.random.default_rng(1).uniform(0, 1, size=(2, 50))
+    for bad in (np.inf, np.nan, 1e300):
+        Pb = P.copy()
+        Pb[1, 17] = bad
+        with pytest.raises(gsi.GsiError, match="finite and within"):
+            gsi.pointcov_implicit_operator(ctx, Pb, "exponential", ell=1.0)
+    # far, but inside the range: the entries underflow to exactly zero, nothing is poisoned
+    Pf = P.copy()
+    Pf[:, 3] = 1e20
+    op = gsi.pointcov_implicit_operator(ctx, Pf, "gaussian", ell=1.0)
+    X = np.random.default_rng(2).standard_normal((50, 8))
+    Y = op.matmul(X)
+    op.close()
+    A = _dense_pointcov(Pf, "gaussian", 1.0, 1.0, 0.0)
+    assert np.isfinite(Y).all() and np.abs(Y - A @ X).max() < 1e-11 * np.abs(A @ X).max()
 
 
 # ---- the WHOLE multi-rank pipeline on the HIP backend, on one GPU.  RCCL refuses two ranks on one device, so the ranks are

@@ -20,7 +20,7 @@ cd $R
  GSI_GEMM_FORCE_SPLIT=1 timeout -k 10 200 python tools/pointcov_bench.py | grep exponential; GSI_GEMM_FORCE_SPLIT=2 timeout -k 10 200 python tools/pointcov_bench.py | grep exponential
  echo "# GSI_POINTCOV_WIDE=0 (128 x 160 tiles, every entry generated twice at l = 320)"; GSI_POINTCOV_WIDE=0 timeout -k 10 200 python tools/pointcov_bench.py
  echo "# l = 160 (one column chunk: the 128 x 160 kernel)"; timeout -k 10 200 python tools/pointcov_bench.py 450 160
- echo "# GSI_POINTCOV_PANELS=1 (round 3: row panels in HBM)"; GSI_POINTCOV_PANELS=1 timeout -k 10 200 python tools/pointcov_bench.py) > gpurun_out/r04_pointcov_bench.log 2>&1
+) > gpurun_out/r04_pointcov_bench.log 2>&1
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_pc -- python3 $R/tools/pointcov_bench.py > $R/gpurun_out/prof_pc.log 2>&1
 find $R/gpurun_out/prof_pc -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/r04_pointcov_kernel_stats.csv \;
