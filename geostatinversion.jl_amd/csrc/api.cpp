@@ -490,6 +490,7 @@ int gsi_randsvd(gsi_ctx* ctx, const gsi_op* op, const double* Omega, int64_t K, 
 }
 
 // ---- the dense operator still in HOST memory: what getxis(Q::Matrix, ...) is called with ----------------------------
+}  // extern "C" (the helpers below are C++)
 namespace {
 // A dense operator whose rows are on their way: allocated, the upload started in row blocks (single rank, large matrices;
 // otherwise uploaded synchronously), `pending_upload` set for the first product.  The guard ends the transfer on every path.
@@ -517,6 +518,7 @@ std::unique_ptr<gsi_op> dense_op_streaming(gsi_ctx* ctx, const double* A_host, i
   return o;
 }
 }  // namespace
+extern "C" {
 
 int gsi_randsvd_dense_host(gsi_ctx* ctx, const double* A_host, int64_t m, int64_t n, int64_t lda, const double* Omega,
                            int64_t K, int64_t p, int64_t q, double* Z_out, double* S_out, gsi_op** op_out) {

@@ -202,12 +202,13 @@ class HipBackend : public Backend {
     return in_use_ + pooled_ + ws + (int64_t)garbage_bytes_;
   }
   // ---- the host boundary (host_staging.hpp): caller memory is pageable; transfers of GSI_STAGE_MIN_MB (default 16) MiB and
-  // more go through the pinned staging ring (GSI_STAGE_THREADS workers, default 4, GSI_STAGE_CHUNK_MB MiB chunks, default
-  // 16: 0.98 of this box's pinned-copy rate in both directions, profiles/r05_h2d_rates.log); smaller ones straight from the
+  // more go through the pinned staging ring (GSI_STAGE_THREADS workers, default 6 -- four reach the link rate on contiguous
+  // sources, the strided row-block reads want the margin --, GSI_STAGE_CHUNK_MB MiB chunks, default 16: 0.98 of this box's
+  // pinned-copy rate in both directions, profiles/r05_h2d_rates.log); smaller ones straight from the
   // caller's pages (54 us for C1's 768 KB Omega).  If the ring cannot be allocated the direct path serves everything.
   HostStager* stager() {
     if (stager_ || stager_failed_) return stager_.get();
-    static const int threads = getenv("GSI_STAGE_THREADS") ? std::max(1, std::min(32, atoi(getenv("GSI_STAGE_THREADS")))) : 4;
+    static const int threads = getenv("GSI_STAGE_THREADS") ? std::max(1, std::min(32, atoi(getenv("GSI_STAGE_THREADS")))) : 6;
     static const size_t chunk = (size_t)(getenv("GSI_STAGE_CHUNK_MB") ? std::max(1, std::min(1024, atoi(getenv("GSI_STAGE_CHUNK_MB")))) : 16) << 20;
     try {
       stager_.reset(new HostStager(device_, threads, chunk));
@@ -257,14 +258,18 @@ class HipBackend : public Backend {
                                cols, hipMemcpyDeviceToHost, st_));
     HIP_CHECK(hipStreamSynchronize(st_));
   }
-  // Row-block upload in the background (Backend::upload2d_begin): matrices of 256 MiB and more, in blocks of 4096 rows
-  // (32 KB per column segment on the host side; a block of a 65536-column matrix is 2 GiB = 37 ms of PCIe against ~10 ms
-  // of contraction: the product of block b runs while block b + 1 crosses).  GSI_STAGE_BLOCK_ROWS overrides (tests).
+  // Row-block upload in the background (Backend::upload2d_begin): matrices of 256 MiB and more, in blocks of up to 32768 rows
+  // = 256 output tiles, one full round of the contraction (what stays exposed after the upload is the LAST block's product,
+  // ~10 ms at C2 whatever the block height, so tall blocks lose nothing) and 256 KB per column segment on the host side:
+  // the workers' strided reads of the caller's matrix ran at 0.24 s per 8.6 GB against 0.35 s with 32 KB segments, and
+  // with short segments the upload was sometimes bound by them (profiles/r05_boundary_probe.log).  At least two blocks.
+  // GSI_STAGE_BLOCK_ROWS overrides (tests: many small blocks).
   int64_t upload_block_rows(int64_t rows, int64_t cols) override {
     const int64_t forced = getenv("GSI_STAGE_BLOCK_ROWS") ? atoll(getenv("GSI_STAGE_BLOCK_ROWS")) : 0;
     if (forced >= 128) return std::min(rows, (forced / 128) * 128);
     if (sizeof(double) * (size_t)rows * (size_t)cols < ((size_t)256 << 20) || rows < 2 * 4096) return rows;
-    return 4096;
+    const int64_t half = (((rows + 1) / 2 + 127) / 128) * 128;
+    return std::max<int64_t>(4096, std::min<int64_t>(32768, half));
   }
   void* upload2d_begin(double* dst, int64_t ldd, const double* host, int64_t ldh, int64_t rows, int64_t cols,
                        int64_t block_rows) override {
@@ -952,6 +957,7 @@ class HipBackend : public Backend {
     w.norms = (double*)ws_svd_.p;
     w.pairs = (int32_t*)((char*)ws_svd_.p + sizeof(double) * (l + 8) + 64);
     w.rotcount = flags_ + 8;
+    w.persistent_ok = ranks_sharing_device_ <= 1;
     const int sw = hipk::svd_small(st_, G, l, U, S, w);
     last_svd_sweeps_ = sw < 0 ? -sw : sw;
     if (sw < 0) ++n_svd_cap_hits_;          // 40 sweeps and rotatable pairs left (factors graded over > 1e10): gsi_ctx_path_info reports it
