@@ -818,7 +818,10 @@ int gsi_qr_thinQ(gsi_ctx* ctx, const double* Y, int64_t m, int64_t l, double* Q_
     Backend* be = ctx->c.be.get();
     Buf P(be, (size_t)m * l), R(be, (size_t)l * l);
     be->upload2d(P.p, m, Y, m, m, l);
-    be->qr_thinQ(P.p, m, l, m, R.p);
+    {
+      ScopedPhase ph(be, PH_QR);
+      be->qr_thinQ(P.p, m, l, m, R.p);
+    }
     be->download2d(Q_out, m, P.p, m, m, l);
     if (R_out) be->download2d(R_out, l, R.p, l, l, l);
     check_async_errors(ctx->c);

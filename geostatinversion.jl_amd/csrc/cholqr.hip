@@ -15,7 +15,10 @@
 // the second round checks |Q1'Q1 - I|_max; on any doubt the caller runs the Householder path (panel_qr.hip)
 // on the untouched panel.  Decision = one 4-byte read per factorization, taken before the last product.
 #include "hip_common.hpp"
+#include <atomic>
 #include <cfloat>
+#include <cstdio>
+#include <cstdlib>
 
 namespace gsi { namespace hipk {
 
@@ -173,6 +176,320 @@ __global__ void cq_triprod_kernel(const double* __restrict__ R2, const double* _
   }
 }
 
+// ---- R = chol(G) and X = R^-1 of the l x l Gram matrix in ONE launch (round 5) ---------------------------
+// The blocked form above is 2 + 4 l / 32 dependent launches per Cholesky round on l x l data (41 at l = 320: one-wave
+// factorizations of the diagonal blocks, trailing updates and the products of the blocked inverse through the big
+// contraction kernel, which is all latency at this size): 0.6 ms per round, two rounds per thin QR.  A dependent launch costs
+// ~4.5 us on this chip whatever it does, and the small products ran at 12 - 25 us each.  Here one workgroup of 8 waves does
+// the whole job out of L2 and LDS:
+//   per 32-column block   wave 0: chol of the diagonal block in registers (lane = column, pivot row through v_readlane: the
+//                         code of cq_chol_block_kernel);  all: the block row U12 = U11^-T G12 by forward substitution, one
+//                         thread per trailing column (no explicit inverse on the critical path), kept in LDS;  all: the
+//                         trailing update G22 -= U12' U12 of the UPPER triangle as 16 x 16 MFMA tiles fed from LDS, the
+//                         accumulator's lane index along the rows of G (contiguous loads and stores);
+//   then                  the diagonal blocks' inverses, one wave per block, all at once;  block column j of X = R^-1 as
+//                         -X[0:j0, 0:j0] (R[0:j0, j] X_jj): the small factor row-wise in LDS, the product as MFMA tiles with
+//                         the X operand read where it lies (lane index along its rows).
+// Measured at l = 320 (GSI_CQ_TRACE=1, 100 MHz stamps by thread 0): 0.43 ms per round -- set-up 12 us, the ten diagonal blocks
+// 98, block rows 118, trailing updates 93, diagonal inverses 18, W 27, the inverse's tiles 68 -- against ~0.55 for the blocked
+// form: the thin QR of a 10^6 x 320 panel 10.9 -> 10.7 ms, of a 125 000-row shard 2.87 -> 2.58, 65536 x 160 0.82 -> 0.65
+// (profiles/r05_qr_fused_ab.log).  What is left is a chain: every step waits for one wave's 32 pivots, then for one thread
+// per column's 32-row substitution; overlapping the next diagonal block with the rest of the trailing update (look-ahead) is
+// the next step, not taken here.  Results differ from the blocked form in rounding only (summation order of the updates;
+// reciprocal pivots).
+constexpr int CQF_THREADS = 512;     // 8 waves, 2 per SIMD: 256 VGPRs each (the in-register 32 x 32 factorizations hold 64 - 128 of them)
+constexpr int CQF_MAXL = 384;                    // beyond: the blocked multi-launch form (its products use the whole chip)
+constexpr int CQF_LDU = CQF_MAXL - CQ_TB + 16;   // row stride of the block row image Us[p][c]: = 16 mod 32 (bank spread of the MFMA operand reads)
+constexpr int CQF_LDK = CQF_MAXL - CQ_TB + 4;    // row stride of Wt[c][k]: = 4 mod 32
+constexpr int CQF_DS = CQ_TB + 4;               // row stride of the 32 x 32 LDS blocks: rows 16-byte aligned (broadcast reads of 8 entries)
+static_assert(CQF_LDU % 32 == 16 && CQF_LDK % 32 == 4, "LDS strides");
+typedef double cq_double4 __attribute__((ext_vector_type(4)));
+constexpr size_t CQF_LDS_BYTES = sizeof(double) * ((size_t)CQ_TB * CQF_LDU + (size_t)CQ_TB * CQF_DS + 2 * CQ_TB + 64);
+
+// wave 0: U11 = chol(G11) in registers; Ds <- U11 (zeros below the diagonal), Dinv <- reciprocal pivots, G11 <- U11
+__device__ __forceinline__ void cqf_chol_diag(double* __restrict__ G, int l, int j0, int b, double tiny, double* __restrict__ Ds,
+                                                        double* __restrict__ Dinv, int32_t* __restrict__ flag, int lane) {
+  const int c = lane & (CQ_TB - 1);                     // lanes 32..63 mirror lanes 0..31 (no stores)
+  double col[CQ_TB];
+#pragma unroll
+  for (int r = 0; r < CQ_TB; ++r)
+    col[r] = (r < b && c < b && r <= c) ? G[(j0 + r) + (int64_t)(j0 + c) * l] : (r == c ? 1.0 : 0.0);
+  bool bad = false;
+  double rdiag = 1.0;
+#pragma unroll
+  for (int k = 0; k < CQ_TB; ++k) {
+    double d = cq_bcast(col[k], k);
+    if (k < b && !(d > tiny)) { bad = true; d = 1.0; }
+    // 1 / sqrt(d) to fp64 (v_rsq_f64 + two Newton steps) and multiplications: the sqrt + two divisions of the blocked form are
+    // ~100 dependent instructions per pivot on the one wave everything else waits for
+    double rs = __builtin_amdgcn_rsq(d);
+    rs = rs * (1.5 - 0.5 * d * rs * rs);
+    rs = rs * (1.5 - 0.5 * d * rs * rs);
+    const double ukk = d * rs;
+    col[k] = (c == k) ? ukk : col[k] * rs;             // row k of U (lanes c < k hold nothing that is read)
+    if (c == k) rdiag = rs;
+#pragma unroll
+    for (int r = k + 1; r < CQ_TB; ++r) col[r] -= cq_bcast(col[k], r) * col[k];
+    __builtin_amdgcn_sched_barrier(0);                 // or the scheduler hoists hundreds of broadcasts (SGPR pairs) at once and spills
+  }
+  if (bad && lane == 0) atomicOr(flag, 1);
+  if (lane < CQ_TB) {
+    Dinv[c] = rdiag;
+#pragma unroll
+    for (int r = 0; r < CQ_TB; ++r) {
+      const double v = (r <= c) ? col[r] : 0.0;
+      Ds[r * CQF_DS + c] = v;
+      if (r < b && c < b) G[(j0 + r) + (int64_t)(j0 + c) * l] = v;
+    }
+  }
+}
+// one wave: X_jj = U_jj^-1 by back substitution along the lanes (lane = column)
+__device__ __forceinline__ void cqf_inv_diag(const double* __restrict__ G, int l, int j0, int b, double* __restrict__ X, int lane) {
+  const int c = lane & (CQ_TB - 1);
+  double col[CQ_TB], x[CQ_TB];
+#pragma unroll
+  for (int r = 0; r < CQ_TB; ++r)
+    col[r] = (r < b && c < b && r <= c) ? G[(j0 + r) + (int64_t)(j0 + c) * l] : (r == c ? 1.0 : 0.0);
+#pragma unroll
+  for (int r = CQ_TB - 1; r >= 0; --r) {
+    double sacc = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int p = r + 1; p < CQ_TB; ++p) sacc -= cq_bcast(col[r], p) * x[p];
+    x[r] = (r <= c) ? sacc / cq_bcast(col[r], r) : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (lane < CQ_TB && c < b) {
+#pragma unroll
+    for (int r = 0; r < CQ_TB; ++r)
+      if (r < b) X[(j0 + r) + (int64_t)(j0 + c) * l] = x[r];
+  }
+}
+// one thread = one trailing column c: u = U11^-T g by forward substitution; Us[:, c] <- u, G12[:, c] <- u.
+// Eight rows at a time: the finished rows are re-read from the thread's own column of Us (LDS), so the registers hold eight
+// accumulators, not the whole column and the 496 entries of U11 the fully unrolled form loads (which the compiler kept live
+// all at once: 4 KB of scratch per lane).
+__device__ __forceinline__ void cqf_block_row_col(double* __restrict__ gcol /* G + j0 + (j0 + b + c) l */, int b,
+                                                  const double* __restrict__ Ds, const double* __restrict__ Dinv,
+                                                  double* __restrict__ us /* Us + c */) {
+  double g[CQ_TB];                                       // the whole column first: ONE L2 round trip, not one per chunk
+#pragma unroll
+  for (int p = 0; p < CQ_TB; ++p) g[p] = (p < b) ? gcol[p] : 0.0;
+#pragma unroll
+  for (int pb = 0; pb < CQ_TB; pb += 8) {
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = g[pb + j];
+#pragma unroll 4
+    for (int q = 0; q < pb; ++q) {
+      const double uq = us[q * CQF_LDU];
+      const double* dr = Ds + q * CQF_DS + pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] -= dr[j] * uq;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int i = 0; i < j; ++i) acc[j] -= Ds[(pb + i) * CQF_DS + pb + j] * acc[i];
+      acc[j] *= Dinv[pb + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double v = (pb + j < b) ? acc[j] : 0.0;
+      us[(pb + j) * CQF_LDU] = v;
+      if (pb + j < b) gcol[pb + j] = v;
+    }
+    asm volatile("" ::: "memory");                       // chunk by chunk: the next chunk's LDS reads are not hoisted over this one's
+  }
+}
+// trace (null in production): 100 MHz ticks per phase, accumulated by thread 0 -- [0] set-up, [1] diagonal blocks, [2] block
+// rows, [3] trailing updates, [4] diagonal inverses, [5] W = R X_jj, [6] the inverse's tiles (tools/qr_small_time.py --trace)
+#define CQF_STAMP(ph) do { if (trace != nullptr && tid == 0) { const unsigned long long now_ = wall_clock64(); trace[ph] += now_ - t_last; t_last = now_; } } while (0)
+__global__ __launch_bounds__(CQF_THREADS) void cq_chol_inv_kernel(double* __restrict__ G, int l, double* __restrict__ X,
+                                                                  int32_t* __restrict__ flag, unsigned long long* __restrict__ trace) {
+  unsigned long long t_last = (trace != nullptr) ? wall_clock64() : 0ull;
+  extern __shared__ double cqf_lds[];
+  double* Us = cqf_lds;                                   // [32][CQF_LDU] block row / (inverse) Wt[32][CQF_LDK]
+  double* Ds = Us + CQ_TB * CQF_LDU;                      // [32][33] the diagonal block's factor
+  double* Dinv = Ds + CQ_TB * CQF_DS;                // [32] reciprocal pivots
+  double* red = Dinv + CQ_TB;                             // [32 + ...] reduction scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = (l + CQ_TB - 1) / CQ_TB;
+  // tiny = 16 l eps max_i G_ii : pivots below it mean "numerically rank deficient" (flag |= 1)
+  {
+    double mx = 0.0;
+    for (int i = tid; i < l; i += CQF_THREADS) mx = fmax(mx, G[i + (int64_t)i * l]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      double m2 = 0.0;
+      for (int w2 = 0; w2 < CQF_THREADS / 64; ++w2) m2 = fmax(m2, red[w2]);
+      red[32] = m2 * (double)l * DBL_EPSILON * 16.0;
+    }
+    // X <- 0 below the diagonal blocks and everywhere it is not written later (the consumers read whole column chunks)
+    for (int64_t e = tid; e < (int64_t)l * l; e += CQF_THREADS) X[e] = 0.0;
+    __syncthreads();
+  }
+  const double tiny = red[32];
+  CQF_STAMP(0);
+
+  // ================= R = chol(G), right-looking, 32-column blocks =================
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int j0 = jb * CQ_TB;
+    const int b = (l - j0 < CQ_TB) ? (l - j0) : CQ_TB;
+    const int nc = l - j0 - b;                              // trailing columns
+    if (wave == 0) cqf_chol_diag(G, l, j0, b, tiny, Ds, Dinv, flag, lane);     // ---- A: the diagonal block ----
+    __syncthreads();
+    CQF_STAMP(1);
+    if (nc > 0) {
+      // ---- B: block row U12 = U11^-T G12, thread = trailing column; and zeros below U11 ----
+      const int ncp = (nc + 15) & ~15;                      // the MFMA tiles read whole 16-column groups: zero padding
+      for (int c = tid; c < ncp; c += CQF_THREADS) {
+        if (c < nc) cqf_block_row_col(G + j0 + (int64_t)(j0 + b + c) * l, b, Ds, Dinv, Us + c);
+        else {
+#pragma unroll
+          for (int p = 0; p < CQ_TB; ++p) Us[p * CQF_LDU + c] = 0.0;
+        }
+      }
+      for (int e = tid; e < b * nc; e += CQF_THREADS) {     // strictly-lower part of this block column -> 0 (rows along the lanes)
+        const int r = j0 + b + e % nc, c = j0 + e / nc;
+        G[r + (int64_t)c * l] = 0.0;
+      }
+      __syncthreads();
+      CQF_STAMP(2);
+      // ---- C: trailing update of the upper triangle, 16 x 16 tiles: G22[r, c] -= sum_p U12[p, r] U12[p, c] ----
+      // Four tiles per pass: their 16 loads of G are in flight together (one L2 round trip per pass, not per tile).
+      const int nt = ncp >> 4;
+      const int ntiles = nt * (nt + 1) / 2;
+      const int jl = lane & 15, kq = lane >> 4;
+      double* Gt = G + (int64_t)(j0 + b) + (int64_t)(j0 + b) * l;     // trailing matrix (0, 0)
+      constexpr int NWV = CQF_THREADS / 64, TPP = 4;
+      // (requesting the next pass's tiles before this pass's MFMAs -- a two-deep software pipeline -- measured SLOWER, 106 against
+      // 93 us per round at l = 320: sixteen more live registers put the kernel into scratch)
+      for (int t0 = wave; t0 < ntiles; t0 += NWV * TPP) {
+        cq_double4 acc[TPP];
+        int trs[TPP], tcs[TPP];
+#pragma unroll
+        for (int u = 0; u < TPP; ++u) {
+          const int t = t0 + u * NWV;
+          int tr = 0, rem = (t < ntiles) ? t : 0;            // t -> (tr <= tc), row-major over the upper triangle
+          while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
+          trs[u] = tr; tcs[u] = tr + rem;
+          const int r = tr * 16 + jl;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int c = tcs[u] * 16 + kq + 4 * v;
+            acc[u][v] = (t < ntiles && r < nc && c < nc) ? Gt[r + (int64_t)c * l] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < TPP; ++u) {
+#pragma unroll
+          for (int k0 = 0; k0 < CQ_TB; k0 += 4) {
+            const double fa = -Us[(k0 + kq) * CQF_LDU + tcs[u] * 16 + jl];      // a-operand: i <-> column of G
+            const double fb = Us[(k0 + kq) * CQF_LDU + trs[u] * 16 + jl];       // b-operand: j (= lane & 15) <-> row of G
+            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[u], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < TPP; ++u) {
+          const int t = t0 + u * NWV;
+          const int r = trs[u] * 16 + jl;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int c = tcs[u] * 16 + kq + 4 * v;
+            if (t < ntiles && r < nc && c < nc) Gt[r + (int64_t)c * l] = acc[u][v];
+          }
+        }
+      }
+      __syncthreads();
+      CQF_STAMP(3);
+    }
+  }
+
+  // ================= X = R^-1 =================
+  // diagonal blocks: X_jj = U_jj^-1, one wave per block, all at once
+  for (int jb = wave; jb < nblk; jb += CQF_THREADS / 64) {
+    const int j0 = jb * CQ_TB;
+    cqf_inv_diag(G, l, j0, (l - j0 < CQ_TB) ? (l - j0) : CQ_TB, X, lane);
+  }
+  __syncthreads();
+  CQF_STAMP(4);
+  // block columns j = 1 .. nblk - 1:  X[0:j0, j] = -X[0:j0, 0:j0] * (R[0:j0, j] * X_jj)
+  double* Wt = Us;                                           // Wt[c][k], row stride CQF_LDK
+  double* Xjj = Ds;                                          // [32][33]
+  for (int jb = 1; jb < nblk; ++jb) {
+    const int j0 = jb * CQ_TB;
+    const int b = (l - j0 < CQ_TB) ? (l - j0) : CQ_TB;
+    for (int e = tid; e < CQ_TB * CQ_TB; e += CQF_THREADS) {
+      const int r = e & (CQ_TB - 1), c = e >> 5;
+      Xjj[r * CQF_DS + c] = (r < b && c < b) ? X[(j0 + r) + (int64_t)(j0 + c) * l] : 0.0;
+    }
+    __syncthreads();
+    // W = R[0:j0, jcols] X_jj as MFMA tiles, R read where it lies (lane index along its rows), straight into Wt[c][k]:
+    // D[i][j] = sum_p X_jj[p][c0 + i] R[k0 + j][j0 + p]
+    {
+      const int jl = lane & 15, kq = lane >> 4;
+      const int nkt = j0 >> 4;
+      for (int t = wave; t < 2 * nkt; t += CQF_THREADS / 64) {
+        const int kt = t >> 1, ct = t & 1;
+        const double* rp = G + (kt * 16 + jl) + (int64_t)(j0 + kq) * l;
+        double fb[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) fb[s8] = (4 * s8 + kq < b) ? rp[(int64_t)(4 * s8) * l] : 0.0;
+        cq_double4 acc = (cq_double4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const double fa = Xjj[(4 * s8 + kq) * CQF_DS + ct * 16 + jl];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb[s8], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Wt[(ct * 16 + kq + 4 * v) * CQF_LDK + kt * 16 + jl] = acc[v];
+      }
+    }
+    __syncthreads();
+    CQF_STAMP(5);
+    // tiles: 16 rows (r0 < j0) x the 32 columns of the block column (two accumulators sharing the X operand); reduction
+    // k = r0 .. j0 (X is upper triangular) in chunks of 16, the X operand of the next chunk requested before this chunk's MFMAs
+    const int nrt = j0 >> 4;                                  // j0 is a multiple of 32
+    const int jl = lane & 15, kq = lane >> 4;
+    for (int rt = wave; rt < nrt; rt += CQF_THREADS / 64) {   // (the long reductions, small r0, are dealt first)
+      const int r0 = rt * 16;
+      cq_double4 acc0 = (cq_double4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+      const double* xp = X + (r0 + jl) + (int64_t)kq * l;     // b-operand: j <-> row of X (contiguous along the lanes)
+      double fbn[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) fbn[s4] = xp[(int64_t)(r0 + 4 * s4) * l];
+      for (int kb = r0; kb < j0; kb += 16) {
+        double fb[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) fb[s4] = fbn[s4];
+        if (kb + 16 < j0) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) fbn[s4] = xp[(int64_t)(kb + 16 + 4 * s4) * l];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int k0 = kb + 4 * s4;
+          const double fa0 = -Wt[jl * CQF_LDK + k0 + kq];              // a-operand: i <-> column within the block column
+          const double fa1 = -Wt[(16 + jl) * CQF_LDK + k0 + kq];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb[s4], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb[s4], acc1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c = kq + 4 * v;
+        if (c < b) X[(r0 + jl) + (int64_t)(j0 + c) * l] = acc0[v];
+        if (16 + c < b) X[(r0 + jl) + (int64_t)(j0 + 16 + c) * l] = acc1[v];
+      }
+    }
+    __syncthreads();
+    CQF_STAMP(6);
+  }
+}
+#undef CQF_STAMP
+
 static inline int grid_for(int64_t total, int cap = 2048) {
   int64_t g = (total + 255) / 256;
   if (g > cap) g = cap;
@@ -234,6 +551,28 @@ void cq_round(hipStream_t st, const double* src, int64_t lds, double* dst, int64
   if (check)
     hipLaunchKernelGGL(cq_orth_check_kernel, dim3(grid_for((int64_t)l * l, 64)), dim3(256), 0, st, Rp, l, 0.1, flag);
   if (shift) hipLaunchKernelGGL(cq_shift_kernel, dim3(1), dim3(256), 0, st, Rp, l, (double)m);
+  // R = chol(G) and X = R^-1: one launch up to l = 384 (GSI_CQ_FUSED=0: the blocked form below, A/B)
+  static const bool fused_off = (getenv("GSI_CQ_FUSED") != nullptr && getenv("GSI_CQ_FUSED")[0] == '0');
+  if (!fused_off && l <= CQF_MAXL && l >= 1) {
+    static std::atomic<uint64_t> attr_mask{0};
+    if (first_use_on_this_device(attr_mask))
+      (void)hipFuncSetAttribute((const void*)cq_chol_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CQF_LDS_BYTES);
+    static const bool trace_on = (getenv("GSI_CQ_TRACE") != nullptr);            // measurement only: synchronises and prints
+    unsigned long long* trace = nullptr;
+    if (trace_on && hipMalloc((void**)&trace, 8 * sizeof(unsigned long long)) == hipSuccess) hipMemsetAsync(trace, 0, 8 * sizeof(unsigned long long), st);
+    hipLaunchKernelGGL(cq_chol_inv_kernel, dim3(1), dim3(CQF_THREADS), CQF_LDS_BYTES, st, Rp, l, X, flag, trace);
+    if (trace != nullptr) {
+      unsigned long long h[8];
+      hipMemcpyAsync(h, trace, sizeof(h), hipMemcpyDeviceToHost, st);
+      hipStreamSynchronize(st);
+      hipFree(trace);
+      fprintf(stderr, "[gsi cq trace] l = %d: set-up %.1f us, diagonal blocks %.1f, block rows %.1f, trailing updates %.1f, diagonal inverses %.1f, "
+              "W rows %.1f, inverse tiles %.1f\n", l, h[0] / 100.0, h[1] / 100.0, h[2] / 100.0, h[3] / 100.0, h[4] / 100.0, h[5] / 100.0, h[6] / 100.0);
+    }
+    if (apply && !trmm_upper_tall(st, m, l, src, lds, X, l, dst, ldd))                    // dst = src R^-1 (R^-1 upper)
+      gemm_f64_trmm_upper(st, m, l, l, src, lds, X, l, dst, ldd, gemm_ws);
+    return;
+  }
   // R = chol(G), blocked: per 32-column block one small kernel (diagonal block + its inverse + block
   // row) and one MFMA GEMM for the trailing update; the block inverses are what the solve below needs
   hipLaunchKernelGGL(cq_diagmax_kernel, dim3(1), dim3(256), 0, st, Rp, l, b.Gt);
