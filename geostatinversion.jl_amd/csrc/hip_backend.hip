@@ -421,8 +421,14 @@ class HipBackend : public Backend {
     // the spectrum and the work array (tens of GB) are allocated, not at the first product
     if (Mtot >= ((int64_t)1 << 31))
       throw Error(GSI_ERR_ARG, "fft covariance: the embedding grid must have fewer than 2^31 points (e.g. 1024 x 512 x 512 embeds to 2^31)");
-    // work array: as many column pairs at once as fit ~2 GB, at most 64
-    int64_t nb = ((int64_t)2 << 30) / (16 * Mtot);
+    // work array: as many column pairs at once as fit ~2 GB, at most 64.  (GSI_FFT_W_MB: the experiment of VERDICT r4 item 7 --
+    // few enough pairs per batch that the array between the passes stays in the 256 MB Infinity Cache: DESIGN.md 4.6,
+    // profiles/r05_fft_pair_major.log)
+    // 2-D grids whose pair array is <= 128 MB run 256 MB batches: +4 % at 1000^2 (6.57 -> 6.31 ms per 256 columns), the only
+    // place the experiment moved anything; 128 MB and less lose to the shorter launches.
+    static const int64_t w_env = getenv("GSI_FFT_W_MB") ? std::max<int64_t>(1, atoll(getenv("GSI_FFT_W_MB"))) : 0;
+    const int64_t w_mb = w_env > 0 ? w_env : ((d == 2 && 16 * Mtot <= ((int64_t)128 << 20)) ? 256 : 2048);
+    int64_t nb = (w_mb << 20) / (16 * Mtot);
     p->nb_max = (int)std::max<int64_t>(1, std::min<int64_t>(nb, 64));
     p->lam = alloc(hipk::fft_plan_doubles(p->M));
     try { p->W = alloc((size_t)2 * Mtot * p->nb_max); } catch (...) { release(p->lam); throw; }

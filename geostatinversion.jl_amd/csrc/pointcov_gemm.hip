@@ -44,15 +44,22 @@ struct PointGen {
 // MT = 3 (96 rows per workgroup, wave tile 48 x 80, 120 accumulator registers): per flop 2/3 of the X traffic and 2/3 of the
 // barriers of the 64-row tile (60 MFMAs per wave between barriers instead of 40).  A wave generates 96 x 2 entries per tile, three
 // per lane: (k0, row l), (k1, row 32 + l) and -- lanes 0..31: (k0, row 64 + l), lanes 32..63: (k1, row l - 32).
-template <int NTQ, int MT>
+// RGN = 4 (round 5: sketches of 97 .. 160 columns): the SAME wave tile (48 x 80 at MT = 3, NTQ = 5) with the
+// eight waves arranged as 4 row groups x 2 column halves -- a workgroup owns 192 rows x 160 columns, every entry is still
+// generated once, and per flop the generator work, the X traffic and the barriers are those of the 96 x 320 form.  (The 128 x
+// 160 form of gemm_f64.hip, GEN 2, generates 128 x 32 entries per 80 MFMAs of a wave and stayed at 50 TFLOP/s at l = 160.)  A wave
+// then generates 192 x 2 entries per tile, six per lane: rows l, 64 + l, 128 + l of both of its columns.
+template <int NTQ, int MT, int RGN>
 __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
     int64_t M, int64_t L, int64_t K, const double* __restrict__ P4, const double2* __restrict__ Xp, int64_t ktiles,
     double* __restrict__ C, int64_t ldc, double* __restrict__ slabs, int64_t kchunk, int nchunks_x, PointGen gen) {
-  constexpr int NT = 4 * NTQ;                 // 16-column tiles per workgroup
-  constexpr int BM = 32 * MT;                 // rows of C per workgroup
+  static_assert(RGN == 2 || (RGN == 4 && MT == 3), "arrangements: 2 row groups x 4 column quarters, or 4 x 2 with 48-row wave tiles");
+  constexpr int NT = (8 / RGN) * NTQ;         // 16-column tiles per workgroup
+  constexpr int BM = 16 * MT * RGN;           // rows of C per workgroup
+  constexpr int NIT = (NT * 16 + WCSTEP - 1) / WCSTEP;   // 64-column groups of the X tile (the packed stream is zero beyond NT * 16)
   constexpr int WBMP = BM + 16;               // padded row stride of the G image [k][row]
   constexpr int A_ELEMS = WBK * WBMP;
-  constexpr int B_ELEMS = NT * 16 * WBKP;
+  constexpr int B_ELEMS = NIT * WCSTEP * WBKP;
   constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
   extern __shared__ double smem_raw[];        // [64-entry table] [2][G tile | X tile]
   double* const gtab = smem_raw;
@@ -61,8 +68,8 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = wave & 1;          // row group: C rows 16 MT rg .. of the workgroup tile
-  const int cq = wave >> 1;         // column quarter: 16-column tiles cq * NTQ ..
+  const int rg = wave % RGN;        // row group: C rows 16 MT rg .. of the workgroup tile
+  const int cq = wave / RGN;        // column quarter (half at RGN = 4): 16-column tiles cq * NTQ ..
   const int ch = wave >> 2;         // which of the two waves of a SIMD (w, w + 4): their chores are staggered
   const int jl = lane & 15;
   const int kk = lane >> 4;
@@ -87,16 +94,16 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
   // register sets of the X prefetch: two (tiles t+3, t+2 in flight) at 64 rows; ONE at 96 rows -- 120 accumulator registers
   // leave no room for the second, and the packed stream comes out of L2 within the one tile (60 MFMAs per wave) it then has
   constexpr int NS = (MT == 3) ? 1 : 2;
-  double2 b_reg[NS][NTQ];
+  double2 b_reg[NS][NIT];
   const int b_c = tid >> 3;
   const int b_k = 2 * (tid & 7);
-  const double2* const Xbase = Xp + ((tile_lin % nchunks_x) * ktiles * NTQ) * WTHREADS + tid;
+  const double2* const Xbase = Xp + ((tile_lin % nchunks_x) * ktiles * NIT) * WTHREADS + tid;
 
   // this thread's row point(s) (fixed for the whole kernel)
   const int64_t row_first = gen.roff + r0;
   double px, py, pz;
   double pbx = 0.0, pby = 0.0, pbz = 0.0, pcx = 0.0, pcy = 0.0, pcz = 0.0;       // MT = 3: rows 32 + lane and (64 + lane | lane - 32)
-  const int rowC = (lane < 32) ? 64 + lane : lane - 32;
+  const int rowC = (RGN == 4) ? 128 + lane : ((lane < 32) ? 64 + lane : lane - 32);
   {
     auto rowpt = [&](int r, double& x, double& y, double& z) {
       const int64_t gr = row_first + r;
@@ -104,7 +111,8 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
       x = P4[4 * i0]; y = P4[4 * i0 + 1]; z = P4[4 * i0 + 2];
     };
     rowpt(lane, px, py, pz);
-    if constexpr (MT == 3) { rowpt(32 + lane, pbx, pby, pbz); rowpt(rowC, pcx, pcy, pcz); }
+    if constexpr (RGN == 4) { rowpt(64 + lane, pbx, pby, pbz); rowpt(128 + lane, pcx, pcy, pcz); }
+    else if constexpr (MT == 3) { rowpt(32 + lane, pbx, pby, pbz); rowpt(rowC, pcx, pcy, pcz); }
   }
   const GenPointK gq = gen_point_setup(gen.dim, gen.kind);
   gen_table_init(gtab, tid, gen.sigma2);
@@ -112,11 +120,14 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
 
   auto prefetch = [&](int64_t k0, auto SET) __attribute__((always_inline)) {
     constexpr int set = decltype(SET)::value;
-    const double2* src = Xbase + (k0 / WBK) * (NTQ * WTHREADS);   // (k0 is a multiple of the tile depth)
+    const double2* src = Xbase + (k0 / WBK) * (NIT * WTHREADS);   // (k0 is a multiple of the tile depth)
 #pragma unroll
-    for (int it = 0; it < NTQ; ++it) {                         // (element-wise: the struct copy kept the array in scratch memory)
-      const double2 v = src[it * WTHREADS];
-      b_reg[set][it].x = v.x; b_reg[set][it].y = v.y;
+    for (int it = 0; it < NIT; ++it) {                         // (element-wise: the struct copy kept the array in scratch memory)
+      // the last 64-column group of a 160-column tile is half padding: waves 4..7 (b_c >= 32) have nothing to fetch there
+      if ((it + 1) * WCSTEP <= NT * 16 || wave < (NT * 16 - it * WCSTEP) / 8) {
+        const double2 v = src[it * WTHREADS];
+        b_reg[set][it].x = v.x; b_reg[set][it].y = v.y;
+      }
     }
   };
 
@@ -152,7 +163,33 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
       const int kw = 2 * wave;
       const int fl = gen_flags(gq.flags);
       const int rel0 = (int)(qg0 - row_first), rel1 = (int)(qg1 - row_first);  // (point indices are 31-bit)
-      if constexpr (MT == 2) {
+      if constexpr (RGN == 4) {
+        // six entries per lane: rows lane, 64 + lane, 128 + lane of column k0, then of column k1 (two triples side by side)
+        auto triple = [&](const double2& qxy, double qz, int rel, int kcol) __attribute__((always_inline)) {
+          double dx = px - qxy.x, dy = py - qxy.y;
+          double s0 = fma(dx, dx, dy * dy);
+          dx = pbx - qxy.x; dy = pby - qxy.y;
+          double s1 = fma(dx, dx, dy * dy);
+          dx = pcx - qxy.x; dy = pcy - qxy.y;
+          double s2 = fma(dx, dx, dy * dy);
+          if (fl & 1) {
+            const double dz0 = pz - qz, dz1 = pbz - qz, dz2 = pcz - qz;
+            s0 = fma(dz0, dz0, s0); s1 = fma(dz1, dz1, s1); s2 = fma(dz2, dz2, s2);
+          }
+          double v0, v1, v2;
+          gen_point_triple(gq, fl, s0, s1, s2, gtab, v0, v1, v2);
+          if ((unsigned)rel < (unsigned)BM) {                                    // uniform: the diagonal crosses this column
+            v0 += (lane == rel) ? gen.nugget : 0.0;
+            v1 += (64 + lane == rel) ? gen.nugget : 0.0;
+            v2 += (128 + lane == rel) ? gen.nugget : 0.0;
+          }
+          a_s[kcol * WBMP + lane] = v0;
+          a_s[kcol * WBMP + 64 + lane] = v1;
+          a_s[kcol * WBMP + 128 + lane] = v2;
+        };
+        triple(qxy0, qz0, rel0, kw);
+        triple(qxy1, qz1, rel1, kw + 1);
+      } else if constexpr (MT == 2) {
         double dx = px - qxy0.x, dy = py - qxy0.y;
         double s0 = fma(dx, dx, dy * dy);
         dx = px - qxy1.x; dy = py - qxy1.y;
@@ -196,8 +233,9 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_wide_kernel(
       load_points(k0 + WBK);                                                    // the next tile's (clamped when there is none)
     }
 #pragma unroll
-    for (int it = 0; it < NTQ; ++it)
-      *reinterpret_cast<double2*>(b_s + (b_c + WCSTEP * it) * WBKP + b_k) = b_reg[set][it];
+    for (int it = 0; it < NIT; ++it)
+      if ((it + 1) * WCSTEP <= NT * 16 || wave < (NT * 16 - it * WCSTEP) / 8)
+        *reinterpret_cast<double2*>(b_s + (b_c + WCSTEP * it) * WBKP + b_k) = b_reg[set][it];
   };
 
   double fa[MT], fan[MT];
@@ -303,14 +341,15 @@ __global__ __launch_bounds__(WTHREADS) void pointcov_pack_kernel(int64_t L, int6
   }
 }
 
-template <int NTQ, int MT>
+template <int NTQ, int MT, int RGN = 2>
 void launch_wide2(dim3 grid, hipStream_t st, int64_t M, int64_t L, int64_t K, const double* P4, const double2* Xp, int64_t ktiles,
                   double* C, int64_t ldc, double* slabs, int64_t kchunk, int nchunks, const PointGen& gen) {
-  constexpr size_t shmem = (64 + 2 * (WBK * (32 * MT + 16) + 4 * NTQ * 16 * WBKP)) * sizeof(double);
+  constexpr int NIT = ((8 / RGN) * NTQ * 16 + WCSTEP - 1) / WCSTEP;
+  constexpr size_t shmem = (64 + 2 * (WBK * (16 * MT * RGN + 16) + NIT * WCSTEP * WBKP)) * sizeof(double);
   static std::atomic<uint64_t> attr_mask{0};
   if (first_use_on_this_device(attr_mask))
-    (void)hipFuncSetAttribute((const void*)pointcov_wide_kernel<NTQ, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  hipLaunchKernelGGL((pointcov_wide_kernel<NTQ, MT>), grid, dim3(WTHREADS), shmem, st, M, L, K, P4, Xp, ktiles, C, ldc, slabs,
+    (void)hipFuncSetAttribute((const void*)pointcov_wide_kernel<NTQ, MT, RGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL((pointcov_wide_kernel<NTQ, MT, RGN>), grid, dim3(WTHREADS), shmem, st, M, L, K, P4, Xp, ktiles, C, ldc, slabs,
                      kchunk, nchunks, gen);
 }
 template <int NTQ>
@@ -325,18 +364,30 @@ int forced_split() {
   return f;
 }
 // the tiling of a product with L columns: chunks of 64 ntq columns, ntq in 3..5 (L > 160)
-struct WideTiling { int ntq, mt; int64_t nchunks, active; int nsplit; int64_t kchunk; int ns_eff; };
+// rgn = 4: the 192-row x (128 | 160)-column arrangement for 97 <= L <= 160 (one chunk); pack_groups = 64-column groups per chunk of
+// the packed X stream
+struct WideTiling { int ntq, mt, rgn, pack_groups; int64_t nchunks, active; int nsplit; int64_t kchunk; int ns_eff; };
 WideTiling wide_tiling(int64_t M, int64_t L, int64_t K) {
   WideTiling w;
   static const int rows = getenv("GSI_POINTCOV_ROWS") ? atoi(getenv("GSI_POINTCOV_ROWS")) : 96;   // 64 | 96 rows per workgroup (A/B)
-  w.mt = (rows == 64) ? 2 : 3;
   const int64_t tiles = (L + 15) / 16;
-  const int64_t nch = (tiles + 19) / 20;
-  const int64_t nt = (tiles + nch - 1) / nch;                 // balanced: 11 .. 20 tiles per chunk
-  w.ntq = (int)((nt + 3) / 4);
-  if (w.ntq < 3) w.ntq = 3;
-  w.nchunks = (L + 64 * w.ntq - 1) / (64 * w.ntq);
-  w.active = ((M + 32 * w.mt - 1) / (32 * w.mt)) * w.nchunks;
+  if (L <= 160) {
+    w.rgn = 4; w.mt = 3;
+    w.ntq = (tiles <= 8) ? 4 : 5;                              // 128 or 160 columns per workgroup
+    w.nchunks = 1;
+    w.pack_groups = (2 * w.ntq * 16 + WCSTEP - 1) / WCSTEP;    // 2 or 3
+    w.active = (M + 191) / 192;
+  } else {
+    w.rgn = 2;
+    w.mt = (rows == 64) ? 2 : 3;
+    const int64_t nch = (tiles + 19) / 20;
+    const int64_t nt = (tiles + nch - 1) / nch;               // balanced: 11 .. 20 tiles per chunk
+    w.ntq = (int)((nt + 3) / 4);
+    if (w.ntq < 3) w.ntq = 3;
+    w.nchunks = (L + 64 * w.ntq - 1) / (64 * w.ntq);
+    w.pack_groups = w.ntq;
+    w.active = ((M + 32 * w.mt - 1) / (32 * w.mt)) * w.nchunks;
+  }
   // K splits: the grid takes ceil(g s / 256) / s rounds of workgroups, and with 2110 row blocks (n = 202 500, 96 rows) the
   // partial last round is the whole difference between 8.24 and 9 -- measured 478 (s = 1), 453 (2), 439 (4), 440 ms (8), exactly
   // the model.  So the best s is taken outright (the contraction kernel's chooser asks for a 3 % gain per step and stops at 2).
@@ -358,13 +409,14 @@ WideTiling wide_tiling(int64_t M, int64_t L, int64_t K) {
 }
 bool wide_applies(int64_t L) {
   static const bool on = !(getenv("GSI_POINTCOV_WIDE") != nullptr && getenv("GSI_POINTCOV_WIDE")[0] == '0');   // A/B
-  return on && L > 160;
+  static const bool tall_on = !(getenv("GSI_POINTCOV_TALL") != nullptr && getenv("GSI_POINTCOV_TALL")[0] == '0');   // A/B: l <= 160 on GEN 2
+  return on && (L > 160 || (tall_on && L > 96));              // narrower sketches: gemm_f64.hip's 128 x 160 form (GEN 2)
 }
 }  // namespace
 
 size_t gemm_pointcov_workspace_doubles(int64_t M, int64_t L, int64_t K) {
   size_t need = gemm_workspace_doubles(M, L, K);
-  if (L > 160) {
+  if (wide_applies(L)) {
     const WideTiling w = wide_tiling(M, L, K);
     if (w.ns_eff > 1) need = std::max(need, (size_t)w.ns_eff * (size_t)M * (size_t)L);
   }
@@ -375,7 +427,7 @@ size_t gemm_pointcov_pack_doubles(int64_t M, int64_t L, int64_t K) {
   if (M <= 0 || L <= 0 || K <= 0 || !wide_applies(L)) return 0;
   const WideTiling w = wide_tiling(M, L, K);
   const int64_t ktiles = (K + WBK - 1) / WBK;
-  return (size_t)w.nchunks * (size_t)ktiles * (size_t)(64 * w.ntq) * (size_t)WBK;
+  return (size_t)w.nchunks * (size_t)ktiles * (size_t)(WCSTEP * w.pack_groups) * (size_t)WBK;
 }
 
 // returns false when the product is not this kernel's (narrow sketches: gemm_f64.hip's 160-column kernel generates once anyway).
@@ -387,11 +439,15 @@ bool gemm_f64_pointcov_wide(hipStream_t st, int64_t M, int64_t L, int64_t K, con
   const WideTiling w = wide_tiling(M, L, K);
   const int64_t ktiles = (K + WBK - 1) / WBK;
   double2* const Xp = reinterpret_cast<double2*>(xpack);
-  hipLaunchKernelGGL(pointcov_pack_kernel, dim3((unsigned)ktiles, (unsigned)w.nchunks), dim3(WTHREADS), 0, st, L, K, B, ldb, w.ntq,
+  hipLaunchKernelGGL(pointcov_pack_kernel, dim3((unsigned)ktiles, (unsigned)w.nchunks), dim3(WTHREADS), 0, st, L, K, B, ldb, w.pack_groups,
                      ktiles, Xp);
   const PointGen gen = {(int32_t)npts, kind, d, 0, roff, koff, sigma2, nugget};
   dim3 grid((unsigned)w.active, (unsigned)w.ns_eff, 1);
   double* slabs = (w.ns_eff > 1) ? ws : nullptr;
+  if (w.rgn == 4) {
+    if (w.ntq == 4) launch_wide2<4, 3, 4>(grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen);
+    else launch_wide2<5, 3, 4>(grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen);
+  } else
   switch (w.ntq) {
     case 3: launch_wide<3>(w.mt, grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;
     case 4: launch_wide<4>(w.mt, grid, st, M, L, K, pts4, Xp, ktiles, C, ldc, slabs, w.kchunk, (int)w.nchunks, gen); break;

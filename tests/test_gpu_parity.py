@@ -1341,7 +1341,11 @@ def _dense_pointcov(P, kind, ell, sigma2, nugget):
                                          # the 64-row x 320-column kernel (pointcov_gemm.hip: 160 < l): ragged widths, three
                                          # dimensions, fewer rows than one tile, two column chunks, an even leading dimension
                                          (1500, 3, "matern52", 250), (3000, 2, "gaussian", 400), (50, 2, "exponential", 170),
-                                         (5000, 1, "matern32", 192), (2048, 3, "exponential", 320)])
+                                         (5000, 1, "matern32", 192), (2048, 3, "exponential", 320),
+                                         # the 192-row x 160-column arrangement (97 <= l <= 160): ragged widths on both of its
+                                         # column counts (128, 160), fewer rows than one tile, three dimensions, a nugget
+                                         (1000, 2, "exponential", 97), (3001, 3, "gaussian", 128), (190, 2, "matern52", 144),
+                                         (4099, 1, "exponential", 150)])
 def test_pointcov_implicit_products(gsi, ctx, n, d, kind, l):
     rng = np.random.default_rng(n + l)
     P = rng.uniform(0.0, 30.0, size=(d, n))

@@ -25,7 +25,7 @@ PINNED = [
     r"gsi::hipk::gemm_f64_kernel<8, true, 0, 0>",
     r"gsi::hipk::gemm_f64_kernel<10, false, 1, [012]>",  # table-generated operand (the implicit 10^6 x 10^6 covariance)
     r"gsi::hipk::gemm_f64_kernel<10, false, 2, [012]>",  # scattered-point operand, 128 x 160 form
-    r"gsi::hipk::pointcov_wide_kernel<",                 # scattered-point operand, 96 x 320 form
+    r"gsi::hipk::\(anonymous namespace\)::pointcov_wide_kernel<",   # scattered-point operand: 96 x 320 and 192 x 160 forms
     r"gsi::hipk::lu_leaf_kernel<512, 8, false, false>",  # lu(Y).L leaves                   (RandMatFact.jl:60-61,68-69,72-73)
     r"gsi::hipk::lu_rankk_kernel<64, 1, 128>",
     r"gsi::hipk::sy_kernel<20, true>",                   # CholeskyQR Gram                  (RandMatFact.jl:75-76)
