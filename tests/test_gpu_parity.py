@@ -169,6 +169,48 @@ def test_svd_tall_clustered_spectrum(gsi, ctx, n, l):
     assert np.linalg.norm(W - V @ R) <= 1e-11 * np.linalg.norm(W)
 
 
+def test_svd_persistent_kernel_forms_agree_and_timeout_falls_back(gsi):
+    """The small SVD's persistent kernel (one launch for the whole Jacobi iteration, grid barrier between rounds) against the
+    launch-per-round form (GSI_SVD_PERSIST=0), and a barrier that times out at once (GSI_SVD_POLL_LIMIT=0: the launch ends with
+    its abort flag set, G is a valid partly swept matrix, the launch-per-round form finishes the job): the same singular values
+    and the same subspaces in all three, each in a process of its own (the switches are read once)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import gsi_amd as gsi
+ctx = gsi.Context(0)
+out = {}
+for l, decay in [(320, 1.0), (160, 2.0), (96, 0.5), (33, 1.0)]:
+    rng = np.random.default_rng(l)
+    n = 3 * l + 11
+    W = (rng.standard_normal((n, l)) * (np.arange(1, l + 1.0) ** -decay)) @ rng.standard_normal((l, l))
+    S, V = gsi.svd_tall(W, ctx=ctx)
+    ref = np.linalg.svd(W, compute_uv=False)
+    assert np.max(np.abs(S - ref)) < 1e-12 * ref[0], (l, np.max(np.abs(S - ref)) / ref[0])
+    assert np.abs(V.T @ V - np.eye(l)).max() < 1e-11
+    out["S%d" % l] = S
+np.savez(sys.argv[1], **out)
+print("svd-ok", ctx.counters()["jacobi_sweeps"])
+"""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("persistent", {}), ("per-round", {"GSI_SVD_PERSIST": "0"}), ("timeout", {"GSI_SVD_POLL_LIMIT": "0"})):
+            env = dict(os.environ)
+            env.update(extra)
+            path = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=env, cwd=here)
+            assert r.returncode == 0 and "svd-ok" in r.stdout, tag + ": " + r.stdout[-2000:] + r.stderr[-4000:]
+            res[tag] = dict(np.load(path))
+    for k in res["persistent"]:
+        for tag in ("per-round", "timeout"):
+            assert np.max(np.abs(res[tag][k] - res["persistent"][k])) < 1e-12 * res["persistent"][k][0], (k, tag)
+
+
 @pytest.mark.parametrize("n,l", [(1400, 1300), (2800, 2600)])
 def test_svd_tall_very_wide(gsi, ctx, n, l):
     """Sketch widths beyond the 16- and 8-column LDS blockings of the Jacobi kernel (4 / 2 columns per block)."""
@@ -674,7 +716,7 @@ def test_fft_grid_limit_is_refused_at_creation(gsi, ctx):
     """An embedding of 2^31 points (32-bit offsets inside a column pair's array): GSI_ERR_ARG when the operator is created,
     before spectrum and work array are allocated -- not at the first product."""
     before = ctx.device_bytes()
-    with pytest.raises(gsi.GsiError, match="fewer than 2\^31"):
+    with pytest.raises(gsi.GsiError, match=r"fewer than 2\^31"):
         gsi.fft_powerlaw_operator(ctx, [1024, 512, 512], -3.5)
     assert ctx.device_bytes() == before
 
