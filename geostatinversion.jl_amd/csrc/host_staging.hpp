@@ -16,6 +16,8 @@
 // its stream when it has queued its last rectangle of that block.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -65,17 +67,47 @@ inline std::vector<StageRect> stage_plan_rowblocks(int64_t rows, int64_t cols, i
   return v;
 }
 
+// The CPUs next to the GPU (its PCIe root's NUMA node), from sysfs: the staging workers run there and their pinned buffers are
+// allocated and first written there.  On the two-socket box this was measured on, a process on the GPU's node moves 54 GB/s in
+// both directions, one on the other node 51 up and 42 down (profiles/r05_boundary_numa.log); wherever the CALLER's thread and
+// arrays are, the workers' side of the copy is then always the short one.  Best effort: no sysfs entry, no binding.
+inline bool gpu_local_cpus(int device, cpu_set_t* set) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return false;
+  for (char* p = bdf; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return false;
+  char buf[1024] = {0};
+  const size_t got = fread(buf, 1, sizeof(buf) - 1, f);
+  fclose(f);
+  if (got == 0) return false;
+  CPU_ZERO(set);
+  int n = 0;
+  for (char* p = buf; *p && *p != '\n';) {                   // "64-127,192-255"
+    char* e = nullptr;
+    const long a = strtol(p, &e, 10);
+    if (e == p) break;
+    long b = a;
+    p = e;
+    if (*p == '-') { b = strtol(p + 1, &e, 10); p = e; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, set); ++n; }
+    if (*p == ',') ++p;
+  }
+  return n > 0;
+}
+
 class HostStager {
  public:
   HostStager(int device, int threads, size_t chunk_bytes) : device_(device), T_(threads), chunk_(chunk_bytes) {
     pinned_.assign((size_t)2 * T_, nullptr);
     slot_ev_.assign((size_t)2 * T_, nullptr);
     st_.assign((size_t)T_, nullptr);
+    static const bool bind_off = (getenv("GSI_STAGE_BIND") != nullptr && getenv("GSI_STAGE_BIND")[0] == '0');
+    bind_ = !bind_off && gpu_local_cpus(device_, &cpus_);
     try {
-      for (int i = 0; i < 2 * T_; ++i) {
-        ck(hipHostMalloc((void**)&pinned_[(size_t)i], chunk_, hipHostMallocDefault), "hipHostMalloc (staging buffer)");
-        ck(hipEventCreateWithFlags(&slot_ev_[(size_t)i], hipEventDisableTiming), "hipEventCreate");
-      }
+      for (int i = 0; i < 2 * T_; ++i) ck(hipEventCreateWithFlags(&slot_ev_[(size_t)i], hipEventDisableTiming), "hipEventCreate");
       for (int t = 0; t < T_; ++t) ck(hipStreamCreateWithFlags(&st_[(size_t)t], hipStreamNonBlocking), "hipStreamCreate");
     } catch (...) {
       free_all();
@@ -83,7 +115,20 @@ class HostStager {
     }
     blocks_done_.reset(new std::atomic<int>[(size_t)T_]);
     for (int t = 0; t < T_; ++t) blocks_done_[(size_t)t].store(0);
+    ready_ = 0;
     for (int t = 0; t < T_; ++t) workers_.emplace_back([this, t] { worker(t); });
+    {                                                       // every worker has bound itself and allocated its two buffers
+      std::unique_lock<std::mutex> g(mu_);
+      done_cv_.wait(g, [this] { return ready_ == T_; });
+    }
+    if (!init_error_.empty()) {
+      { std::lock_guard<std::mutex> g(mu_); quit_ = true; }
+      cv_.notify_all();
+      for (auto& w : workers_) w.join();
+      workers_.clear();
+      free_all();
+      throw std::runtime_error(init_error_);
+    }
   }
   ~HostStager() {
     {
@@ -173,6 +218,20 @@ class HostStager {
     for (auto& p : devstage_) if (p) hipFree(p);
   }
   void worker(int t) {
+    // bound to the GPU's NUMA node first, then the pinned buffers: allocated and first written from there
+    if (bind_) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpus_), &cpus_);
+    {
+      std::string err;
+      if (hipSetDevice(device_) != hipSuccess) err = "hipSetDevice failed in a staging worker";
+      for (int i = 0; i < 2 && err.empty(); ++i) {
+        hipError_t e = hipHostMalloc((void**)&pinned_[(size_t)(2 * t + i)], chunk_, hipHostMallocDefault);
+        if (e != hipSuccess) { err = std::string("hipHostMalloc (staging buffer): ") + hipGetErrorString(e); (void)hipGetLastError(); }
+        else memset(pinned_[(size_t)(2 * t + i)], 0, chunk_);
+      }
+      std::lock_guard<std::mutex> g(mu_);
+      if (!err.empty() && init_error_.empty()) init_error_ = err;
+      if (++ready_ == T_) done_cv_.notify_all();
+    }
     int64_t seen = 0;
     for (;;) {
       {
@@ -278,6 +337,10 @@ class HostStager {
 
   int device_, T_;
   size_t chunk_;
+  bool bind_ = false;
+  cpu_set_t cpus_;
+  int ready_ = 0;
+  std::string init_error_;
   std::vector<double*> pinned_, devstage_;    // devstage_: device-side staging for rectangles that are strided on the device (lazy)
   std::vector<hipEvent_t> slot_ev_, blk_ev_;
   std::vector<hipStream_t> st_;
