@@ -503,7 +503,7 @@ def _timed(fn, reps=1):
     return sorted(ts)[len(ts) // 2]
 
 
-def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms, c2_step_ms):
+def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms, c2_step_ms, c1_oracle_ms=None):
     """"upload and Omega generation timed and reported separately".  Every figure of the line above is
     device-resident; what the reference's callers invoke hands over HOST memory -- getxis(Q::Matrix, numxis, p, q, seed)
     (GeostatInversion.jl:63-70), LowRankCovMatrix(samples) (lowrank.jl:14-30), randn(n, l) on the host (RandMatFact.jl:54).
@@ -563,7 +563,8 @@ def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms
         "gsi_randsvd_dense_host_ms": 1e3 * t_all,
         "what": "gsi_randsvd_dense_host = what getxis(Q::Matrix, ...) costs per call: matrix up, Omega up, randsvd, Z and S down",
         "device_resident_step_ms": c1_step_ms,
-        "host_api_over_device_resident": (1e3 * t_all / c1_step_ms) if c1_step_ms else None}
+        "host_api_over_device_resident": (1e3 * t_all / c1_step_ms) if c1_step_ms else None,
+        "oracle_ms_per_step": c1_oracle_ms, "oracle_note": "the numpy/scipy oracle on this box's host cores, same matrix (secondary.c1_dense_2000)"}
 
     # ---- C2: 65536 x 65536 (34.4 GB), K = 128, p = 32, q = 2 ---------------------------------------------------------
     # the Gaussian covariance of the 256 x 256 grid is a Kronecker product: built on the host in seconds
@@ -1053,7 +1054,8 @@ def main():
             hb = dict(host, S=Sv) if host is not None else None
             out["boundary"] = boundary_block(gsi, ctx, barrier, ms_per_step, hb, Ns, K, p, q,
                                              sec_.get("c1_dense_2000", {}).get("ms_per_step"),
-                                             sec_.get("c2_dense_65536", {}).get("ms_per_step"))
+                                             sec_.get("c2_dense_65536", {}).get("ms_per_step"),
+                                             sec_.get("c1_dense_2000", {}).get("oracle_ms_per_step"))
         except Exception as exc:                            # noqa: BLE001 -- must not cost the line
             out["boundary"] = {"error": f"{type(exc).__name__}: {exc}"}
             for ch in list(ctx._children):

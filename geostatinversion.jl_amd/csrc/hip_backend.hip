@@ -963,7 +963,6 @@ class HipBackend : public Backend {
     w.norms = (double*)ws_svd_.p;
     w.pairs = (int32_t*)((char*)ws_svd_.p + sizeof(double) * (l + 8) + 64);
     w.rotcount = flags_ + 8;
-    w.persistent_ok = ranks_sharing_device_ <= 1;
     const int sw = hipk::svd_small(st_, G, l, U, S, w);
     last_svd_sweeps_ = sw < 0 ? -sw : sw;
     if (sw < 0) ++n_svd_cap_hits_;          // 40 sweeps and rotatable pairs left (factors graded over > 1e10): gsi_ctx_path_info reports it

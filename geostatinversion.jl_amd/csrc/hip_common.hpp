@@ -183,9 +183,7 @@ void scholqr3_apply(hipStream_t st, double* Y, int64_t m, int64_t l, int64_t ld,
 struct SvdWork {
   int32_t* rotcount;  // [1]
   double* norms;      // [l]
-  int32_t* pairs;     // [SVD_SCHED_INTS] block-pair activity flags, then the sparse sweep's schedule (null: plain sweeps only);
-                      // the persistent kernel's state (barrier counter, stamps, per-visit flags)
-  bool persistent_ok = true;   // false when other ranks' kernels share this device (the workgroups of a round must be co-resident)
+  int32_t* pairs;     // [SVD_SCHED_INTS] block-pair activity flags, then the sparse sweep's schedule (null: plain sweeps only)
 };
 constexpr int SVD_SCHED_INTS = 4096;
 // returns number of sweeps used

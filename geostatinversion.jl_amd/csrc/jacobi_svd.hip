@@ -271,93 +271,13 @@ __global__ __launch_bounds__(SVD_THREADS) void jacobi_block_kernel(double* __res
   if (tid == 0 && s_rot) atomicAdd(rotcount, s_rot);
 }
 
-// ---- the whole iteration in ONE launch (round 5) ---------------------------------------------------------
-// At l = 320 a step's small SVD was 134 launches of ~26 us (19 rounds x 7 sweeps of 10 workgroups) plus, from the fourth sweep
-// on, an activity kernel, a device-to-host copy of its flags and a host-built schedule per sweep.  A dependent launch costs
-// ~4.5 us on this chip whatever it does (the one-line kernels of this library all measure 4.4 - 4.8 us), and every host round
-// trip some tens.  Here the nblk / 2 workgroups of a round stay resident and walk the rounds of the round-robin tournament
-// themselves; between rounds they meet in a grid barrier (one atomic counter; release / acquire fences at agent scope around it,
-// as cooperative-groups grid.sync() does: the blocks travel between workgroups through L2 / HBM exactly as between launches).
-// What to visit is decided on the device and EXACTLY: block b carries the stamp of the last visit that rotated one of its
-// columns, the pair slot (round, workgroup) the stamp of its last visit that rotated nothing; a slot whose clean stamp is
-// newer than both of its blocks' stamps would rotate nothing again (same columns, same arithmetic) and is skipped without
-// loading anything.  The iteration ends at the first barrier at which a full cycle of nblk - 1 rounds has passed since the
-// last rotation -- every pair has then been seen below the threshold on the final columns: the same criterion as "a sweep
-// without rotations", found up to a sweep earlier, with no host in the loop.
-// (The "rotated in visit v" flags are one int per visit, final once barrier v has passed: every workgroup derives the same
-// count of rotation-free visits from them, whatever head start the fastest one has into visit v + 1.)
-// state: [0] barrier counter, [2] abort (a barrier timed out), [3] visits done, [4] converged,
-//        [8 .. 8 + nblk) block stamps, then the clean stamps of the (nblk - 1) x (nblk / 2) pair slots, then one
-//        "a rotation happened" flag per visit (index 1 .. max_visits)
-constexpr int JP_HDR = 8;
-inline int jp_state_ints(int nblk, int max_visits) { return JP_HDR + nblk + (nblk - 1) * (nblk / 2) + max_visits + 2; }
-__device__ __forceinline__ int32_t jp_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void jp_store(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <int SVD_W>
-__global__ __launch_bounds__(SVD_THREADS) void jacobi_persistent_kernel(double* __restrict__ G, int l, int lp, int nblk, double tol2,
-                                                                        int max_visits, int32_t* __restrict__ state, int poll_limit) {
-  constexpr int SVD_C = 2 * SVD_W;
-  extern __shared__ double cols[];  // [SVD_C][lp] followed by int slots
-  int* s_int = reinterpret_cast<int*>(cols + SVD_C * lp);      // [0] rotations of this visit, [1] skip, [2] stop
-  const int tid = threadIdx.x;
-  const int nwg = (int)gridDim.x;                             // == nblk / 2
-  int32_t* bstamp = state + JP_HDR;
-  int32_t* cstamp = state + JP_HDR + nblk;
-  int32_t* rotflag = cstamp + (nblk - 1) * nwg;
-  int since_rot = 0;                                          // consecutive visits without a rotation anywhere (thread 0's copy is used)
-  int visit = 0;
-  int stop = 0;                                               // 1 converged, 2 visit budget used up, 3 barrier time-out
-  while (!stop) {
-    ++visit;
-    const int r = (visit - 1) % (nblk - 1);
-    int ba, bb;
-    rr_pair(nblk, r, (int)blockIdx.x, &ba, &bb);
-    const int slot = r * nwg + (int)blockIdx.x;
-    if (tid == 0) {
-      s_int[0] = 0;
-      const int32_t mb = max(jp_load(bstamp + ba), jp_load(bstamp + bb));
-      s_int[1] = (jp_load(cstamp + slot) > mb) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_int[1]) {                                          // (uniform over the workgroup)
-      jacobi_load_blocks<SVD_W>(cols, G, l, lp, ba, bb, tid);
-      __syncthreads();
-      const int rots = jacobi_sweep_blocks<SVD_W>(cols, l, lp, tol2, 1, r == 0 ? 0 : 1, tid);
-      if ((tid & 15) == 0 && rots) atomicAdd(&s_int[0], rots);
-      __syncthreads();
-      if (s_int[0]) {
-        jacobi_store_blocks<SVD_W>(cols, G, l, lp, ba, bb, tid);
-        if (tid == 0) { jp_store(bstamp + ba, visit); jp_store(bstamp + bb, visit); jp_store(rotflag + visit, 1); }
-      } else if (tid == 0) {
-        jp_store(cstamp + slot, visit);
-      }
-    }
-    // ---- grid barrier: everything this workgroup wrote is visible to the others before any of them passes ----
-    __syncthreads();
-    if (tid == 0) {
-      __threadfence();
-      atomicAdd(state + 0, 1);
-      const int32_t target = visit * nwg;
-      int spins = 0, st_ = 0;
-      while (jp_load(state + 0) < target) {
-        if (jp_load(state + 2) != 0) { st_ = 3; break; }
-        if (++spins > poll_limit) { jp_store(state + 2, 1); st_ = 3; break; }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      __threadfence();
-      if (!st_) {
-        since_rot = jp_load(rotflag + visit) ? 0 : since_rot + 1;
-        if (since_rot >= nblk - 1) st_ = 1;
-        else if (visit >= max_visits) st_ = 2;
-      }
-      s_int[2] = st_;
-    }
-    __syncthreads();
-    stop = s_int[2];
-  }
-  if (blockIdx.x == 0 && tid == 0) { state[3] = visit; state[4] = (stop == 1) ? 1 : 0; }
-}
-
+// (Round 5 built the whole iteration as ONE persistent launch -- the workgroups of a round resident, a grid barrier between the
+// rounds, exact skipping of pair slots by modification stamps, then a look-before-sweeping step through the matrix cores --
+// and measured it against this form: SLOWER on the benchmark's factor, 4.2 - 4.4 against 3.8 ms (9 sweeps against 8), equal within
+// 2 % on random factors.  A round is ~25 us of dependent rotations, not launch latency (the barrier costs what the launch did),
+// and a barrier-synchronised round is as slow as its slowest workgroup, so nothing short of the host-built schedule of active
+// pairs below makes the late sweeps cheap.  The kernel is kept as tools/rejected_kernels/jacobi_persistent.hip.txt;
+// DESIGN.md 4.4, profiles/r05_svd_persistent_ab.log.)
 // Which block pairs still hold a column pair that would be rotated (the rotation test itself: c^2 > tol^2 a b)?  One workgroup
 // per pair ba <= bb of SVD_W-column blocks, one thread per column pair; flags[pair] = 1 / 0.  What it buys: the sweep that
 // only FINDS that nothing is left to rotate (one in ten at l = 320) becomes one small launch, and the late sweeps -- a few
@@ -438,33 +358,6 @@ static int svd_small_impl(hipStream_t st, double* G, int l, double* U, double* S
   // finding that out).  Few: the next sweep visits only those, packed greedily into rounds of disjoint block pairs.
   const int npairs = nblk * (nblk + 1) / 2;
   static const bool plain = (getenv("GSI_SVD_PLAIN") != nullptr);
-  // One persistent launch for the whole iteration (see jacobi_persistent_kernel): the default whenever several block pairs
-  // exist and this context has the chip to itself (the workgroups of a round must all be resident: nblk / 2 <= 19 of them).
-  // GSI_SVD_PERSIST=0: the launch-per-round forms below (A/B).  A barrier that times out leaves a valid, partly swept G:
-  // the forms below finish the job from there.
-  static const bool persist_off = (getenv("GSI_SVD_PERSIST") != nullptr && getenv("GSI_SVD_PERSIST")[0] == '0');
-  if constexpr (SVD_W == 16) {
-    const int max_visits = max_sweeps * (nblk - 1);
-    if (!persist_off && !plain && w.persistent_ok && nblk > 2 && w.pairs != nullptr && jp_state_ints(nblk, max_visits) <= SVD_SCHED_INTS) {
-      static std::atomic<uint64_t> attr_mask3{0};
-      if (first_use_on_this_device(attr_mask3))
-        (void)hipFuncSetAttribute((const void*)jacobi_persistent_kernel<SVD_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      hipMemsetAsync(w.pairs, 0, sizeof(int32_t) * (size_t)jp_state_ints(nblk, max_visits), st);
-      static const int poll_limit = getenv("GSI_SVD_POLL_LIMIT") ? atoi(getenv("GSI_SVD_POLL_LIMIT")) : 20000000;     // ~ seconds
-      hipLaunchKernelGGL(jacobi_persistent_kernel<SVD_W>, dim3(nblk / 2), dim3(SVD_THREADS), shmem, st, G, l, lp, nblk, tol2, max_visits,
-                         w.pairs, poll_limit);
-      int32_t hdr[JP_HDR];
-      hipMemcpyAsync(hdr, w.pairs, sizeof(hdr), hipMemcpyDeviceToHost, st);
-      hipStreamSynchronize(st);
-      if (hdr[2] == 0) {                                    // no time-out: done (converged, or the visit budget is used up)
-        hipLaunchKernelGGL(jacobi_norms_kernel, dim3((l + 3) / 4), dim3(256), 0, st, G, l, w.norms);
-        hipLaunchKernelGGL(jacobi_finish_kernel, dim3(l), dim3(64), 0, st, G, l, w.norms, U, S);
-        const int sw = (hdr[3] + nblk - 2) / (nblk - 1);
-        return hdr[4] ? sw : -sw;
-      }
-      // a workgroup waited in vain for the others (not all resident?): carry on with one launch per round
-    }
-  }
   if constexpr (SVD_W == 16) {
     if (!plain && nblk > 2 && w.pairs != nullptr && npairs + 3 * npairs <= SVD_SCHED_INTS) {
       static std::atomic<uint64_t> attr_mask2{0};

@@ -169,11 +169,10 @@ def test_svd_tall_clustered_spectrum(gsi, ctx, n, l):
     assert np.linalg.norm(W - V @ R) <= 1e-11 * np.linalg.norm(W)
 
 
-def test_svd_persistent_kernel_forms_agree_and_timeout_falls_back(gsi):
-    """The small SVD's persistent kernel (one launch for the whole Jacobi iteration, grid barrier between rounds) against the
-    launch-per-round form (GSI_SVD_PERSIST=0), and a barrier that times out at once (GSI_SVD_POLL_LIMIT=0: the launch ends with
-    its abort flag set, G is a valid partly swept matrix, the launch-per-round form finishes the job): the same singular values
-    and the same subspaces in all three, each in a process of its own (the switches are read once)."""
+def test_svd_activity_driven_and_plain_sweeps_agree(gsi):
+    """The small SVD's default form (activity flags after every sweep, host-built schedule of the active block pairs) against the
+    plain full sweeps (GSI_SVD_PLAIN=1): the same singular values to rounding, each in a process of its own (the switch is read
+    once)."""
     import os
     import subprocess
     import sys
@@ -194,21 +193,20 @@ for l, decay in [(320, 1.0), (160, 2.0), (96, 0.5), (33, 1.0)]:
     assert np.abs(V.T @ V - np.eye(l)).max() < 1e-11
     out["S%d" % l] = S
 np.savez(sys.argv[1], **out)
-print("svd-ok", ctx.counters()["jacobi_sweeps"])
+print("svd-ok")
 """
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for tag, extra in (("persistent", {}), ("per-round", {"GSI_SVD_PERSIST": "0"}), ("timeout", {"GSI_SVD_POLL_LIMIT": "0"})):
+        for tag, extra in (("activity", {}), ("plain", {"GSI_SVD_PLAIN": "1"})):
             env = dict(os.environ)
             env.update(extra)
             path = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=env, cwd=here)
             assert r.returncode == 0 and "svd-ok" in r.stdout, tag + ": " + r.stdout[-2000:] + r.stderr[-4000:]
             res[tag] = dict(np.load(path))
-    for k in res["persistent"]:
-        for tag in ("per-round", "timeout"):
-            assert np.max(np.abs(res[tag][k] - res["persistent"][k])) < 1e-12 * res["persistent"][k][0], (k, tag)
+    for k in res["activity"]:
+        assert np.max(np.abs(res["plain"][k] - res["activity"][k])) < 1e-12 * res["activity"][k][0], k
 
 
 @pytest.mark.parametrize("n,l", [(1400, 1300), (2800, 2600)])
