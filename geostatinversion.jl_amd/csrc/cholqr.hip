@@ -190,13 +190,15 @@ __global__ void cq_triprod_kernel(const double* __restrict__ R2, const double* _
 //   then                  the diagonal blocks' inverses, one wave per block, all at once;  block column j of X = R^-1 as
 //                         -X[0:j0, 0:j0] (R[0:j0, j] X_jj): the small factor row-wise in LDS, the product as MFMA tiles with
 //                         the X operand read where it lies (lane index along its rows).
-// Measured at l = 320 (GSI_CQ_TRACE=1, 100 MHz stamps by thread 0): 0.43 ms per round -- set-up 12 us, the ten diagonal blocks
-// 98, block rows 118, trailing updates 93, diagonal inverses 18, W 27, the inverse's tiles 68 -- against ~0.55 for the blocked
-// form: the thin QR of a 10^6 x 320 panel 10.9 -> 10.7 ms, of a 125 000-row shard 2.87 -> 2.58, 65536 x 160 0.82 -> 0.65
-// (profiles/r05_qr_fused_ab.log).  What is left is a chain: every step waits for one wave's 32 pivots, then for one thread
-// per column's 32-row substitution; overlapping the next diagonal block with the rest of the trailing update (look-ahead) is
-// the next step, not taken here.  Results differ from the blocked form in rounding only (summation order of the updates;
-// reciprocal pivots).
+// Measured at l = 320 (GSI_CQ_TRACE=1, 100 MHz stamps by thread 0): 0.39 ms per round -- set-up 12 us, the first diagonal block
+// 13, block rows 105, trailing updates with the next diagonal block inside them 145, diagonal inverses 19, W 28, the inverse's
+// tiles 68 -- against ~0.55 for the blocked form: the thin QR of a 10^6 x 320 panel 10.9 -> 10.5 ms, of a 125 000-row shard
+// 2.87 -> 2.42, 65536 x 160 0.82 -> 0.66 (profiles/r05_qr_fused_ab.log).  First version 0.49 ms: the W rows through the matrix
+// cores (72 -> 27 us), reciprocal square roots in the pivots, four trailing tiles' loads in flight, one block of look-ahead
+// (diagonal blocks 98 + trailing 93 -> 13 + 145) and 16-byte accesses in the block row (118 -> 105) took it here.  What is left
+// is a chain per block: a block row (10.5 us: one thread per column, LDS-broadcast reads of U11 the limit), the next block's
+// tiles, max(diagonal block, rest of the update).  Results differ from the blocked form in rounding only (summation order of
+// the updates; reciprocal pivots).
 constexpr int CQF_THREADS = 512;     // 8 waves, 2 per SIMD: 256 VGPRs each (the in-register 32 x 32 factorizations hold 64 - 128 of them)
 constexpr int CQF_MAXL = 384;                    // beyond: the blocked multi-launch form (its products use the whole chip)
 constexpr int CQF_LDU = CQF_MAXL - CQ_TB + 16;   // row stride of the block row image Us[p][c]: = 16 mod 32 (bank spread of the MFMA operand reads)
@@ -268,12 +270,22 @@ __device__ __forceinline__ void cqf_inv_diag(const double* __restrict__ G, int l
 // Eight rows at a time: the finished rows are re-read from the thread's own column of Us (LDS), so the registers hold eight
 // accumulators, not the whole column and the 496 entries of U11 the fully unrolled form loads (which the compiler kept live
 // all at once: 4 KB of scratch per lane).
+// VEC (l even and a full 32-row block): the thread's 256 contiguous bytes as sixteen 16-byte loads and stores -- across the lanes
+// the accesses are a column apart (l x 8 bytes) whatever the width, so a wave instruction touches 64 lines; halving the
+// instruction count halves the address traffic of the one texture path the CU's waves share.
+template <bool VEC>
 __device__ __forceinline__ void cqf_block_row_col(double* __restrict__ gcol /* G + j0 + (j0 + b + c) l */, int b,
                                                   const double* __restrict__ Ds, const double* __restrict__ Dinv,
                                                   double* __restrict__ us /* Us + c */) {
   double g[CQ_TB];                                       // the whole column first: ONE L2 round trip, not one per chunk
+  if constexpr (VEC) {
+    const double2* g2 = reinterpret_cast<const double2*>(gcol);
 #pragma unroll
-  for (int p = 0; p < CQ_TB; ++p) g[p] = (p < b) ? gcol[p] : 0.0;
+    for (int p = 0; p < CQ_TB; p += 2) { const double2 v = g2[p >> 1]; g[p] = v.x; g[p + 1] = v.y; }
+  } else {
+#pragma unroll
+    for (int p = 0; p < CQ_TB; ++p) g[p] = (p < b) ? gcol[p] : 0.0;
+  }
 #pragma unroll
   for (int pb = 0; pb < CQ_TB; pb += 8) {
     double acc[8];
@@ -296,13 +308,19 @@ __device__ __forceinline__ void cqf_block_row_col(double* __restrict__ gcol /* G
     for (int j = 0; j < 8; ++j) {
       const double v = (pb + j < b) ? acc[j] : 0.0;
       us[(pb + j) * CQF_LDU] = v;
-      if (pb + j < b) gcol[pb + j] = v;
+      if constexpr (!VEC) { if (pb + j < b) gcol[pb + j] = v; }
+    }
+    if constexpr (VEC) {
+      double2* o2 = reinterpret_cast<double2*>(gcol + pb);
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) o2[j >> 1] = make_double2(acc[j], acc[j + 1]);
     }
     asm volatile("" ::: "memory");                       // chunk by chunk: the next chunk's LDS reads are not hoisted over this one's
   }
 }
-// trace (null in production): 100 MHz ticks per phase, accumulated by thread 0 -- [0] set-up, [1] diagonal blocks, [2] block
-// rows, [3] trailing updates, [4] diagonal inverses, [5] W = R X_jj, [6] the inverse's tiles (tools/qr_small_time.py --trace)
+// trace (null in production): 100 MHz ticks per phase, accumulated by thread 0 -- [0] set-up, [1] the first diagonal block, [2]
+// block rows, [3] trailing updates with the next diagonal block inside them, [4] diagonal inverses, [5] W = R X_jj, [6] the
+// inverse's tiles (GSI_CQ_TRACE=1)
 #define CQF_STAMP(ph) do { if (trace != nullptr && tid == 0) { const unsigned long long now_ = wall_clock64(); trace[ph] += now_ - t_last; t_last = now_; } } while (0)
 __global__ __launch_bounds__(CQF_THREADS) void cq_chol_inv_kernel(double* __restrict__ G, int l, double* __restrict__ X,
                                                                   int32_t* __restrict__ flag, unsigned long long* __restrict__ trace) {
@@ -333,78 +351,98 @@ __global__ __launch_bounds__(CQF_THREADS) void cq_chol_inv_kernel(double* __rest
   const double tiny = red[32];
   CQF_STAMP(0);
 
-  // ================= R = chol(G), right-looking, 32-column blocks =================
+  // ================= R = chol(G), right-looking, 32-column blocks, one block of look-ahead =================
+  // Per block: B the block row (all waves); C1 the trailing tiles that touch the NEXT block's 32 rows (all waves); C2 wave 0
+  // factors the next diagonal block while waves 1..7 finish the rest of the trailing update -- the 9.8 us of a diagonal
+  // block hide behind the ~8 us the other tiles take anyway.
+  auto trailing_tiles = [&](int j0, int b, int nc, int ncp, bool first_rows, int w0, int nw) __attribute__((always_inline)) {
+    // 16 x 16 tiles (tr <= tc) of the upper triangle of the trailing matrix; first_rows: the tiles with tr < 2 (the next block's
+    // rows), else the others; dealt over waves w0, w0 + 1, .., w0 + nw - 1.  Four tiles per pass: their 16 loads of G are in
+    // flight together (one L2 round trip per pass, not per tile).
+    const int nt = ncp >> 4;
+    const int nfirst = (nt >= 2) ? (2 * nt - 1) : nt;         // tiles with tr < 2: (0, 0..nt-1), (1, 1..nt-1)
+    const int ntot = nt * (nt + 1) / 2;
+    const int cnt = first_rows ? nfirst : ntot - nfirst;
+    const int base = first_rows ? 0 : nfirst;                 // row-major over the upper triangle: tr = 0, then tr = 1, ...
+    const int jl = lane & 15, kq = lane >> 4;
+    double* Gt = G + (int64_t)(j0 + b) + (int64_t)(j0 + b) * l;     // trailing matrix (0, 0)
+    constexpr int TPP = 4;
+    if (wave < w0 || wave >= w0 + nw) return;
+    for (int t0 = wave - w0; t0 < cnt; t0 += nw * TPP) {
+      cq_double4 acc[TPP];
+      int trs[TPP], tcs[TPP];
+#pragma unroll
+      for (int u = 0; u < TPP; ++u) {
+        const int tl = t0 + u * nw;
+        int tr = 0, rem = base + ((tl < cnt) ? tl : 0);        // linear index -> (tr <= tc)
+        while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
+        trs[u] = tr; tcs[u] = tr + rem;
+        const int r = tr * 16 + jl;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = tcs[u] * 16 + kq + 4 * v;
+          acc[u][v] = (tl < cnt && r < nc && c < nc) ? Gt[r + (int64_t)c * l] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TPP; ++u) {
+#pragma unroll
+        for (int k0 = 0; k0 < CQ_TB; k0 += 4) {
+          const double fa = -Us[(k0 + kq) * CQF_LDU + tcs[u] * 16 + jl];      // a-operand: i <-> column of G
+          const double fb = Us[(k0 + kq) * CQF_LDU + trs[u] * 16 + jl];       // b-operand: j (= lane & 15) <-> row of G
+          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[u], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TPP; ++u) {
+        const int tl = t0 + u * nw;
+        const int r = trs[u] * 16 + jl;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = tcs[u] * 16 + kq + 4 * v;
+          if (tl < cnt && r < nc && c < nc) Gt[r + (int64_t)c * l] = acc[u][v];
+        }
+      }
+    }
+  };
+  if (wave == 0) cqf_chol_diag(G, l, 0, (l < CQ_TB) ? l : CQ_TB, tiny, Ds, Dinv, flag, lane);     // the first diagonal block
+  __syncthreads();
+  CQF_STAMP(1);
   for (int jb = 0; jb < nblk; ++jb) {
     const int j0 = jb * CQ_TB;
     const int b = (l - j0 < CQ_TB) ? (l - j0) : CQ_TB;
     const int nc = l - j0 - b;                              // trailing columns
-    if (wave == 0) cqf_chol_diag(G, l, j0, b, tiny, Ds, Dinv, flag, lane);     // ---- A: the diagonal block ----
-    __syncthreads();
-    CQF_STAMP(1);
-    if (nc > 0) {
-      // ---- B: block row U12 = U11^-T G12, thread = trailing column; and zeros below U11 ----
-      const int ncp = (nc + 15) & ~15;                      // the MFMA tiles read whole 16-column groups: zero padding
-      for (int c = tid; c < ncp; c += CQF_THREADS) {
-        if (c < nc) cqf_block_row_col(G + j0 + (int64_t)(j0 + b + c) * l, b, Ds, Dinv, Us + c);
-        else {
+    if (nc <= 0) break;
+    // ---- B: block row U12 = U11^-T G12, thread = trailing column; and zeros below U11 ----
+    const int ncp = (nc + 15) & ~15;                      // the MFMA tiles read whole 16-column groups: zero padding
+    const bool vec = ((l & 1) == 0) && b == CQ_TB && ((reinterpret_cast<uintptr_t>(G) & 15) == 0);
+    for (int c = tid; c < ncp; c += CQF_THREADS) {
+      if (c < nc) {
+        if (vec) cqf_block_row_col<true>(G + j0 + (int64_t)(j0 + b + c) * l, b, Ds, Dinv, Us + c);
+        else cqf_block_row_col<false>(G + j0 + (int64_t)(j0 + b + c) * l, b, Ds, Dinv, Us + c);
+      } else {
 #pragma unroll
-          for (int p = 0; p < CQ_TB; ++p) Us[p * CQF_LDU + c] = 0.0;
-        }
+        for (int p = 0; p < CQ_TB; ++p) Us[p * CQF_LDU + c] = 0.0;
       }
-      for (int e = tid; e < b * nc; e += CQF_THREADS) {     // strictly-lower part of this block column -> 0 (rows along the lanes)
-        const int r = j0 + b + e % nc, c = j0 + e / nc;
-        G[r + (int64_t)c * l] = 0.0;
-      }
-      __syncthreads();
-      CQF_STAMP(2);
-      // ---- C: trailing update of the upper triangle, 16 x 16 tiles: G22[r, c] -= sum_p U12[p, r] U12[p, c] ----
-      // Four tiles per pass: their 16 loads of G are in flight together (one L2 round trip per pass, not per tile).
-      const int nt = ncp >> 4;
-      const int ntiles = nt * (nt + 1) / 2;
-      const int jl = lane & 15, kq = lane >> 4;
-      double* Gt = G + (int64_t)(j0 + b) + (int64_t)(j0 + b) * l;     // trailing matrix (0, 0)
-      constexpr int NWV = CQF_THREADS / 64, TPP = 4;
-      // (requesting the next pass's tiles before this pass's MFMAs -- a two-deep software pipeline -- measured SLOWER, 106 against
-      // 93 us per round at l = 320: sixteen more live registers put the kernel into scratch)
-      for (int t0 = wave; t0 < ntiles; t0 += NWV * TPP) {
-        cq_double4 acc[TPP];
-        int trs[TPP], tcs[TPP];
-#pragma unroll
-        for (int u = 0; u < TPP; ++u) {
-          const int t = t0 + u * NWV;
-          int tr = 0, rem = (t < ntiles) ? t : 0;            // t -> (tr <= tc), row-major over the upper triangle
-          while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
-          trs[u] = tr; tcs[u] = tr + rem;
-          const int r = tr * 16 + jl;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int c = tcs[u] * 16 + kq + 4 * v;
-            acc[u][v] = (t < ntiles && r < nc && c < nc) ? Gt[r + (int64_t)c * l] : 0.0;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < TPP; ++u) {
-#pragma unroll
-          for (int k0 = 0; k0 < CQ_TB; k0 += 4) {
-            const double fa = -Us[(k0 + kq) * CQF_LDU + tcs[u] * 16 + jl];      // a-operand: i <-> column of G
-            const double fb = Us[(k0 + kq) * CQF_LDU + trs[u] * 16 + jl];       // b-operand: j (= lane & 15) <-> row of G
-            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[u], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < TPP; ++u) {
-          const int t = t0 + u * NWV;
-          const int r = trs[u] * 16 + jl;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int c = tcs[u] * 16 + kq + 4 * v;
-            if (t < ntiles && r < nc && c < nc) Gt[r + (int64_t)c * l] = acc[u][v];
-          }
-        }
-      }
-      __syncthreads();
-      CQF_STAMP(3);
     }
+    for (int e = tid; e < b * nc; e += CQF_THREADS) {     // strictly-lower part of this block column -> 0 (rows along the lanes)
+      const int r = j0 + b + e % nc, c = j0 + e / nc;
+      G[r + (int64_t)c * l] = 0.0;
+    }
+    __syncthreads();
+    CQF_STAMP(2);
+    // ---- C1: the trailing tiles of the next block's rows (all waves) ----
+    trailing_tiles(j0, b, nc, ncp, true, 0, CQF_THREADS / 64);
+    __syncthreads();
+    // ---- C2: wave 0 factors the next diagonal block; the other waves update the rest of the trailing matrix ----
+    {
+      const int j1 = j0 + b;
+      const int b1 = (l - j1 < CQ_TB) ? (l - j1) : CQ_TB;
+      if (wave == 0) cqf_chol_diag(G, l, j1, b1, tiny, Ds, Dinv, flag, lane);
+      trailing_tiles(j0, b, nc, ncp, false, 1, CQF_THREADS / 64 - 1);
+    }
+    __syncthreads();
+    CQF_STAMP(3);
   }
 
   // ================= X = R^-1 =================
