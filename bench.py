@@ -23,7 +23,7 @@ roofline     = the dominant kernel, the fp64 MFMA contraction gemm_f64_kernel: 2
                average launch duration (HIP events on the library's stream around every operator contraction inside
                the timed region), against the 78.6 TFLOP/s dense fp64 MFMA peak; the same launches against the HBM
                peak ("hbm"); `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of this very command
-               (tools/pmc_bench_traffic.sh -> profiles/r04_bench_traffic.json, older rounds' files behind it; keyed on a
+               (tools/pmc_bench_traffic.sh -> profiles/r05_bench_traffic.json, older rounds' files behind it; keyed on a
                hash over all of csrc/ + the public header: null when collected on a different build)
 phases_hbm   = the HBM-bound panel phases (LU, QR, Z = Q_W U): one read + one write of the n x l panel per
                factorization over the measured time per factorization, against 8 TB/s
@@ -50,7 +50,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILES = ["r04_bench_traffic.json", "r03_bench_traffic.json", "r02_bench_traffic.json"]   # newest first; replayed only on a hash match
+TRAFFIC_FILES = ["r05_bench_traffic.json", "r04_bench_traffic.json", "r03_bench_traffic.json", "r02_bench_traffic.json"]   # newest first; replayed only on a hash match
 
 
 def kernel_source_hash():
