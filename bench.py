@@ -503,6 +503,16 @@ def _timed(fn, reps=1):
     return sorted(ts)[len(ts) // 2]
 
 
+def settle(ctx, seconds=6.0):
+    """Give the context's cached device memory back and let the driver finish with it before anything is timed: after tens
+    of GB are freed (232 GB by the 512^3 workload, 34 GB by C2's matrix) host<->device copies ran at half their rate for a
+    few seconds -- the DMA engines that move our chunks were busy with the freed pages (28 against 53 GB/s on the headline's
+    Omega / Z inside a full run, profiles/r05_boundary_after_free.log).  Untimed."""
+    ctx.release_cache()
+    ctx.sync()
+    time.sleep(seconds)
+
+
 def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms, c2_step_ms, c1_oracle_ms=None):
     """"upload and Omega generation timed and reported separately".  Every figure of the line above is
     device-resident; what the reference's callers invoke hands over HOST memory -- getxis(Q::Matrix, numxis, p, q, seed)
@@ -576,7 +586,7 @@ def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms
     A2 = np.kron(k1, k1).T                               # symmetric: the transposed view is the column-major matrix, no copy
     t_build = time.perf_counter() - t0
     Om2 = np.asfortranarray(np.random.default_rng(2).standard_normal((n2, l2)))
-    ctx.release_cache()
+    settle(ctx)
     ops = []
     t_up2 = _timed(lambda: ops.append(gsi.dense_operator(ctx, A2)))
     Z2r, S2r = host_randsvd(ops[0], Om2, K2, p2, q2)     # warm (workspaces exist afterwards)
@@ -601,7 +611,7 @@ def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms
         "device_resident_step_ms": c2_step_ms,
         "host_api_over_device_resident": (1e3 * t_all2 / c2_step_ms) if c2_step_ms else None}
     del A2, Z2, Z2r
-    ctx.release_cache()
+    settle(ctx)
 
     # ---- headline: LowRankCovMatrix(samples) with 8.2 GB of samples, Omega 2.56 GB in, Z 2.56 GB out -------------------
     if host is not None and "samples" in host:
