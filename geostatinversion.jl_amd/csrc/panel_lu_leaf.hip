@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256) void lu_u12_kernel(const double* __restrict__ 
 // MFMA operands swapped like the big contraction kernel: lane (jl = lane & 15, kk = lane >> 4) holds, for C row
 // jl (+16 h), the columns kk + 4 reg of a 16-column tile.
 template <int K, int DEPTH, int RK_CHUNK>
-__global__ __launch_bounds__(256) void lu_rankk_kernel(double* __restrict__ Y, int64_t ld, int64_t m, int64_t r_begin,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RK_CHUNK == 64 ? 3 : 2, RK_CHUNK == 64 ? 3 : 4))) void lu_rankk_kernel(double* __restrict__ Y, int64_t ld, int64_t m, int64_t r_begin,
                                                        int64_t jb, int64_t c0, int64_t t,
                                                        const double* __restrict__ U12) {
   typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -996,12 +996,18 @@ static void launch_rankk_v(hipStream_t st, unsigned grid, double* Y, int64_t ld,
   hipLaunchKernelGGL((lu_rankk_kernel<K, DEPTH, CHUNK>), dim3(grid), dim3(256), shmem, st, Y, ld, m, r_begin, jb, c0, t, U12);
 }
 // U12 columns staged per pass (its LDS image bounds the workgroups per CU: 128 columns = 67 KB = 2 workgroups, 64 = 4) and C
-// tiles in flight per wave: A/B knobs GSI_LU_RK_CHUNK (64 | 128), GSI_LU_RK_DEPTH (1 | 2)
+// tiles in flight per wave: A/B knobs GSI_LU_RK_CHUNK (64 | 128), GSI_LU_RK_DEPTH (1 | 2).
+// Round 5: THREE waves per SIMD.  The kernel is a latency chain per wave (C tile in, 2 K / 4 MFMAs, C tile out) at 44 % of the
+// matrix pipe and 0.54 of the HBM peak; with 164 VGPRs + 16 AGPRs it ran two waves per SIMD whatever the chunk.  Told to fit
+// three (amdgpu_waves_per_eu on the 64-column instantiations: 160 VGPRs, no AGPR copies, no spills) and with 64-column chunks
+// (34 KB of LDS: three workgroups per CU) the four updates of a factorization take 2.4 instead of 2.8 ms: LU 29.4 -> 27.7 - 28.4 ms
+// per step in alternating runs (profiles/r05_lu_rankk_occupancy.log).  Four waves (128 VGPRs) spill 46 registers: 32.6.  The
+// same 64-column chunks at two waves per SIMD were "noise" in round 3 (tools/ab_rankk.sh): it was the occupancy, not the chunk.
 template <int K>
 static void launch_rankk(hipStream_t st, unsigned grid, double* Y, int64_t ld, int64_t m, int64_t r_begin, int64_t jb,
                          int64_t c0, int64_t t, const double* U12) {
   static const int depth = getenv("GSI_LU_RK_DEPTH") ? atoi(getenv("GSI_LU_RK_DEPTH")) : 1;
-  static const int chunk = getenv("GSI_LU_RK_CHUNK") ? atoi(getenv("GSI_LU_RK_CHUNK")) : 128;
+  static const int chunk = getenv("GSI_LU_RK_CHUNK") ? atoi(getenv("GSI_LU_RK_CHUNK")) : 64;
   if (chunk == 64 && depth == 2) launch_rankk_v<K, 2, 64>(st, grid, Y, ld, m, r_begin, jb, c0, t, U12);
   else if (chunk == 64) launch_rankk_v<K, 1, 64>(st, grid, Y, ld, m, r_begin, jb, c0, t, U12);
   else if (depth == 2) launch_rankk_v<K, 2, 128>(st, grid, Y, ld, m, r_begin, jb, c0, t, U12);

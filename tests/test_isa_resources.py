@@ -31,7 +31,7 @@ def test_the_record_covers_the_kernels_that_carry_a_step():
     """The six kernels on top of the last profiled bench run (profiles/r04_bench_kernel_stats.csv) + the generated forms."""
     rec = json.load(open(isa_resources.RECORD))["kernels"]
     for k in ("gsi::hipk::gemm_f64_kernel<10, false, 0, 0>", "gsi::hipk::gemm_f64_kernel<10, true, 0, 0>",
-              "gsi::hipk::lu_leaf_kernel<512, 8, false, false>", "gsi::hipk::lu_rankk_kernel<64, 1, 128>",
+              "gsi::hipk::lu_leaf_kernel<512, 8, false, false>", "gsi::hipk::lu_rankk_kernel<64, 1, 64>",
               "gsi::hipk::sy_kernel<20, true>", "gsi::hipk::tr_kernel<20, true>", "gsi::hipk::gemm_f64_kernel<10, false, 1, 0>",
               "gsi::hipk::gemm_f64_kernel<10, false, 1, 1>", "gsi::hipk::gemm_f64_kernel<10, false, 1, 2>"):
         assert k in rec, k

@@ -27,7 +27,7 @@ PINNED = [
     r"gsi::hipk::gemm_f64_kernel<10, false, 2, [012]>",  # scattered-point operand, 128 x 160 form
     r"gsi::hipk::\(anonymous namespace\)::pointcov_wide_kernel<",   # scattered-point operand: 96 x 320 and 192 x 160 forms
     r"gsi::hipk::lu_leaf_kernel<512, 8, false, false>",  # lu(Y).L leaves                   (RandMatFact.jl:60-61,68-69,72-73)
-    r"gsi::hipk::lu_rankk_kernel<64, 1, 128>",
+    r"gsi::hipk::lu_rankk_kernel<64, 1, (64|128)>",   # (64-column chunks at three waves per SIMD: the default since round 5)
     r"gsi::hipk::sy_kernel<20, true>",                   # CholeskyQR Gram                  (RandMatFact.jl:75-76)
     r"gsi::hipk::tr_kernel<20, true>",
     r"gsi::hipk::jacobi_block_kernel<16>",               # svd(B)                           (RandMatFact.jl:86)
