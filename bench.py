@@ -162,12 +162,11 @@ def toolchain_info():
     """What compiled the kernels (the resource usage of the hot kernels is pinned per compiler version,
     profiles/isa_resources.json) and what runs them."""
     info = {}
-    try:
-        r = subprocess.run(["hipcc", "--version"], capture_output=True, text=True, timeout=60)
-        lines = [ln.strip() for ln in r.stdout.splitlines() if ln.strip()]
-        info["hipcc_version"] = "; ".join(lines[:2])
-    except Exception as exc:                                # noqa: BLE001
-        info["hipcc_version"] = f"unavailable ({type(exc).__name__})"
+    try:                                                    # written by build.py when it compiled the library: no compiler is started here
+        with open(os.path.join(ROOT, "geostatinversion.jl_amd", "build", "hipcc_version.txt")) as f:
+            info["hipcc_version"] = f.read().strip()
+    except OSError:
+        info["hipcc_version"] = "unrecorded (library built without build.py)"
     try:
         info["isa_resources"] = json.load(open(os.path.join(ROOT, "profiles", "isa_resources.json"))).get("hipcc_version")
     except Exception:                                       # noqa: BLE001

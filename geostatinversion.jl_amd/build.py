@@ -118,6 +118,13 @@ def build(force=False, verbose=False):
                     print(warn)
     if jobs or force or _newer(LIB, objs):
         run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,-Bsymbolic", "-o", LIB] + objs + ["-ldl"])
+    # what compiled the library, as a build-time fact beside it (bench.py prints it; it must not start a compiler at run time:
+    # under `rocprofv3 --pmc` every child inherits the profiler's preload, and hipcc's own exec of its helper is then an exec
+    # from a process that has initialised the GPU -- the GPU boxes refuse that)
+    vfile = os.path.join(OBJ, "hipcc_version.txt")
+    if jobs or force or not os.path.exists(vfile):
+        with open(vfile, "w") as f:
+            f.write(hipcc_version() + "\n")
     return LIB
 
 
