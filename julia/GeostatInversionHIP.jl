@@ -57,7 +57,12 @@ end
 "Return the context's cached device memory (released panels, idle workspaces) to the driver."
 release_cache!(c::Context) = check(ccall((:gsi_ctx_release_cache, libgsi), Cint, (Ptr{Cvoid},), c.h))
 const default_ctx = Ref{Union{Nothing, Context}}(nothing)
-ctx() = something(default_ctx[], (default_ctx[] = Context(0)))
+"The process-wide default context (GPU 0), created at its first use.  (`something(a, b)` would evaluate `b` -- a new
+context -- at every call: the arguments of a function are evaluated before it runs.)"
+function ctx()
+	default_ctx[] === nothing && (default_ctx[] = Context(0))
+	return default_ctx[]::Context
+end
 
 "Join `nranks` contexts (one Julia process per GPU) into an RCCL communicator; rank 0 creates the id."
 function unique_id()

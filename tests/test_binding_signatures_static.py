@@ -232,3 +232,12 @@ def test_julia_blocks_balance(path):
             opens += 1
     assert not stack, f"{path}: unclosed {stack[-1][0]} of line {stack[-1][1]}"
     assert opens == ends, f"{path}: {opens} block openers, {ends} `end`s"
+
+
+def test_default_context_is_created_once():
+    """`something(default_ctx[], (default_ctx[] = Context(0)))` built a new GPU context at EVERY `ctx()` call (a function's
+    arguments are evaluated before it runs): operators and matrices of one session ended up on different contexts."""
+    src = _strip_jl(open(JULIA_FILES[0]).read())
+    assert not re.search(r"something\s*\([^)]*Context\s*\(", src)
+    body = re.search(r"function ctx\(\)(.*?)\nend", src, flags=re.S)
+    assert body and "=== nothing" in body.group(1) and body.group(1).count("Context(0)") == 1
