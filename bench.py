@@ -537,8 +537,10 @@ def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms
     outs = {}
 
     def out_arrays(n_, l_):
-        # result arrays that exist already (written once): a first write into fresh pages costs the HOST ~0.25 us per 4 KB page
-        # -- 0.15 s for the headline's 2.56 GB Z -- whoever fills them; reported separately below ("fresh_output_array")
+        # result arrays that exist already (written once).  A FRESH array (what the Julia shim's Matrix{Float64}(undef, n, l)
+        # is) costs the staged download 2-5 ms more: the workers' first-touch faults hide under their DMA waits
+        # (tools/prefault_probe.py, profiles/r05_prefault_probe.log); reported below as "fresh_output_array", with the host's own
+        # cost of creating and unmapping such an array beside it -- which an earlier version of this block timed as the call's.
         if (n_, l_) not in outs:
             outs[(n_, l_)] = (np.zeros((n_, l_), order="F"), np.zeros(l_))
         return outs[(n_, l_)]
@@ -628,7 +630,14 @@ def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms
         Zh, Svh = host_randsvd(hs[0], Om, K, p, q)         # warm
         Svh = Svh.copy()
         t_rsh = _timed(lambda: host_randsvd(hs[0], Om, K, p, q), reps=3)
-        t_fresh = _timed(lambda: host_randsvd(hs[0], Om, K, p, q, fresh=True))
+        t0 = time.perf_counter()
+        Zf, Sf = np.empty((n, l), order="F"), np.empty(l)          # fresh pages, never written
+        t_alloc = time.perf_counter() - t0
+        t_fresh = _timed(lambda: L.check(lib.gsi_randsvd(ctx.h, hs[0].h, L.dptr(Om), K, p, q, L.dptr(Zf), Sf.ctypes.data_as(L.c_dp)), lib))
+        fresh_same = bool(np.array_equal(Zf, Zh))
+        t0 = time.perf_counter()
+        del Zf
+        t_free = time.perf_counter() - t0
         back = np.zeros_like(Sh)
         t_dn = _timed(lambda: L.check(lib.gsi_op_lowrank_samples(ctx.h, hs[0].h, back.ctypes.data_as(L.c_dp), n), lib))
         hs[0].close()
@@ -637,6 +646,8 @@ def boundary_block(gsi, ctx, barrier, headline_ms, host, Ns, K, p, q, c1_step_ms
             "gsi_op_lowrank_samples_download": rate(Sh.nbytes, t_dn, max(d2h.value, 1e-9)),
             "gsi_randsvd_host_Omega_in_Z_out_ms": 1e3 * t_rsh,
             "gsi_randsvd_host_fresh_output_array_ms": 1e3 * t_fresh,
+            "fresh_output_equals_reused_output_bitwise": fresh_same,
+            "host_side_np_empty_ms": 1e3 * t_alloc, "host_side_unmap_of_a_written_result_ms": 1e3 * t_free,
             "host_transfer_bytes_per_call": float(2 * Om.nbytes),
             "device_resident_step_ms": headline_ms,
             "host_api_over_device_resident": 1e3 * t_rsh / headline_ms,
