@@ -248,6 +248,14 @@ end
 Base.adjoint(A::DeviceOperator) = AdjointOperator(A)
 Base.transpose(A::DeviceOperator) = AdjointOperator(A)
 Base.size(A::AdjointOperator) = (A.parent.n, A.parent.m)
+function Base.size(A::AdjointOperator, i::Int)
+	(i == 1 || i == 2) || error("there is no $i-th dimension in a DeviceOperator")   # lowrank.jl:58
+	return i == 1 ? A.parent.n : A.parent.m
+end
+Base.eltype(::AdjointOperator) = Float64
+Base.adjoint(At::AdjointOperator) = At.parent
+Base.transpose(At::AdjointOperator) = At.parent
+Base.:*(At::AdjointOperator, x::Vector{Float64}) = vec(At * reshape(x, :, 1))
 function Base.:*(At::AdjointOperator, X::Matrix{Float64})
 	A = At.parent
 	Y = Matrix{Float64}(undef, A.n, size(X, 2))
@@ -592,6 +600,8 @@ function pcgalsqr(forwardmodel::Function, s0::Vector, X::Vector, xis::DeviceBasi
 	end
 	return s
 end
+
+const pcga = pcgadirect                                                                  # GeostatInversion.jl:105
 
 "`rga(forwardmodel, s0, X, xis, R, y, S; ...)`  (GeostatInversion.jl:101-103)"
 rga(forwardmodel::Function, s0::Vector, X::Vector, xis::DeviceBasis, R, y::Vector, S; pcgafunc=pcgadirect, kwargs...) =
