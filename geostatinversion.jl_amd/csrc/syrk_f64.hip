@@ -393,6 +393,19 @@ __global__ __launch_bounds__(SY_THREADS) void tr_kernel(const double* __restrict
       }
     }
   };
+  // FAST: column block bb of the tile is FINAL after chunk bb (chunk kb only touches the blocks bb >= kb), so its four stores per
+  // lane go out during chunk bb + 1, behind that chunk's prefetch loads in program order (vmcnt retires in order: the loads never
+  // queue behind stores of their own chunk) -- the 327 KB of result stores that a workgroup, alone on its CU, used to issue after
+  // its last MFMA (16 of a block's 72 us) are spread over the block.  Same uniform-base + 32-bit-offset addressing as the loads.
+  const char* const Cb = reinterpret_cast<const char*>(C + r0);
+  const uint32_t c_voff = (uint32_t)(8 * ((int64_t)(16 * r + jl) + (int64_t)kk * ldc));   // FAST: fits (launcher: 3 ldc + 128 < 2^29)
+  const int64_t c_step = 8 * 4 * ldc;                                     // uniform: 4 columns on
+  auto store_block = [&](auto Bc) {
+    constexpr int b = decltype(Bc)::value;
+    const char* cb = Cb + (int64_t)(16 * b) * 8 * ldc;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) { *reinterpret_cast<double*>(const_cast<char*>(cb) + c_voff) = acc[b][reg]; cb += c_step; }
+  };
   using KB0 = std::integral_constant<int, 0>;
   using KB1 = std::integral_constant<int, 1>;
   prefetch(KB0{});
@@ -439,13 +452,20 @@ __global__ __launch_bounds__(SY_THREADS) void tr_kernel(const double* __restrict
         if (kb + 2 < nkb) prefetch(std::integral_constant<int, kb + 2>{});
         __builtin_amdgcn_s_setprio(1);
       }
+      if constexpr (FAST && kb >= 1) {
+        // half a chunk behind the staging chores (inside their low-priority section, right behind the prefetch loads: measured
+        // slower, 10.38 against 10.05 ms per thin QR of a 10^6 x 320 panel)
+        if (st == ((r & 4) ? 3 : 1)) store_block(std::integral_constant<int, kb - 1>{});   // final since the end of chunk kb - 1
+      }
     }
     __syncthreads();
   };
   sy_for_each(chunk, std::make_integer_sequence<int, NB>{});
   // lane holds D[i = kk + 4 reg][j = jl] = C[r0 + 16 r + jl][16 b + kk + 4 reg]
   const int64_t row = r0 + 16 * r + jl;
-  if (FAST || row < m) {
+  if constexpr (FAST) {
+    store_block(std::integral_constant<int, NB - 1>{});      // the others went out as they became final
+  } else if (row < m) {
     double* cp = C + row;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -469,7 +489,8 @@ static void tr_launch(hipStream_t st, int64_t m, int64_t l, const double* A, int
   // whole row blocks through the FAST instantiation (no clamps, 32-bit per-thread offsets); the last partial block, odd
   // sketch widths and leading dimensions beyond the 32-bit offsets through the general one
   static const bool no_fast = (getenv("GSI_TR_NO_FAST") != nullptr);
-  const bool fast_ok = !no_fast && (l == 16 * NB) && (3 * lda + TR_ROWS < ((int64_t)1 << 29)) && (31 * ldx + 16 < ((int64_t)1 << 29));
+  const bool fast_ok = !no_fast && (l == 16 * NB) && (3 * lda + TR_ROWS < ((int64_t)1 << 29)) && (31 * ldx + 16 < ((int64_t)1 << 29)) &&
+                       (3 * ldc + TR_ROWS < ((int64_t)1 << 29));
   const int64_t nfull = fast_ok ? m / TR_ROWS : 0, nblk = (m + TR_ROWS - 1) / TR_ROWS;
   if (nfull > 0)
     hipLaunchKernelGGL((tr_kernel<NB, true>), dim3((unsigned)nfull), dim3(SY_THREADS), shmem, st, A, lda, m, X, ldx, (int)l, C, ldc,

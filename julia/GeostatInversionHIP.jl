@@ -35,6 +35,9 @@ function check(status::Cint)
 		msg = unsafe_string(ccall((:gsi_last_error, libgsi), Cstring, ()))
 		# the reference raises ErrorException via error(...) (RandMatFact.jl:63, lowrank.jl:58)
 		status == 2 && error(msg)
+		# lu(Y) on an exactly zero pivot (RandMatFact.jl:60) and cholesky(Hermitian(B2)) of eig_nystrom (:95) throw these in the reference
+		status == 3 && throw(LinearAlgebra.SingularException(0))
+		status == 7 && throw(LinearAlgebra.PosDefException(0))
 		throw(GsiError(Int(status), msg))
 	end
 	return nothing
